@@ -1,0 +1,315 @@
+"""TEST INFRASTRUCTURE -- generate tests/golden/*.npz by running the REAL reference on CPU in this container.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_goldens
+
+Reads /root/reference (never copied, never shipped); writes only small input/output vectors.  The fixtures are
+data: seeded inputs, the reference's outputs for them, and (for tiny modules) the seeded weights the outputs
+belong to.  Each group below names the reference entry point it pins.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import configs, ref_harness
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def npf(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def sd_np(module, prefix=""):
+    return {prefix + k: npf(v) for k, v in module.state_dict().items()}
+
+
+def sd_hash(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def sample_idx(n, k=256, seed=7):
+    g = np.random.RandomState(seed)
+    return np.sort(g.choice(n, size=min(k, n), replace=False)).astype(np.int64)
+
+
+def summary(t, name, out, k=256):
+    f = t.detach().flatten()
+    idx = sample_idx(f.numel(), k)
+    out[f"{name}.idx"] = idx
+    out[f"{name}.val"] = npf(f[torch.from_numpy(idx)])
+    out[f"{name}.mean"] = np.float64(f.double().mean().item())
+    out[f"{name}.std"] = np.float64(f.double().std().item())
+    out[f"{name}.shape"] = np.array(t.shape, dtype=np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def gen_pe(R):
+    """PositionEncoding('pe_1.25_80','pi')  (model_blocks.py:108-126), fp32 and fp64 call forms."""
+    pe = R.model_blocks.PositionEncoding("pe_1.25_80", "pi")
+    idx = [0, 36, 131]
+    t64 = torch.tensor([(i + 1) / 132 for i in idx], dtype=torch.float64)
+    o32 = pe(t64[:, None].float()).view(len(idx), -1)                       # model_nerv.py:47-48
+    o64 = pe(t64[:, None]).float().view(len(idx), -1)                       # model_hnerv.py:241
+    xy = (torch.arange(16) / 16)[:, None]                                   # model_enerv.py:281-291
+    oxy = pe(xy).view(16, -1)
+    np.savez(os.path.join(OUT, "pe.npz"), t64=npf(t64), bases=npf(pe.pe_bases), out_f32=npf(o32), out_f64=npf(o64),
+             xy=npf(xy), out_xy=npf(oxy))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _grads(out, inputs, params, seed):
+    g = torch.Generator().manual_seed(seed)
+    cot = torch.randn(out.shape, generator=g)
+    gs = torch.autograd.grad(out, list(inputs) + list(params), cot, allow_unused=True)
+    return cot, gs
+
+
+def gen_blocks(R):
+    """Tiny-shape block goldens: SFTLayer, ResBlock_SFT, NeRVBlock(pshuffel_3x3, s in 1,2,3,5, k in 1,3), Conv_Up_Block,
+    OutImg, NeRV_MLP  (model_blocks.py:14-105, :57-71; model_enerv.py:73-102)."""
+    out = {}
+    args = configs.tiny_nerv()
+    mb = R.model_blocks
+
+    def run(name, module, x, z=None, seed=0):
+        x = x.clone().requires_grad_(True)
+        ins = [x]
+        if z is not None:
+            z = z.clone().requires_grad_(True)
+            ins.append(z)
+            y = module((x, z))
+        else:
+            y = module(x)
+        params = list(module.parameters())
+        cot, gs = _grads(y, ins, params, seed)
+        out[f"{name}/x"] = npf(x)
+        if z is not None:
+            out[f"{name}/z"] = npf(z)
+        out[f"{name}/y"] = npf(y)
+        out[f"{name}/cot"] = npf(cot)
+        out[f"{name}/dx"] = npf(gs[0])
+        if z is not None:
+            out[f"{name}/dz"] = npf(gs[1])
+        for (pn, _), g in zip(module.named_parameters(), gs[len(ins):]):
+            out[f"{name}/grad/{pn}"] = npf(g)
+        for k, v in sd_np(module).items():
+            out[f"{name}/sd/{k}"] = v
+
+    torch.manual_seed(11)
+    run("sft_c12", mb.SFTLayer(32, 12, 1, "relu", 1, args=args), torch.randn(2, 12, 10, 14), torch.randn(2, 32, 1, 1), 1)
+    torch.manual_seed(12)
+    run("tat_c15", mb.ResBlock_SFT(15, 15, cond_ch=32, in_act="relu", out_act="gelu", omega=1, args=args),
+        torch.randn(2, 15, 11, 13), torch.randn(2, 32, 1, 1), 2)
+    cases = [("blk_s1_k3_c12", 12, 12, 1, 3, (9, 20)), ("blk_s2_k3_c15_12", 15, 12, 2, 3, (7, 10)),
+             ("blk_s3_k3_c9_7", 9, 7, 3, 3, (5, 6)), ("blk_s5_k1_c30", 10, 10, 5, 1, (3, 4)),
+             ("blk_s2_k1_c20_33", 20, 33, 2, 1, (6, 9))]
+    for i, (name, ngf, new_ngf, s, k, hw) in enumerate(cases):
+        torch.manual_seed(20 + i)
+        blk = mb.NeRVBlock(dec_block=True, conv_type="pshuffel_3x3", ngf=ngf, new_ngf=new_ngf, ks=k, strd=s, bias=True,
+                           norm="none", act="sin", sft_ngf=32, args=args)
+        run(name, blk, torch.randn(2, ngf, *hw), torch.randn(2, 32, 1, 1), 30 + i)
+    torch.manual_seed(40)
+    cub = R.model_enerv.Conv_Up_Block(ngf=8, new_ngf=24, ks=3, stride=5, bias=True, norm="none", act="sin",
+                                      conv_type="pshuffel_3x3", sft_ngf=32, args=args)
+    run("conv_up_block", cub, torch.randn(2, 8, 3, 4), torch.randn(2, 32, 1, 1), 41)
+    # HNeRV decoder[0]: DownConv('conv', ks=0, strd=1) + sin + TAT at the embedding resolution (model_hnerv.py:200-202)
+    hargs = configs.tiny_hnerv()
+    torch.manual_seed(42)
+    d0 = mb.NeRVBlock(dec_block=False, conv_type="conv", ngf=4, new_ngf=10, ks=0, strd=1, bias=True, norm="none",
+                      act="sin", sft_ngf=32, args=hargs)
+    run("hnerv_dec0", d0, torch.randn(2, 4, 9, 16), torch.randn(2, 32, 1, 1), 43)
+    torch.manual_seed(44)
+    run("mlp_sin", mb.NeRV_MLP(dim_list=[160, 64, 32], bias=True, act="sin", omega=1, args=args), torch.randn(3, 160, 1, 1), None, 45)
+    # OutImg
+    x = torch.randn(2, 3, 5, 7)
+    out["outimg/x"] = npf(x)
+    out["outimg/y"] = npf(mb.OutImg(x, "tanh"))
+    np.savez_compressed(os.path.join(OUT, "blocks.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _model(R, args):
+    if args.model == "NeRV_Boost":
+        return R.model_nerv.NeRV_Boost(1, args=args)
+    if args.model == "ENeRV_Boost":
+        return R.model_enerv.ENeRV_Boost(3, args=args)
+    return R.model_hnerv.HNeRV_Boost(args)
+
+
+def gen_tiny_models(R):
+    """Whole tiny models, seeded init: full state_dict + forward samples + loss + every parameter gradient's norm
+    (model_nerv.py:45-61, model_enerv.py:279-317, model_hnerv.py:224-251; loss L1_freq hnerv_utils.py:378-385)."""
+    for name, args, hw in (("tiny_nerv", configs.tiny_nerv(), (180, 320)), ("tiny_enerv", configs.tiny_enerv(), (180, 320)),
+                           ("tiny_hnerv", configs.tiny_hnerv(), (180, 320))):
+        torch.manual_seed(1)
+        m = _model(R, args)
+        out = {f"sd/{k}": v for k, v in sd_np(m).items()}
+        out["sd_sha256"] = np.array(sd_hash(m.state_dict()))
+        g = torch.Generator().manual_seed(5)
+        frame = torch.rand(2, 3, *hw, generator=g)
+        norm_idx = torch.tensor([3 / 7, 6 / 7], dtype=torch.float64)
+        inp = frame if args.model == "HNeRV_Boost" else norm_idx
+        img, lst, _ = m(inp, norm_idx=norm_idx)
+        assert img.shape[-2:] == hw, img.shape
+        loss = R.hnerv_utils.loss_fn(img, frame, "L1_freq")
+        loss.backward()
+        out["frame_seed"] = np.int64(5)
+        out["norm_idx"] = npf(norm_idx)
+        summary(img, "img", out, 1024)
+        for i, t in enumerate(lst):
+            summary(t, f"list{i}", out, 128)
+        out["loss_L1_freq"] = np.float64(loss.item())
+        out["psnr"] = npf(R.hnerv_utils.psnr_fn_single(img.detach(), frame))
+        for pn, p in m.named_parameters():
+            out[f"gnorm/{pn}"] = np.float64(p.grad.double().norm().item()) if p.grad is not None else np.float64(-1)
+            if p.grad is not None and p.grad.numel() <= 4096:
+                out[f"grad/{pn}"] = npf(p.grad)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+
+
+def gen_full_models(R):
+    """Real BASELINE shapes, torch.manual_seed(1) construction: state_dict checksum (pins init ORDER), parameter count,
+    per-layer output summaries at one t, loss L1_freq and gradient norms.  C1 (NeRV-boost 1.5M 720p) only: the
+    1080p models take minutes and >10 GB on CPU; their init checksum and parameter counts are still recorded."""
+    out = {}
+    for name, args in (("c1", configs.c1()), ("c3", configs.c3()), ("c4", configs.c4())):
+        torch.manual_seed(1)
+        m = _model(R, args)
+        sd = m.state_dict()
+        out[f"{name}/sd_sha256"] = np.array(sd_hash(sd))
+        out[f"{name}/n_params"] = np.int64(sum(p.numel() for p in m.parameters()))
+        out[f"{name}/n_tensors"] = np.int64(len(sd))
+        out[f"{name}/keys"] = np.array(list(sd.keys()))
+        out[f"{name}/shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        first = next(iter(sd.values()))
+        out[f"{name}/first_vals"] = npf(first.flatten()[:8])
+        if name == "c1":
+            g = torch.Generator().manual_seed(5)
+            frame = torch.rand(1, 3, 720, 1280, generator=g)
+            norm_idx = torch.tensor([37 / 132], dtype=torch.float64)
+            img, lst, _ = m(norm_idx, norm_idx=norm_idx)
+            loss = R.hnerv_utils.loss_fn(img, frame, "L1_freq")
+            loss.backward()
+            summary(img, "c1/img", out, 2048)
+            for i, t in enumerate(lst):
+                summary(t, f"c1/list{i}", out, 128)
+            out["c1/loss_L1_freq"] = np.float64(loss.item())
+            out["c1/psnr"] = npf(R.hnerv_utils.psnr_fn_single(img.detach(), frame))
+            for pn, p in m.named_parameters():
+                out[f"c1/gnorm/{pn}"] = np.float64(p.grad.double().norm().item())
+    np.savez_compressed(os.path.join(OUT, "full_models.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def gen_loss(R):
+    """loss_fn variants and psnr_fn_single on seeded inputs (hnerv_utils.py:335-403).  Fusion10_freq goes through the
+    msssim_ref stand-in -> that entry is self-consistency only (PARITY UNPINNED)."""
+    out = {}
+    for tag, shape, seed in (("small", (2, 3, 176, 208), 3), ("odd", (1, 3, 180, 270), 4), ("720p", (1, 3, 720, 1280), 6)):
+        g = torch.Generator().manual_seed(seed)
+        tgt = torch.rand(shape, generator=g)
+        pred = (tgt + 0.1 * torch.randn(shape, generator=g)).clamp(0, 1).requires_grad_(True)
+        out[f"{tag}/shape"] = np.array(shape)
+        out[f"{tag}/seed"] = np.int64(seed)
+        if tag != "720p":
+            out[f"{tag}/pred"] = npf(pred).astype(np.float32)
+            out[f"{tag}/target"] = npf(tgt)
+        for lt in ("L1", "L2", "L1_freq", "Fusion10_freq"):
+            pred.grad = None
+            l = R.hnerv_utils.loss_fn(pred, tgt, lt)
+            l.backward()
+            out[f"{tag}/{lt}/loss"] = np.float64(l.item())
+            summary(pred.grad, f"{tag}/{lt}/grad", out, 512)
+        out[f"{tag}/psnr"] = npf(R.hnerv_utils.psnr_fn_single(pred.detach(), tgt))
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+
+
+def gen_optim(R):
+    """Adan 6-step trajectory on a 3-tensor toy problem with the train script's call form Adan(params, lr=...)
+    (train_nerv_all.py:264, optimizer.py:125-362); adjust_lr table (hnerv_utils.py:292-322)."""
+    out = {}
+    g = torch.Generator().manual_seed(9)
+    ps = [torch.randn(7, 5, generator=g), torch.randn(13, generator=g), torch.randn(2, 3, 3, 3, generator=g)]
+    params = [p.clone().requires_grad_(True) for p in ps]
+    opt = R.optimizer.Adan(params, lr=0.003)
+    for i, p in enumerate(ps):
+        out[f"p0/{i}"] = npf(p)
+    for step in range(6):
+        grads = [torch.randn(p.shape, generator=g) * (0.5 + step) for p in params]
+        for p, gr in zip(params, grads):
+            p.grad = gr.clone()
+        for group in opt.param_groups:
+            group["lr"] = 0.003 * (0.1 + 0.15 * step)
+        opt.step()
+        for i, (p, gr) in enumerate(zip(params, grads)):
+            out[f"g{step}/{i}"] = npf(gr)
+            out[f"p{step + 1}/{i}"] = npf(p)
+    import types
+    a = types.SimpleNamespace(lr_type="cosine_0.1_1_0.1", lr=0.003, epochs=300)
+
+    class _O:
+        param_groups = [{"lr": 0.0}]
+    xs = np.array([0.0, 0.01, 0.05, 0.0999, 0.1, 0.25, 0.5, 0.9, 0.999, 37.25 / 300.0])
+    out["lr/x"] = xs
+    out["lr/cosine"] = np.array([R.hnerv_utils.adjust_lr(_O, float(x), 0, a) for x in xs])
+    a.lr_type = "hybrid_0.2_1_2_0.1_0.05"
+    out["lr/hybrid"] = np.array([R.hnerv_utils.adjust_lr(_O, float(x), 0, a) for x in xs])
+    np.savez(os.path.join(OUT, "optim.npz"), **out)
+
+
+def gen_host(R):
+    """Host-side facts: fc_dim from the size solver (train_nerv_all.py:193-217 restated inline there -- no callable, so
+    the values recorded are those the reference's expression yields), data_split, quant_tensor, frame order of the
+    shuffled loader after model construction (train_nerv_all.py:155, :188-191, :222, :328)."""
+    out = {}
+    hu = R.hnerv_utils
+    tr, va = hu.data_split(list(range(20)), [6, 8, 10], False, 0)
+    out["split/train"], out["split/val"] = np.array(tr), np.array(va)
+    g = torch.Generator().manual_seed(2)
+    for i, t in enumerate((torch.randn(12, 12, 3, 3, generator=g), torch.randn(48, generator=g), torch.randn(256, 160, 1, 1, generator=g))):
+        q, new_t = hu.quant_tensor(t, 8)
+        out[f"quant/{i}/t"] = npf(t)
+        out[f"quant/{i}/q"] = npf(q["quant"])
+        out[f"quant/{i}/new"] = npf(new_t)
+    # frame order: same call sequence as train(): seeds -> loaders -> model -> iterate
+    import random
+    from torch.utils.data import DataLoader, Dataset, Subset
+
+    class _DS(Dataset):
+        def __len__(self): return 132
+        def __getitem__(self, i): return {"idx": i}
+    orders = []
+    torch.manual_seed(1); np.random.seed(1); random.seed(1)
+    full = _DS()
+    _ = DataLoader(full, batch_size=1, shuffle=False, num_workers=0)
+    tr_idx, _v = hu.data_split(list(range(132)), [1, 1, 1], False, 0)
+    dl = DataLoader(Subset(full, tr_idx), batch_size=1, shuffle=True, num_workers=0, drop_last=True)
+    _m = R.model_nerv.NeRV_Boost(1, args=configs.c1())
+    for _e in range(2):
+        orders.append([int(s["idx"][0]) for s in dl])
+    out["frame_order/c1"] = np.array(orders)
+    np.savez_compressed(os.path.join(OUT, "host.npz"), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    R = ref_harness.load_reference()
+    which = sys.argv[1:] or ["pe", "blocks", "tiny", "full", "loss", "optim", "host"]
+    fns = dict(pe=gen_pe, blocks=gen_blocks, tiny=gen_tiny_models, full=gen_full_models, loss=gen_loss, optim=gen_optim, host=gen_host)
+    for w in which:
+        print("generating", w, flush=True)
+        fns[w](R)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
