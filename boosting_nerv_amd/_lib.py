@@ -1,0 +1,151 @@
+"""ctypes binding of libbnerv_hip.so (include/bnerv.h).  The HIP extension is the ONLY compute path of this package:
+if the shared object is missing or a call fails, we raise -- there is no CPU / eager fallback."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbnerv_hip.so")
+
+MAX_DENSE_GROUPS = 40
+ADAN_MAX_TENSORS = 48
+SFT_CHUNKS = 32
+DENSE_DX_CHUNK = 64
+
+ACT_NONE, ACT_RELU, ACT_SIN = 0, 1, 2
+IN_PLAIN, IN_AFFINE, IN_GELU_AFFINE, IN_UNSHUFFLE, IN_TANHGRAD = 0, 1, 2, 3, 4
+EP_BIAS, EP_BIAS_SIN, EP_BIAS_RES, EP_BIAS_TANH, EP_PLAIN, EP_DGELU, EP_DSIN = 0, 1, 2, 3, 4, 5, 6
+
+_fp = C.c_void_p     # device pointers travel as void* (data_ptr())
+
+
+class DenseFwdDesc(C.Structure):
+    _fields_ = [("x", _fp), ("w", _fp), ("b", _fp), ("y", _fp), ("aux", _fp),
+                ("I", C.c_int), ("O", C.c_int), ("act", C.c_int), ("_pad", C.c_int)]
+
+
+class DenseBwdDesc(C.Structure):
+    _fields_ = [("x", _fp), ("w", _fp), ("y", _fp), ("aux", _fp), ("dy", _fp), ("dpre", _fp), ("dw", _fp), ("db", _fp),
+                ("dx_part", _fp), ("I", C.c_int), ("O", C.c_int), ("act", C.c_int), ("_pad", C.c_int)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("x", _fp), ("w", _fp), ("bias", _fp), ("out", _fp), ("out2", _fp), ("aux0", _fp), ("aux1", _fp),
+                ("aux2", _fp), ("scale", _fp), ("shift", _fp), ("partial", _fp),
+                ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("H", C.c_int), ("W", C.c_int), ("k", C.c_int),
+                ("in_mode", C.c_int), ("ep_mode", C.c_int), ("in_s", C.c_int), ("out_s", C.c_int),
+                ("transposed", C.c_int), ("wCo", C.c_int), ("wCi", C.c_int)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("x", _fp), ("g", _fp), ("gaux", _fp), ("scale", _fp), ("shift", _fp), ("dw", _fp), ("db", _fp),
+                ("ws", _fp), ("ws_bytes", C.c_size_t),
+                ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("H", C.c_int), ("W", C.c_int), ("k", C.c_int),
+                ("in_mode", C.c_int), ("g_mode", C.c_int), ("g_s", C.c_int)]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("pred", _fp), ("target", _fp), ("grad", _fp), ("loss_out", _fp), ("stats_out", _fp), ("ws", _fp),
+                ("ws_bytes", C.c_size_t), ("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("c_l1", C.c_float), ("c_l2", C.c_float), ("c_ms", C.c_float), ("c_fft", C.c_float)]
+
+
+class AdanChunk(C.Structure):
+    _fields_ = [("p", _fp * ADAN_MAX_TENSORS), ("g", _fp * ADAN_MAX_TENSORS), ("exp_avg", _fp * ADAN_MAX_TENSORS),
+                ("exp_avg_sq", _fp * ADAN_MAX_TENSORS), ("exp_avg_diff", _fp * ADAN_MAX_TENSORS),
+                ("neg_pre_grad", _fp * ADAN_MAX_TENSORS), ("n", C.c_int * ADAN_MAX_TENSORS), ("n_tensors", C.c_int)]
+
+
+class AdanHyper(C.Structure):
+    _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("beta3", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("clip_global_grad_norm", C.c_float), ("no_prox", C.c_int),
+                ("sched_dev", _fp)]
+
+
+class BucketChunk(C.Structure):
+    _fields_ = [("t", _fp * (ADAN_MAX_TENSORS * 2)), ("n", C.c_int * (ADAN_MAX_TENSORS * 2)),
+                ("off", C.c_int * (ADAN_MAX_TENSORS * 2)), ("n_tensors", C.c_int)]
+
+
+# every symbol include/bnerv.h declares: name -> (restype, argtypes)
+_I, _Z, _V, _F = C.c_int, C.c_size_t, C.c_void_p, C.c_float
+SYMBOLS = {
+    "bnerv_abi_version": (_I, []),
+    "bnerv_last_error": (C.c_char_p, []),
+    "bnerv_build_arch": (C.c_char_p, []),
+    "bnerv_pe_fwd_f32": (_I, [_V, _V, _V, _V, _I, _I]),
+    "bnerv_pe_fwd_f64": (_I, [_V, _V, _V, _V, _I, _I]),
+    "bnerv_dense_grouped_fwd": (_I, [_V, C.POINTER(DenseFwdDesc), _I, _I]),
+    "bnerv_dense_grouped_bwd": (_I, [_V, C.POINTER(DenseBwdDesc), _I, _I]),
+    "bnerv_sft_affine_fwd": (_I, [_V, _V, _V, _V, _V, _I, _I, _I]),
+    "bnerv_sft_affine_bwd": (_I, [_V, _V, _V, _V, _V, _V, _I, _I, _I]),
+    "bnerv_reduce_slabs": (_I, [_V, _V, _I, _I, _V]),
+    "bnerv_conv_tiles": (_I, [_I, _I]),
+    "bnerv_conv_igemm": (_I, [_V, C.POINTER(ConvDesc)]),
+    "bnerv_conv_wgrad_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "bnerv_conv_wgrad": (_I, [_V, C.POINTER(WgradDesc)]),
+    "bnerv_loss_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "bnerv_fft_prepare": (_I, [_I, _I]),
+    "bnerv_loss_fwd_bwd": (_I, [_V, C.POINTER(LossDesc)]),
+    "bnerv_msssim": (_I, [_V, _V, _V, _V, _V, _Z, _I, _I, _I, _I]),
+    "bnerv_psnr_ws_bytes": (_Z, [_I, _I, _I, _I]),
+    "bnerv_psnr": (_I, [_V, _V, _V, _V, _V, _Z, _I, _I, _I, _I]),
+    "bnerv_adan_multi_tensor": (_I, [_V, C.POINTER(AdanChunk), C.POINTER(AdanHyper)]),
+    "bnerv_bucket_gather": (_I, [_V, C.POINTER(BucketChunk), _V, _F]),
+    "bnerv_bucket_scatter": (_I, [_V, C.POINTER(BucketChunk), _V, _F]),
+}
+
+_lib = None
+
+
+class BnervError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared object (once) and bind every symbol.  Raises if the library is missing: the HIP path is the
+    product, there is nothing to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise BnervError(f"{LIB_PATH} not found -- build it with boosting_nerv_amd/csrc/build.sh "
+                         f"(or `python -c 'import __graft_entry__ as g; g.build()'`)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    if lib.bnerv_abi_version() != 1:
+        raise BnervError(f"ABI version mismatch: {lib.bnerv_abi_version()}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().bnerv_last_error().decode("utf-8", "replace")
+        raise BnervError(f"{what} failed (rc={rc}): {msg}")
+
+
+def require_device(t, name="tensor"):
+    """The decoder path runs only on a ROCm device; fail loudly rather than silently computing elsewhere."""
+    if not t.is_cuda:
+        raise BnervError(f"{name} is on {t.device}: the bnerv HIP path needs a ROCm GPU tensor (no CPU fallback exists)")
+    return t
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32c(t):
+    """contiguous fp32 view/copy (plumbing: kernels require dense NCHW fp32)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()

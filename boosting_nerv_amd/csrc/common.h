@@ -1,0 +1,50 @@
+// common.h -- shared helpers for the bnerv gfx950 kernels (error reporting, math, wave reductions).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/bnerv.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+int bnerv_set_error(int code, const char* fmt, ...);
+
+#define BNERV_REQUIRE(cond, ...)                                  \
+    do {                                                          \
+        if (!(cond)) return bnerv_set_error(BNERV_E_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define BNERV_LAUNCH_CHECK(name)                                                        \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess) return bnerv_set_error(BNERV_E_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device math (accurate forms; never the __sinf/__expf fast intrinsics) ----
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- wave64 / block reductions ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// XCD-aware remap of a 1-D block index: blocks that the dispatcher places on the same XCD (b % 8) get a contiguous
+// range of logical indices, so neighbouring tiles (which share halo rows) share one L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int orig, int n) {
+    const int xcd = orig & 7, q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}

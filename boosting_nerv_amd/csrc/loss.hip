@@ -1,0 +1,783 @@
+// loss.hip -- the high-frequency reconstruction loss of Boosting-NeRV, value AND gradient in one call.
+//
+// Replaces hnerv_utils.loss_fn (hnerv_utils.py:335-397) + its autograd backward, psnr_fn_single (:400-403) and the
+// MS-SSIM metric (:410-412):
+//     loss_b = c_l1*mean|d| + c_l2*mean d^2 + c_ms*(1 - ms_ssim_b) + c_fft*mean(|Re F(d)| + |Im F(d)|)/1 ,  d = pred - target
+// (the reference takes FFT2(pred) - FFT2(target); the DFT is linear, so F(d) is the same quantity with ONE transform).
+//
+// Kernels (all HBM-streaming; no MFMA -- none of this is a GEMM):
+//   diff_stats      sum|d|, sum d^2 per sample                                     (L1, L2, PSNR)
+//   avgpool2        the MS-SSIM pyramid (2x2 mean, padding = size%2), pred and target together
+//   ssim_fwd        per level: 11-tap separable Gaussian statistics in LDS -> per-tile sums of cs (levels 0-3) / ssim (4)
+//   ms_coef         ms_ssim per (b,c) and d(loss)/d(level statistic)
+//   ssim_bwd        per level, coarse -> fine: recompute the statistics for a haloed tile, differentiate, apply the adjoint
+//                   Gaussian, add the upsampled coarser-level gradient; level 0 also adds the L1/L2 terms and writes `grad`
+//   fft_rows_fwd    in-place mixed-radix DIF FFT of every row in LDS (digit-reversed output order -- irrelevant, see below)
+//   fft_cols        column DIF FFT, sum(|Re|+|Im|), S = sign(F), then the ADJOINT transform of S, all in LDS
+//   fft_rows_adj    adjoint row transform, real part, accumulated into `grad`
+// The forward FFT leaves its output digit-reversed; the L1 norm does not care about order and the adjoint network is the
+// exact transpose-conjugate of the forward network, so no reordering pass exists anywhere.
+//
+// MS-SSIM follows pytorch_msssim 0.2.1 (third-party; PARITY UNPINNED).
+#include "common.h"
+#include <math.h>
+#include <map>
+#include <mutex>
+
+namespace {
+
+// =====================================================================================================================
+// L1 / L2 statistics
+// =====================================================================================================================
+constexpr int NSB = 64;   // partial blocks per sample
+
+__global__ __launch_bounds__(256) void diff_stats_kernel(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ part, int n_per_sample) {
+    const int b = blockIdx.y;
+    const float* pp = p + (size_t)b * n_per_sample;
+    const float* tt = t + (size_t)b * n_per_sample;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_per_sample; i += NSB * 256) {
+        const float d = pp[i] - tt[i];
+        s1 += fabsf(d);
+        s2 = fmaf(d, d, s2);
+    }
+    __shared__ float red[2][4];
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        part[((size_t)b * NSB + blockIdx.x) * 2 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    }
+}
+
+__global__ void psnr_final_kernel(const float* __restrict__ part, float* __restrict__ psnr, int B, int n_per_sample) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s2 = 0.0;
+    for (int k = 0; k < NSB; ++k) s2 += (double)part[((size_t)b * NSB + k) * 2 + 1];
+    const float mse = (float)(s2 / (double)n_per_sample);
+    psnr[b] = -10.0f * log10f(mse + 1e-9f);
+}
+
+// grad = k1*sign(d) + k2*d     (losses without the MS-SSIM term)
+__global__ void grad_l1l2_kernel(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ g, size_t n, float k1, float k2) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = p[i] - t[i];
+        const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+        g[i] = k1 * sg + k2 * d;
+    }
+}
+
+// =====================================================================================================================
+// MS-SSIM
+// =====================================================================================================================
+constexpr int LV = BNERV_MSSSIM_LEVELS;
+constexpr int WS_ = 11, HW_ = 10;           // window size, window size - 1
+constexpr int STH = 16, STW = 32;           // ssim tile
+
+struct Win { float g[WS_]; };
+
+struct Pyr { int H[LV], W[LV]; };
+
+static Pyr make_pyr(int H, int W) {
+    Pyr p;
+    p.H[0] = H; p.W[0] = W;
+    for (int l = 1; l < LV; ++l) {
+        const int ph = p.H[l - 1] % 2, pw = p.W[l - 1] % 2;
+        p.H[l] = (p.H[l - 1] + 2 * ph - 2) / 2 + 1;
+        p.W[l] = (p.W[l - 1] + 2 * pw - 2) / 2 + 1;
+    }
+    return p;
+}
+
+static Win make_win() {
+    // exactly pytorch_msssim._fspecial_gauss_1d in fp32: g = exp(-(x-5)^2 / (2*1.5^2)); g /= g.sum()
+    Win w;
+    float s = 0.f;
+    for (int i = 0; i < WS_; ++i) {
+        const float c = (float)(i - WS_ / 2);
+        w.g[i] = expf(-(c * c) / (2.0f * 1.5f * 1.5f));
+        s += w.g[i];
+    }
+    for (int i = 0; i < WS_; ++i) w.g[i] /= s;
+    return w;
+}
+
+// 2x2 mean pool with zero padding (ph, pw), count_include_pad=True; two images per launch (blockIdx.z selects)
+__global__ void avgpool2_kernel(const float* __restrict__ x0, const float* __restrict__ x1, float* __restrict__ y0, float* __restrict__ y1,
+                                int planes, int H, int W, int Ho, int Wo, int ph, int pw) {
+    const float* x = blockIdx.z ? x1 : x0;
+    float* y = blockIdx.z ? y1 : y0;
+    const size_t n = (size_t)planes * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int ox = (int)(i % Wo);
+        const size_t r = i / Wo;
+        const int oy = (int)(r % Ho);
+        const size_t pl = r / Ho;
+        const int iy = 2 * oy - ph, ix = 2 * ox - pw;
+        const float* xp = x + pl * H * W;
+        float s = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int yy = iy + dy, xx = ix + dx;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) s += xp[(size_t)yy * W + xx];
+            }
+        y[i] = 0.25f * s;
+    }
+}
+
+struct SsimArgs {
+    const float* X; const float* Y;
+    float* partial;            // fwd: [BC][tiles]
+    const float* coef;         // bwd: [BC] for this level (already includes 1/Nvalid and the loss chain)
+    const float* dcoarse;      // bwd: [BC][Hc][Wc] gradient wrt the next (coarser) level's pooled image, or NULL
+    float* dX;                 // bwd: [BC][H][W] written
+    int H, W, Hc, Wc, ph, pw;  // ph/pw: padding used when pooling THIS level into the coarser one
+    int tiles_x, tiles_y;
+    float C1, C2;
+    float k_l1, k_l2;          // level 0 only: extra terms k_l1*sign(d) + k_l2*d
+    Win win;
+};
+
+// ---- forward: per-tile sum of cs (LAST=false) or ssim (LAST=true) over the valid region ----
+template <bool LAST>
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(const SsimArgs a) {
+    constexpr int WH = STH + HW_, WW = STW + HW_;        // 26 x 42 input window
+    __shared__ float sX[WH][WW], sY[WH][WW];
+    __shared__ float sV[5][STH][WW];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, bc = blockIdx.z;
+    const int oy0 = blockIdx.y * STH, ox0 = blockIdx.x * STW;
+    const float* X = a.X + (size_t)bc * a.H * a.W;
+    const float* Y = a.Y + (size_t)bc * a.H * a.W;
+    for (int i = tid; i < WH * WW; i += 256) {
+        const int r = i / WW, c = i - r * WW;
+        const int y = oy0 + r, x = ox0 + c;
+        const bool in = y < a.H && x < a.W;
+        sX[r][c] = in ? X[(size_t)y * a.W + x] : 0.f;
+        sY[r][c] = in ? Y[(size_t)y * a.W + x] : 0.f;
+    }
+    __syncthreads();
+    // vertical (along H) first, as the reference filters dim 2 then dim 3
+    for (int i = tid; i < STH * WW; i += 256) {
+        const int r = i / WW, c = i - r * WW;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WS_; ++k) {
+            const float g = a.win.g[k], x = sX[r + k][c], y = sY[r + k][c];
+            v0 = fmaf(g, x, v0); v1 = fmaf(g, y, v1); v2 = fmaf(g, x * x, v2); v3 = fmaf(g, y * y, v3); v4 = fmaf(g, x * y, v4);
+        }
+        sV[0][r][c] = v0; sV[1][r][c] = v1; sV[2][r][c] = v2; sV[3][r][c] = v3; sV[4][r][c] = v4;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    const int Hv = a.H - HW_, Wv = a.W - HW_;
+    for (int i = tid; i < STH * STW; i += 256) {
+        const int r = i / STW, c = i - r * STW;
+        float m1 = 0.f, m2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+#pragma unroll
+        for (int k = 0; k < WS_; ++k) {
+            const float g = a.win.g[k];
+            m1 = fmaf(g, sV[0][r][c + k], m1); m2 = fmaf(g, sV[1][r][c + k], m2);
+            exx = fmaf(g, sV[2][r][c + k], exx); eyy = fmaf(g, sV[3][r][c + k], eyy); exy = fmaf(g, sV[4][r][c + k], exy);
+        }
+        if (oy0 + r < Hv && ox0 + c < Wv) {
+            const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+            const float s1 = exx - m11, s2 = eyy - m22, s12 = exy - m12;
+            const float cs = (2.f * s12 + a.C2) / (s1 + s2 + a.C2);
+            if (LAST) acc += ((2.f * m12 + a.C1) / (m11 + m22 + a.C1)) * cs;
+            else acc += cs;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) a.partial[(size_t)bc * (a.tiles_x * a.tiles_y) + blockIdx.y * a.tiles_x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- ms_ssim per (b,c) and the chain coefficients; one block (5 waves) per (b,c) ----
+struct CoefArgs {
+    const float* partial[LV];   // [BC][tiles_l]
+    int tiles[LV];
+    float inv_nvalid[LV];
+    float weights[LV];
+    float* msval;               // [BC]
+    float* coef;                // [LV][BC]
+    int BC;
+    float chain;                // -c_ms / (B*C)
+};
+__global__ __launch_bounds__(320) void ms_coef_kernel(const CoefArgs a) {
+    const int bc = blockIdx.x, lane = threadIdx.x & 63, l = threadIdx.x >> 6;
+    __shared__ float stat[LV];
+    double s = 0.0;
+    for (int i = lane; i < a.tiles[l]; i += 64) s += (double)a.partial[l][(size_t)bc * a.tiles[l] + i];
+    s = wave_sum_d(s);
+    if (lane == 0) stat[l] = (float)(s * (double)a.inv_nvalid[l]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float P = 1.f;
+        for (int k = 0; k < LV; ++k) P *= powf(fmaxf(stat[k], 0.f), a.weights[k]);
+        a.msval[bc] = P;
+        for (int k = 0; k < LV; ++k)
+            a.coef[(size_t)k * a.BC + bc] = stat[k] > 0.f ? a.chain * a.weights[k] * (P / stat[k]) * a.inv_nvalid[k] : 0.f;
+    }
+}
+
+// ---- backward for one level ----
+template <bool LAST, bool LEVEL0>
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(const SsimArgs a) {
+    constexpr int GH = STH + HW_, GW = STW + HW_;        // 26 x 42 statistic-gradient region
+    constexpr int WH = GH + HW_, WW = GW + HW_;          // 36 x 52 input window
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float (*sX)[WW] = reinterpret_cast<float (*)[WW]>(sm);
+    float (*sY)[WW] = reinterpret_cast<float (*)[WW]>(sm + WH * WW);
+    float* sVb = sm + 2 * WH * WW;                       // [5][GH][WW], later reused as sA [3][STH][GW]
+    float* sGb = sVb + 5 * GH * WW;                      // [3][GH][GW]
+    const int tid = threadIdx.x, bc = blockIdx.z;
+    const int py0 = blockIdx.y * STH, px0 = blockIdx.x * STW;
+    const int wy0 = py0 - HW_, wx0 = px0 - HW_;
+    const float* X = a.X + (size_t)bc * a.H * a.W;
+    const float* Y = a.Y + (size_t)bc * a.H * a.W;
+    for (int i = tid; i < WH * WW; i += 256) {
+        const int r = i / WW, c = i - r * WW;
+        const int y = wy0 + r, x = wx0 + c;
+        const bool in = y >= 0 && y < a.H && x >= 0 && x < a.W;
+        sX[r][c] = in ? X[(size_t)y * a.W + x] : 0.f;
+        sY[r][c] = in ? Y[(size_t)y * a.W + x] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < GH * WW; i += 256) {
+        const int r = i / WW, c = i - r * WW;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WS_; ++k) {
+            const float g = a.win.g[k], x = sX[r + k][c], y = sY[r + k][c];
+            v0 = fmaf(g, x, v0); v1 = fmaf(g, y, v1); v2 = fmaf(g, x * x, v2); v3 = fmaf(g, y * y, v3); v4 = fmaf(g, x * y, v4);
+        }
+        sVb[(0 * GH + r) * WW + c] = v0; sVb[(1 * GH + r) * WW + c] = v1; sVb[(2 * GH + r) * WW + c] = v2;
+        sVb[(3 * GH + r) * WW + c] = v3; sVb[(4 * GH + r) * WW + c] = v4;
+    }
+    __syncthreads();
+    const int Hv = a.H - HW_, Wv = a.W - HW_;
+    const float coef = a.coef[bc];
+    for (int i = tid; i < GH * GW; i += 256) {
+        const int r = i / GW, c = i - r * GW;
+        const int oy = wy0 + r, ox = wx0 + c;
+        float gm = 0.f, gxx = 0.f, gxy = 0.f;
+        if (oy >= 0 && oy < Hv && ox >= 0 && ox < Wv) {
+            float m1 = 0.f, m2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+#pragma unroll
+            for (int k = 0; k < WS_; ++k) {
+                const float g = a.win.g[k];
+                m1 = fmaf(g, sVb[(0 * GH + r) * WW + c + k], m1); m2 = fmaf(g, sVb[(1 * GH + r) * WW + c + k], m2);
+                exx = fmaf(g, sVb[(2 * GH + r) * WW + c + k], exx); eyy = fmaf(g, sVb[(3 * GH + r) * WW + c + k], eyy);
+                exy = fmaf(g, sVb[(4 * GH + r) * WW + c + k], exy);
+            }
+            const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+            const float B2 = (exx - m11) + (eyy - m22) + a.C2;
+            const float cs = (2.f * (exy - m12) + a.C2) / B2;
+            float dm = (2.f / B2) * (m1 * cs - m2), dxx = -cs / B2, dxy = 2.f / B2;
+            if (LAST) {
+                const float B1 = m11 + m22 + a.C1;
+                const float lum = (2.f * m12 + a.C1) / B1;
+                dm = (2.f / B1) * (m2 - m1 * lum) * cs + lum * dm;
+                dxx *= lum; dxy *= lum;
+            }
+            gm = coef * dm; gxx = coef * dxx; gxy = coef * dxy;
+        }
+        sGb[(0 * GH + r) * GW + c] = gm; sGb[(1 * GH + r) * GW + c] = gxx; sGb[(2 * GH + r) * GW + c] = gxy;
+    }
+    __syncthreads();
+    float* sA = sVb;   // [3][STH][GW]
+    for (int i = tid; i < STH * GW; i += 256) {
+        const int r = i / GW, c = i - r * GW;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WS_; ++k) {
+            const float g = a.win.g[k];
+            a0 = fmaf(g, sGb[(0 * GH + r + HW_ - k) * GW + c], a0);
+            a1 = fmaf(g, sGb[(1 * GH + r + HW_ - k) * GW + c], a1);
+            a2 = fmaf(g, sGb[(2 * GH + r + HW_ - k) * GW + c], a2);
+        }
+        sA[(0 * STH + r) * GW + c] = a0; sA[(1 * STH + r) * GW + c] = a1; sA[(2 * STH + r) * GW + c] = a2;
+    }
+    __syncthreads();
+    for (int i = tid; i < STH * STW; i += 256) {
+        const int r = i / STW, c = i - r * STW;
+        const int y = py0 + r, x = px0 + c;
+        if (y >= a.H || x >= a.W) continue;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WS_; ++k) {
+            const float g = a.win.g[k];
+            a0 = fmaf(g, sA[(0 * STH + r) * GW + c + HW_ - k], a0);
+            a1 = fmaf(g, sA[(1 * STH + r) * GW + c + HW_ - k], a1);
+            a2 = fmaf(g, sA[(2 * STH + r) * GW + c + HW_ - k], a2);
+        }
+        const float xv = sX[r + HW_][c + HW_], yv = sY[r + HW_][c + HW_];
+        float d = a0 + 2.f * xv * a1 + yv * a2;
+        if (!LAST && a.dcoarse) d += 0.25f * a.dcoarse[((size_t)bc * a.Hc + (y + a.ph) / 2) * a.Wc + (x + a.pw) / 2];
+        if (LEVEL0) {
+            const float df = xv - yv;
+            const float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+            d += a.k_l1 * sg + a.k_l2 * df;
+        }
+        a.dX[((size_t)bc * a.H + y) * a.W + x] = d;
+    }
+}
+constexpr size_t SSIM_BWD_LDS = (size_t)(2 * 36 * 52 + 5 * 26 * 52 + 3 * 26 * 42) * sizeof(float);
+
+// =====================================================================================================================
+// mixed-radix FFT in LDS
+// =====================================================================================================================
+constexpr int MAXRAD = 16;
+struct FftPlan { int N, nrad; int rad[MAXRAD]; const float2* tw; };   // tw[k] = exp(-2*pi*i*k/N)
+
+std::mutex g_tw_mutex;
+std::map<int, float2*> g_tw;
+
+static const float2* get_twiddles(int N) {
+    std::lock_guard<std::mutex> lk(g_tw_mutex);
+    auto it = g_tw.find(N);
+    if (it != g_tw.end()) return it->second;
+    float2* h = (float2*)malloc(sizeof(float2) * N);
+    for (int k = 0; k < N; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / (double)N;
+        h[k].x = (float)cos(ang);
+        h[k].y = (float)sin(ang);
+    }
+    float2* d = nullptr;
+    if (hipMalloc(&d, sizeof(float2) * N) != hipSuccess) { free(h); return nullptr; }
+    if (hipMemcpy(d, h, sizeof(float2) * N, hipMemcpyHostToDevice) != hipSuccess) { free(h); return nullptr; }
+    free(h);
+    g_tw[N] = d;
+    return d;
+}
+
+static bool make_plan(int N, FftPlan* p) {
+    p->N = N; p->nrad = 0;
+    int n = N;
+    auto push = [&](int r) { if (p->nrad < MAXRAD) p->rad[p->nrad++] = r; };
+    while (n % 4 == 0) { push(4); n /= 4; }
+    while (n % 2 == 0) { push(2); n /= 2; }
+    while (n % 3 == 0) { push(3); n /= 3; }
+    while (n % 5 == 0) { push(5); n /= 5; }
+    for (int r = 7; r <= BNERV_FFT_MAX_RADIX && n > 1; r += 2)
+        while (n % r == 0) { push(r); n /= r; }
+    if (n != 1 || p->nrad >= MAXRAD) return false;
+    if (N == 1) { p->nrad = 0; }
+    p->tw = get_twiddles(N);
+    return p->tw != nullptr;
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return float2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return float2{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }   // a * conj(b)
+
+// One butterfly of radix R at sub-transform size Ns (M = Ns/R) on the in-place buffer.
+//  forward (DIF):  y_q = w_Ns^{jq} * sum_m x_m w_R^{mq}             x_m = buf[base+m*M], y_q -> buf[base+q*M]
+//  adjoint      :  x_m = sum_q conj(w_R^{mq}) conj(w_Ns^{jq}) y_q   (exact conjugate transpose of the forward stage)
+template <int R, bool ADJ>
+__device__ __forceinline__ void butterfly(float2* buf, int base, int M, int j, int tstride /* N/Ns */, const FftPlan& pl) {
+    float2 v[R], o[R], wr[R];
+    const int rstep = pl.N / R;
+#pragma unroll
+    for (int k = 0; k < R; ++k) wr[k] = pl.tw[rstep * k];
+#pragma unroll
+    for (int m = 0; m < R; ++m) v[m] = buf[base + m * M];
+    if (ADJ) {
+#pragma unroll
+        for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], pl.tw[(int)(((long long)tstride * j * q) % pl.N)]);
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        float2 s = v[0];
+#pragma unroll
+        for (int m = 1; m < R; ++m) s = ADJ ? float2{s.x + cmulc(v[m], wr[(m * q) % R]).x, s.y + cmulc(v[m], wr[(m * q) % R]).y}
+                                            : float2{s.x + cmul(v[m], wr[(m * q) % R]).x, s.y + cmul(v[m], wr[(m * q) % R]).y};
+        o[q] = s;
+    }
+    if (!ADJ) {
+#pragma unroll
+        for (int q = 1; q < R; ++q) o[q] = cmul(o[q], pl.tw[(int)(((long long)tstride * j * q) % pl.N)]);
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) buf[base + q * M] = o[q];
+}
+
+// generic radix (primes 7..31): O(R^2) with the table, operands staged in registers one output at a time
+template <bool ADJ>
+__device__ void butterfly_generic(float2* buf, int base, int M, int j, int tstride, int R, const FftPlan& pl) {
+    float2 v[BNERV_FFT_MAX_RADIX], o[BNERV_FFT_MAX_RADIX];
+    const int rstep = pl.N / R;
+    for (int m = 0; m < R; ++m) {
+        v[m] = buf[base + m * M];
+        if (ADJ && m) v[m] = cmulc(v[m], pl.tw[(int)(((long long)tstride * j * m) % pl.N)]);
+    }
+    for (int q = 0; q < R; ++q) {
+        float2 s = v[0];
+        for (int m = 1; m < R; ++m) {
+            const float2 w = pl.tw[rstep * ((m * q) % R)];
+            const float2 t = ADJ ? cmulc(v[m], w) : cmul(v[m], w);
+            s.x += t.x; s.y += t.y;
+        }
+        if (!ADJ && q) s = cmul(s, pl.tw[(int)(((long long)tstride * j * q) % pl.N)]);
+        o[q] = s;
+    }
+    for (int q = 0; q < R; ++q) buf[base + q * M] = o[q];
+}
+
+template <bool ADJ>
+__device__ void fft_stage(float2* buf, int nlines, int lstride, int Ns, int R, const FftPlan& pl) {
+    const int N = pl.N, M = Ns / R, per_line = N / R, tstride = N / Ns;
+    for (int bf = threadIdx.x; bf < nlines * per_line; bf += blockDim.x) {
+        const int line = bf / per_line, rem = bf - line * per_line;
+        const int blk = rem / M, j = rem - blk * M;
+        const int base = line * lstride + blk * Ns + j;
+        switch (R) {
+            case 2: butterfly<2, ADJ>(buf, base, M, j, tstride, pl); break;
+            case 3: butterfly<3, ADJ>(buf, base, M, j, tstride, pl); break;
+            case 4: butterfly<4, ADJ>(buf, base, M, j, tstride, pl); break;
+            case 5: butterfly<5, ADJ>(buf, base, M, j, tstride, pl); break;
+            default: butterfly_generic<ADJ>(buf, base, M, j, tstride, R, pl); break;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ void fft_forward(float2* buf, int nlines, int lstride, const FftPlan& pl) {
+    int Ns = pl.N;
+    for (int s = 0; s < pl.nrad; ++s) { fft_stage<false>(buf, nlines, lstride, Ns, pl.rad[s], pl); Ns /= pl.rad[s]; }
+}
+__device__ void fft_adjoint(float2* buf, int nlines, int lstride, const FftPlan& pl) {
+    int Ns = 1;
+    for (int s = pl.nrad - 1; s >= 0; --s) { Ns *= pl.rad[s]; fft_stage<true>(buf, nlines, lstride, Ns, pl.rad[s], pl); }
+}
+
+constexpr int ROWS_PER_BLOCK = 2;
+constexpr int COLS_PER_BLOCK = 8;
+
+struct FftArgs {
+    const float* pred; const float* target;
+    float2* T;            // [BC][H][W] complex workspace
+    float* partial;       // [BC][ncolblk]
+    float* grad;          // [BC][H][W]
+    int BC, H, W;
+    float gscale;         // c_fft / (B*C*H*W*2)
+    int accumulate;       // rows_adj: grad += (1) or grad = (0)
+    FftPlan prow, pcol;
+};
+
+__global__ __launch_bounds__(256) void fft_rows_fwd_kernel(const FftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float2* buf = reinterpret_cast<float2*>(sm);
+    const int W = a.W;
+    const size_t row0 = (size_t)blockIdx.x * ROWS_PER_BLOCK;            // global row index over BC*H
+    const size_t nrows = (size_t)a.BC * a.H;
+    const int nl = (int)min((size_t)ROWS_PER_BLOCK, nrows - row0);
+    for (int i = threadIdx.x; i < nl * W; i += blockDim.x) {
+        const size_t g = row0 * W + i;
+        buf[i] = float2{a.pred[g] - a.target[g], 0.f};
+    }
+    __syncthreads();
+    fft_forward(buf, nl, W, a.prow);
+    for (int i = threadIdx.x; i < nl * W; i += blockDim.x) a.T[row0 * W + i] = buf[i];
+}
+
+__global__ __launch_bounds__(256) void fft_cols_kernel(const FftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float2* buf = reinterpret_cast<float2*>(sm);                          // [COLS_PER_BLOCK][H]
+    __shared__ float red[4];
+    const int H = a.H, W = a.W, bc = blockIdx.y;
+    const int v0 = blockIdx.x * COLS_PER_BLOCK;
+    const int nc = min(COLS_PER_BLOCK, W - v0);
+    float2* T = a.T + (size_t)bc * H * W;
+    for (int i = threadIdx.x; i < H * nc; i += blockDim.x) {
+        const int y = i / nc, c = i - y * nc;
+        buf[c * H + y] = T[(size_t)y * W + v0 + c];
+    }
+    __syncthreads();
+    fft_forward(buf, nc, H, a.pcol);
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < H * nc; i += blockDim.x) {
+        const float2 f = buf[i];           // lines are contiguous: nc*H elements
+        acc += fabsf(f.x) + fabsf(f.y);
+        buf[i] = float2{(f.x > 0.f) ? 1.f : ((f.x < 0.f) ? -1.f : 0.f), (f.y > 0.f) ? 1.f : ((f.y < 0.f) ? -1.f : 0.f)};
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) a.partial[(size_t)bc * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (a.grad == nullptr) return;
+    fft_adjoint(buf, nc, H, a.pcol);
+    for (int i = threadIdx.x; i < H * nc; i += blockDim.x) {
+        const int y = i / nc, c = i - y * nc;
+        T[(size_t)y * W + v0 + c] = buf[c * H + y];
+    }
+}
+
+__global__ __launch_bounds__(256) void fft_rows_adj_kernel(const FftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float2* buf = reinterpret_cast<float2*>(sm);
+    const int W = a.W;
+    const size_t row0 = (size_t)blockIdx.x * ROWS_PER_BLOCK;
+    const size_t nrows = (size_t)a.BC * a.H;
+    const int nl = (int)min((size_t)ROWS_PER_BLOCK, nrows - row0);
+    for (int i = threadIdx.x; i < nl * W; i += blockDim.x) buf[i] = a.T[row0 * W + i];
+    __syncthreads();
+    fft_adjoint(buf, nl, W, a.prow);
+    for (int i = threadIdx.x; i < nl * W; i += blockDim.x) {
+        const size_t g = row0 * W + i;
+        const float v = a.gscale * buf[i].x;
+        a.grad[g] = a.accumulate ? a.grad[g] + v : v;
+    }
+}
+
+// =====================================================================================================================
+// final combine: per-sample loss, batch mean, stats
+// =====================================================================================================================
+struct FinalArgs {
+    const float* stats_part;   // [B][NSB][2]
+    const float* msval;        // [BC] or NULL
+    const float* fft_part;     // [BC][ncolblk] or NULL
+    float* loss_out; float* stats_out;
+    int B, C, n_per_sample, ncolblk;
+    float c_l1, c_l2, c_ms, c_fft;
+};
+__global__ void loss_final_kernel(const FinalArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double total = 0.0;
+    for (int b = 0; b < a.B; ++b) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < NSB; ++k) { s1 += (double)a.stats_part[((size_t)b * NSB + k) * 2]; s2 += (double)a.stats_part[((size_t)b * NSB + k) * 2 + 1]; }
+        double l = (double)a.c_l1 * (s1 / a.n_per_sample) + (double)a.c_l2 * (s2 / a.n_per_sample);
+        double ms = 0.0;
+        if (a.msval) {
+            for (int c = 0; c < a.C; ++c) ms += (double)a.msval[b * a.C + c];
+            ms /= a.C;
+            l += (double)a.c_ms * (1.0 - ms);
+        }
+        if (a.fft_part) {
+            double f = 0.0;
+            for (int c = 0; c < a.C; ++c)
+                for (int k = 0; k < a.ncolblk; ++k) f += (double)a.fft_part[(size_t)(b * a.C + c) * a.ncolblk + k];
+            l += (double)a.c_fft * f / (2.0 * (double)a.n_per_sample);
+        }
+        a.stats_out[b * 4 + 0] = (float)l; a.stats_out[b * 4 + 1] = (float)s1; a.stats_out[b * 4 + 2] = (float)s2; a.stats_out[b * 4 + 3] = (float)ms;
+        total += l;
+    }
+    a.loss_out[0] = (float)(total / a.B);
+}
+__global__ void msssim_final_kernel(const float* __restrict__ msval, float* __restrict__ out, int B, int C) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += msval[b * C + c];
+    out[b] = s / C;
+}
+
+// =====================================================================================================================
+// workspace layout
+// =====================================================================================================================
+struct WsLayout {
+    size_t stats_part, pyrX[LV], pyrY[LV], dXl[LV], ssim_part[LV], msval, coef, T, fft_part, total;
+    int tiles[LV];
+    Pyr pyr;
+    int ncolblk;
+};
+static size_t align64(size_t x) { return (x + 63) & ~size_t(63); }
+static WsLayout make_layout(int B, int C, int H, int W, bool use_ms, bool use_fft) {
+    WsLayout L{};
+    size_t off = 0;                                   // in floats
+    auto take = [&](size_t n) { size_t o = off; off = align64(off + n); return o; };
+    const size_t BC = (size_t)B * C;
+    L.stats_part = take((size_t)B * NSB * 2);
+    L.pyr = make_pyr(H, W);
+    if (use_ms) {
+        for (int l = 0; l < LV; ++l) {
+            const size_t n = BC * L.pyr.H[l] * L.pyr.W[l];
+            if (l > 0) { L.pyrX[l] = take(n); L.pyrY[l] = take(n); L.dXl[l] = take(n); }
+            L.tiles[l] = cdiv(L.pyr.H[l] - HW_, STH) * cdiv(L.pyr.W[l] - HW_, STW);
+            L.ssim_part[l] = take(BC * L.tiles[l]);
+        }
+        L.msval = take(BC);
+        L.coef = take(BC * LV);
+    }
+    if (use_fft) {
+        L.ncolblk = cdiv(W, COLS_PER_BLOCK);
+        L.T = take(BC * H * W * 2);
+        L.fft_part = take(BC * L.ncolblk);
+    }
+    L.total = off;
+    return L;
+}
+
+static int run_ms_forward(hipStream_t st, const float* X, const float* Y, float* ws, const WsLayout& L, int B, int C, float chain) {
+    const int BC = B * C;
+    const Win win = make_win();
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float* Xl = X; const float* Yl = Y;
+    CoefArgs ca{};
+    static const float weights[LV] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
+    for (int l = 0; l < LV; ++l) {
+        const int Hl = L.pyr.H[l], Wl = L.pyr.W[l];
+        if (Hl <= HW_ || Wl <= HW_) return bnerv_set_error(BNERV_E_ARG, "ms_ssim: level %d is %dx%d, needs > %d on both sides", l, Hl, Wl, HW_);
+        SsimArgs a{};
+        a.X = Xl; a.Y = Yl; a.partial = ws + L.ssim_part[l]; a.H = Hl; a.W = Wl;
+        a.tiles_x = cdiv(Wl - HW_, STW); a.tiles_y = cdiv(Hl - HW_, STH); a.C1 = C1; a.C2 = C2; a.win = win;
+        dim3 grid(a.tiles_x, a.tiles_y, BC);
+        if (l == LV - 1) hipLaunchKernelGGL(ssim_fwd_kernel<true>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(ssim_fwd_kernel<false>, grid, dim3(256), 0, st, a);
+        BNERV_LAUNCH_CHECK("ssim_fwd");
+        ca.partial[l] = ws + L.ssim_part[l]; ca.tiles[l] = L.tiles[l];
+        ca.inv_nvalid[l] = 1.0f / ((float)(Hl - HW_) * (float)(Wl - HW_));
+        ca.weights[l] = weights[l];
+        if (l < LV - 1) {
+            const int Ho = L.pyr.H[l + 1], Wo = L.pyr.W[l + 1];
+            const size_t n = (size_t)BC * Ho * Wo;
+            int gx = (int)((n + 255) / 256); if (gx > 4096) gx = 4096;
+            hipLaunchKernelGGL(avgpool2_kernel, dim3(gx, 1, 2), dim3(256), 0, st, Xl, Yl, ws + L.pyrX[l + 1], ws + L.pyrY[l + 1], BC, Hl, Wl, Ho, Wo, Hl % 2, Wl % 2);
+            BNERV_LAUNCH_CHECK("avgpool2");
+            Xl = ws + L.pyrX[l + 1]; Yl = ws + L.pyrY[l + 1];
+        }
+    }
+    ca.msval = ws + L.msval; ca.coef = ws + L.coef; ca.BC = BC; ca.chain = chain;
+    hipLaunchKernelGGL(ms_coef_kernel, dim3(BC), dim3(320), 0, st, ca);
+    BNERV_LAUNCH_CHECK("ms_coef");
+    return BNERV_OK;
+}
+
+static int run_ms_backward(hipStream_t st, const float* X, const float* Y, float* grad, float* ws, const WsLayout& L, int B, int C, float k_l1, float k_l2) {
+    const int BC = B * C;
+    const Win win = make_win();
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssim_bwd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SSIM_BWD_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssim_bwd_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SSIM_BWD_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssim_bwd_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SSIM_BWD_LDS);
+        attr_done = true;
+    }
+    for (int l = LV - 1; l >= 0; --l) {
+        const int Hl = L.pyr.H[l], Wl = L.pyr.W[l];
+        SsimArgs a{};
+        a.X = l ? ws + L.pyrX[l] : X; a.Y = l ? ws + L.pyrY[l] : Y;
+        a.coef = ws + L.coef + (size_t)l * BC;
+        a.dX = l ? ws + L.dXl[l] : grad;
+        a.H = Hl; a.W = Wl; a.C1 = 0.01f * 0.01f; a.C2 = 0.03f * 0.03f; a.win = win;
+        if (l < LV - 1) { a.dcoarse = ws + L.dXl[l + 1]; a.Hc = L.pyr.H[l + 1]; a.Wc = L.pyr.W[l + 1]; a.ph = Hl % 2; a.pw = Wl % 2; }
+        a.k_l1 = k_l1; a.k_l2 = k_l2;
+        dim3 grid(cdiv(Wl, STW), cdiv(Hl, STH), BC);
+        if (l == LV - 1) hipLaunchKernelGGL((ssim_bwd_kernel<true, false>), grid, dim3(256), SSIM_BWD_LDS, st, a);
+        else if (l == 0) hipLaunchKernelGGL((ssim_bwd_kernel<false, true>), grid, dim3(256), SSIM_BWD_LDS, st, a);
+        else hipLaunchKernelGGL((ssim_bwd_kernel<false, false>), grid, dim3(256), SSIM_BWD_LDS, st, a);
+        BNERV_LAUNCH_CHECK("ssim_bwd");
+    }
+    return BNERV_OK;
+}
+
+static int launch_stats(hipStream_t st, const float* p, const float* t, float* part, int B, int n_per_sample) {
+    hipLaunchKernelGGL(diff_stats_kernel, dim3(NSB, B), dim3(256), 0, st, p, t, part, n_per_sample);
+    BNERV_LAUNCH_CHECK("diff_stats");
+    return BNERV_OK;
+}
+
+}  // namespace
+
+extern "C" size_t bnerv_loss_ws_bytes(int B, int C, int H, int W, int use_ms, int use_fft) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return make_layout(B, C, H, W, use_ms != 0, use_fft != 0).total * sizeof(float);
+}
+
+extern "C" int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* dp) {
+    BNERV_REQUIRE(dp != nullptr, "loss: null descriptor");
+    const bnerv_loss_desc d = *dp;
+    BNERV_REQUIRE(d.pred && d.target && d.loss_out && d.stats_out && d.ws, "loss: null tensor");
+    BNERV_REQUIRE(d.B > 0 && d.C > 0 && d.H > 0 && d.W > 0 && d.B <= 65535, "loss: bad dims");
+    BNERV_REQUIRE((size_t)d.C * d.H * d.W < (size_t)1 << 31, "loss: sample too large");
+    const bool use_ms = d.c_ms != 0.f, use_fft = d.c_fft != 0.f;
+    const WsLayout L = make_layout(d.B, d.C, d.H, d.W, use_ms, use_fft);
+    if (d.ws_bytes < L.total * sizeof(float)) return bnerv_set_error(BNERV_E_WS, "loss: workspace %zu < %zu", d.ws_bytes, L.total * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = reinterpret_cast<float*>(d.ws);
+    const int nps = d.C * d.H * d.W, BC = d.B * d.C;
+    int rc = launch_stats(st, d.pred, d.target, ws + L.stats_part, d.B, nps);
+    if (rc) return rc;
+    const float k_l1 = d.c_l1 / ((float)d.B * (float)nps), k_l2 = 2.0f * d.c_l2 / ((float)d.B * (float)nps);
+    if (use_ms) {
+        if (d.H <= 160 || d.W <= 160) return bnerv_set_error(BNERV_E_ARG, "loss: MS-SSIM needs min(H,W) > 160 (got %dx%d)", d.H, d.W);
+        rc = run_ms_forward(st, d.pred, d.target, ws, L, d.B, d.C, -d.c_ms / (float)BC);
+        if (rc) return rc;
+        if (d.grad) { rc = run_ms_backward(st, d.pred, d.target, d.grad, ws, L, d.B, d.C, k_l1, k_l2); if (rc) return rc; }
+    } else if (d.grad) {
+        const size_t n = (size_t)d.B * nps;
+        int gx = (int)((n + 1023) / 1024); if (gx > 4096) gx = 4096;
+        hipLaunchKernelGGL(grad_l1l2_kernel, dim3(gx), dim3(256), 0, st, d.pred, d.target, d.grad, n, k_l1, k_l2);
+        BNERV_LAUNCH_CHECK("grad_l1l2");
+    }
+    if (use_fft) {
+        FftArgs a{};
+        if (!make_plan(d.W, &a.prow) || !make_plan(d.H, &a.pcol))
+            return bnerv_set_error(BNERV_E_ARG, "loss: FFT size %dx%d has a prime factor > %d", d.H, d.W, BNERV_FFT_MAX_RADIX);
+        a.pred = d.pred; a.target = d.target; a.T = reinterpret_cast<float2*>(ws + L.T); a.partial = ws + L.fft_part; a.grad = d.grad;
+        a.BC = BC; a.H = d.H; a.W = d.W; a.gscale = d.c_fft / ((float)d.B * (float)nps * 2.0f); a.accumulate = 1;
+        const size_t lds_row = (size_t)ROWS_PER_BLOCK * d.W * sizeof(float2), lds_col = (size_t)COLS_PER_BLOCK * d.H * sizeof(float2);
+        BNERV_REQUIRE(lds_row <= 160 * 1024 && lds_col <= 160 * 1024, "loss: frame %dx%d too large for the LDS FFT", d.H, d.W);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_adj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_col);
+        const int nrowblk = cdiv(BC * d.H, ROWS_PER_BLOCK);
+        hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(nrowblk), dim3(256), lds_row, st, a);
+        BNERV_LAUNCH_CHECK("fft_rows_fwd");
+        hipLaunchKernelGGL(fft_cols_kernel, dim3(L.ncolblk, BC), dim3(256), lds_col, st, a);
+        BNERV_LAUNCH_CHECK("fft_cols");
+        if (d.grad) {
+            hipLaunchKernelGGL(fft_rows_adj_kernel, dim3(nrowblk), dim3(256), lds_row, st, a);
+            BNERV_LAUNCH_CHECK("fft_rows_adj");
+        }
+    }
+    FinalArgs f{};
+    f.stats_part = ws + L.stats_part; f.msval = use_ms ? ws + L.msval : nullptr; f.fft_part = use_fft ? ws + L.fft_part : nullptr;
+    f.loss_out = d.loss_out; f.stats_out = d.stats_out; f.B = d.B; f.C = d.C; f.n_per_sample = nps; f.ncolblk = L.ncolblk;
+    f.c_l1 = d.c_l1; f.c_l2 = d.c_l2; f.c_ms = d.c_ms; f.c_fft = d.c_fft;
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, f);
+    BNERV_LAUNCH_CHECK("loss_final");
+    return BNERV_OK;
+}
+
+extern "C" int bnerv_msssim(void* stream, const float* x, const float* y, float* out, void* wsv, size_t ws_bytes, int B, int C, int H, int W) {
+    BNERV_REQUIRE(x && y && out && wsv && B > 0 && C > 0, "msssim: bad args");
+    if (H <= 160 || W <= 160) return bnerv_set_error(BNERV_E_ARG, "msssim: needs min(H,W) > 160 (got %dx%d)", H, W);
+    const WsLayout L = make_layout(B, C, H, W, true, false);
+    if (ws_bytes < L.total * sizeof(float)) return bnerv_set_error(BNERV_E_WS, "msssim: workspace %zu < %zu", ws_bytes, L.total * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = reinterpret_cast<float*>(wsv);
+    int rc = run_ms_forward(st, x, y, ws, L, B, C, 0.f);
+    if (rc) return rc;
+    hipLaunchKernelGGL(msssim_final_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, ws + L.msval, out, B, C);
+    BNERV_LAUNCH_CHECK("msssim_final");
+    return BNERV_OK;
+}
+
+extern "C" size_t bnerv_psnr_ws_bytes(int B, int C, int H, int W) { (void)C; (void)H; (void)W; return B > 0 ? (size_t)B * NSB * 2 * sizeof(float) : 0; }
+
+extern "C" int bnerv_psnr(void* stream, const float* o, const float* gt, float* psnr, void* ws, size_t ws_bytes, int B, int C, int H, int W) {
+    BNERV_REQUIRE(o && gt && psnr && ws && B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0, "psnr: bad args");
+    BNERV_REQUIRE((size_t)C * H * W < (size_t)1 << 31, "psnr: sample too large");
+    if (ws_bytes < bnerv_psnr_ws_bytes(B, C, H, W)) return bnerv_set_error(BNERV_E_WS, "psnr: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_stats(st, o, gt, (float*)ws, B, C * H * W);
+    if (rc) return rc;
+    hipLaunchKernelGGL(psnr_final_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, (const float*)ws, psnr, B, C * H * W);
+    BNERV_LAUNCH_CHECK("psnr_final");
+    return BNERV_OK;
+}
+
+// Create the FFT twiddle tables for an H x W frame ahead of time (they are otherwise created on first use; creation
+// allocates and copies synchronously, which is illegal inside a stream capture).
+extern "C" int bnerv_fft_prepare(int H, int W) {
+    FftPlan p;
+    if (!make_plan(H, &p) || !make_plan(W, &p)) return bnerv_set_error(BNERV_E_ARG, "fft_prepare: %dx%d unsupported", H, W);
+    return BNERV_OK;
+}

@@ -1,0 +1,195 @@
+"""ENeRV_Boost -- host-side mirror of the reference's model_enerv.py:253-317 (and of the parts of its base class ENeRV,
+:104-251, that decide parameter names and the seeded-init RNG order).  The 144-token transformer stem stays on stock
+PyTorch-ROCm ops (~0.1 GFLOP); PE, stem MLPs, Conv_Up_Block, NeRVBlocks and head run on the HIP kernels."""
+import time
+
+import torch
+import torch.nn as nn
+
+from .model_blocks import *  # noqa: F401,F403
+from .model_blocks import (ActivationLayer, CustomConv2d, CustomLinear, NeRV_MLP, NeRVBlock, NormLayer, PositionEncoding,
+                           ResBlock_SFT, Sin, UpConv, head_out, tat_modulations)
+from .model_nerv import _CEMHooks
+from . import ops
+
+
+class FeedForward(nn.Module):                                                            # model_enerv.py:19-30
+    def __init__(self, dim, hidden_dim, dropout=0.0, args=None):
+        super().__init__()
+        self.net = nn.Sequential(CustomLinear(dim, hidden_dim, args=args), nn.GELU(), nn.Dropout(dropout),
+                                 CustomLinear(hidden_dim, dim, args=args), nn.Dropout(dropout))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class Attention(nn.Module):                                                              # model_enerv.py:32-57
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.0, args=None):
+        super().__init__()
+        inner_dim = heads * dim_head
+        project_out = not (heads == 1 and dim_head == dim)
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.attend = nn.Softmax(dim=-1)
+        self.to_qkv = CustomLinear(dim, inner_dim * 3, bias=False, args=args)
+        self.to_out = nn.Sequential(CustomLinear(inner_dim, dim, args=args), nn.Dropout(dropout)) if project_out else nn.Identity()
+
+    def forward(self, x):
+        b, n, _ = x.shape
+        q, k, v = [t.reshape(b, n, self.heads, -1).permute(0, 2, 1, 3) for t in self.to_qkv(x).chunk(3, dim=-1)]
+        attn = self.attend(torch.matmul(q, k.transpose(-1, -2)) * self.scale)
+        out = torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(b, n, -1)
+        return self.to_out(out)
+
+
+class TransformerBlock(nn.Module):                                                       # model_enerv.py:59-71
+    def __init__(self, dim, heads, dim_head, mlp_dim, dropout=0.0, prenorm=False, args=None):
+        super().__init__()
+        if prenorm:
+            raise NotImplementedError("prenorm transformer blocks are never built by the reference (model_enerv.py:123-128)")
+        self.attn = Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout, args=args)
+        self.ffn = FeedForward(dim, mlp_dim, dropout=dropout, args=args)
+
+    def forward(self, x):
+        x = self.attn(x) + x
+        return self.ffn(x) + x
+
+
+class Conv_Up_Block(nn.Module):                                                          # model_enerv.py:73-102
+    def __init__(self, **kargs):
+        super().__init__()
+        ngf, new_ngf, args = kargs["ngf"], kargs["new_ngf"], kargs["args"]
+        if ngf <= new_ngf:
+            factor = 4
+            self.conv1 = UpConv(ngf=ngf, new_ngf=ngf // factor, ks=kargs["ks"], strd=kargs["stride"], bias=kargs["bias"],
+                                conv_type=kargs["conv_type"], args=args)
+            self.conv2 = CustomConv2d(ngf // factor, new_ngf, 3, 1, 1, bias=kargs["bias"], args=args)
+            self.up_first = True
+        else:
+            self.conv1 = CustomConv2d(ngf, new_ngf, 3, 1, 1, bias=kargs["bias"], args=args)
+            self.conv2 = UpConv(ngf=new_ngf, new_ngf=new_ngf, ks=kargs["ks"], strd=kargs["stride"], bias=kargs["bias"],
+                                conv_type=kargs["conv_type"], args=args)
+            self.up_first = False
+        self.norm = NormLayer(kargs["norm"], kargs["new_ngf"])
+        self.act = ActivationLayer(kargs["act"])
+        self.use_sft = "sft" in args.sft_block
+        if args.sft_block == "res_sft":
+            self.sft_block = ResBlock_SFT(kargs["new_ngf"], kargs["new_ngf"], cond_ch=kargs["sft_ngf"], in_act="relu",
+                                          out_act="gelu", omega=1, args=args)
+
+    def sft_layers(self):
+        return self.sft_block.sft_layers()
+
+    def forward(self, x, mods=None):
+        if not isinstance(x, tuple):
+            return self.act(self.norm(self.conv2(self.conv1(x))))
+        if not (isinstance(self.act, Sin) and isinstance(self.norm, nn.Identity) and hasattr(self, "sft_block")):
+            raise NotImplementedError("Conv_Up_Block((x, z)) on the HIP path needs act='sin', norm='none', sft_block='res_sft'")
+        feat, embed = x
+        if mods is None:
+            mods = tat_modulations(self.sft_layers(), embed)
+        (s0, t0), (s1, t1) = mods
+        sb = self.sft_block
+        tail = (s0, t0, s1, t1, sb.conv0.effective_weight(), sb.conv0.effective_bias(), sb.conv1.effective_weight(), sb.conv1.effective_bias())
+        if self.up_first:     # conv1 = conv+PixelShuffle (no activation), then [conv2 + sin] fused with the TAT block
+            y = self.conv1(feat)
+            return ops.snerv_block(y, self.conv2.effective_weight(), self.conv2.effective_bias(), *tail, 1)
+        y = self.conv1(feat)
+        c = self.conv2.conv_module()
+        return ops.snerv_block(y, c.effective_weight(), c.effective_bias(), *tail, self.conv2.stride)
+
+
+class ENeRV_Boost(_CEMHooks, nn.Module):
+    def __init__(self, expansion=3, args=None):
+        super().__init__()
+        self.encoder = nn.Identity()
+        self.pe_t = PositionEncoding(args.embed, args.lfreq)
+        self.fc_h, self.fc_w = [int(x) for x in args.fc_hw.split("_")]
+        self.fc_dim = args.fc_dim
+        self.block_dim = args.block_dim
+        mlp_dim = args.block_dim // 2
+
+        # ---- the base-class constructor (ENeRV.__init__, model_enerv.py:104-164), in ITS order: several of these modules
+        # are replaced below, but they must be built first so that the torch RNG is consumed exactly as in the reference
+        self.stem_t = NeRV_MLP(dim_list=[self.pe_t.embed_length, self.block_dim * 2, self.block_dim], act=args.act, args=args)
+        self.pe_t_manipulate = PositionEncoding(args.embed, args.lfreq)
+        self.t_branch = NeRV_MLP(dim_list=[self.pe_t_manipulate.embed_length, 128, 128], act=args.act, args=args)   # base t_branch (replaced below)
+        self.pe_xy = PositionEncoding(args.embed, args.lfreq)
+        self.stem_xy = NeRV_MLP(dim_list=[2 * self.pe_xy.embed_length, self.block_dim], act=args.act, args=args)
+        self.trans1 = TransformerBlock(dim=self.block_dim, heads=1, dim_head=64, mlp_dim=mlp_dim, dropout=0.0, prenorm=False, args=args)
+        self.trans2 = TransformerBlock(dim=self.block_dim, heads=8, dim_head=64, mlp_dim=mlp_dim, dropout=0.0, prenorm=False, args=args)
+        if self.block_dim == self.fc_dim:
+            self.toconv = nn.Identity()
+        else:
+            self.toconv = NeRV_MLP(dim_list=[self.block_dim, self.fc_dim], act=args.act, args=args)
+        self.layers = self._build_layers(expansion, args, base_pass=True)                                 # base layers (replaced below)
+        self.head_layer = CustomConv2d(self._last_ngf, 3, 1, 1, bias=True, args=args)
+        self.out_bias = args.out_bias
+
+        # ---- ENeRV_Boost.__init__ proper (model_enerv.py:254-277)
+        self.t_branch = NeRV_MLP(dim_list=[self.pe_t_manipulate.embed_length, args.ch_t * 2, args.ch_t], act=args.act, args=args)
+        self.t_layers, self.norm_layers = None, None
+        self.layers = self._build_layers(expansion, args, base_pass=False)
+        self.time_decode = False
+        self._xy = None
+
+    def _build_layers(self, expansion, args, base_pass):
+        layers = nn.ModuleList()
+        ngf = self.fc_dim
+        ks_enc, ks_dec1, ks_dec2 = [int(x) for x in args.ks.split("_")]
+        for i, stride in enumerate(args.dec_strds):
+            if i == 0:
+                new_ngf = int(ngf * expansion)
+            else:
+                new_ngf = int(max(ngf // (1 if stride == 1 else args.reduce), args.lower_width))
+            for j in range(args.dec_blks[i]):
+                if base_pass:      # t_layers[k] = NeRV_MLP([128, 2*ngf]) is created BEFORE the block in the base class (:146)
+                    NeRV_MLP(dim_list=[128, 2 * ngf], act=args.act, args=args)
+                if i == 0:
+                    layers.append(Conv_Up_Block(ngf=ngf, new_ngf=new_ngf, ks=min(ks_dec1 + 2 * i, ks_dec2), stride=1 if j else stride,
+                                                bias=True, norm=args.norm, act=args.act, conv_type=args.conv_type[1], sft_ngf=args.ch_t, args=args))
+                else:
+                    layers.append(NeRVBlock(dec_block=True, conv_type=args.conv_type[1], ngf=ngf, new_ngf=new_ngf,
+                                            ks=min(ks_dec1 + 2 * i, ks_dec2), strd=1 if j else stride, bias=True, norm=args.norm,
+                                            act=args.act, sft_ngf=args.ch_t, args=args))
+                ngf = new_ngf
+        self._last_ngf = ngf
+        return layers
+
+    def forward(self, input, input_embed=None, norm_idx=False):
+        device = next(self.parameters()).device
+        if self._xy is None or self._xy.device != device:
+            self._xy = torch.stack(torch.meshgrid(torch.arange(self.fc_h) / self.fc_h, torch.arange(self.fc_w) / self.fc_w, indexing="ij"),
+                                   dim=0).flatten(1, 2).to(device)
+        xy_coord = self._xy
+        dec_start = time.time()
+        batchsize = input.size(0)
+        t = input[:, None].float()
+        t_emb = self.stem_t(self.pe_t(t)).view(batchsize, -1)
+        t_manipulate = self.t_branch(self.pe_t_manipulate(t))
+
+        x_coord = self.pe_xy(xy_coord[0][:, None])
+        y_coord = self.pe_xy(xy_coord[1][:, None])
+        xy_emb = torch.cat([x_coord, y_coord], dim=1)
+        xy_emb = self.stem_xy(xy_emb).view(1, int(self.fc_h * self.fc_w), -1).expand(batchsize, -1, -1)
+        xy_emb = self.trans1(xy_emb)
+        emb = xy_emb * t_emb[:, None, :]
+        emb = self.trans2(emb)
+        emb = emb.reshape(emb.shape[0], self.fc_h, self.fc_w, emb.shape[-1]).permute(0, 3, 1, 2)
+        output = self.toconv(emb.contiguous())
+
+        out_list = [t_manipulate]
+        sfts = []
+        for layer in self.layers:
+            sfts += layer.sft_layers()
+        mods = tat_modulations(sfts, t_manipulate)
+        for i, layer in enumerate(self.layers):
+            output = layer((output, t_manipulate), mods=(mods[2 * i], mods[2 * i + 1]))
+            out_list.append(output)
+        img_out = head_out(self.head_layer, output, self.out_bias)
+        if self.time_decode and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        return img_out, out_list, time.time() - dec_start
+
+    def decoder_params(self):
+        return (sum([p.data.nelement() for p in self.parameters()])) / 1e6

@@ -1,0 +1,79 @@
+"""NeRV_Boost -- host-side mirror of the reference's model_nerv.py:11-94 (constructor, forward signature/return,
+state_dict keys, seeded init order); arithmetic on the HIP kernels."""
+import time
+
+import torch
+import torch.nn as nn
+
+from .model_blocks import *  # noqa: F401,F403
+from .model_blocks import (CustomConv2d, NeRV_MLP, NeRVBlock, PositionEncoding, head_out, mlp_pair_forward,
+                           tat_modulations)
+from .lib.quant_ops import CustomLinear
+
+
+class _CEMHooks:
+    """cal_params / get_bitrate_sum / init_data (model_nerv.py:67-94): CEM compression path, SURVEY 8(f) row N2."""
+
+    def cal_params(self, entropy_model=None):
+        raise NotImplementedError("CEM compression hooks (train_nerv_compression.py) are SURVEY 8(f) row N2: not built yet")
+
+    get_bitrate_sum = init_data = cal_params
+
+
+def decoder_layers_forward(layers, output, t_embed, out_list):
+    """Run a list of NeRVBlocks with the TAT modulations of ALL blocks evaluated up front in two grouped launches."""
+    sfts = []
+    for layer in layers:
+        sfts += layer.sft_layers()
+    mods = tat_modulations(sfts, t_embed)
+    for i, layer in enumerate(layers):
+        output = layer((output, t_embed), mods=(mods[2 * i], mods[2 * i + 1]))
+        out_list.append(output)
+    return output
+
+
+class NeRV_Boost(_CEMHooks, nn.Module):
+    def __init__(self, expansion=1, args=None):
+        super().__init__()
+        self.encoder = nn.Identity()
+        self.pe_t = PositionEncoding(args.embed, args.lfreq)
+        self.fc_h, self.fc_w = [int(x) for x in args.fc_hw.split("_")]
+        self.fc_dim = args.fc_dim
+        mlp_dim_list = [self.pe_t.embed_length] + [256] + [self.fc_h * self.fc_w * self.fc_dim]
+        self.stem = NeRV_MLP(dim_list=mlp_dim_list, bias=True, act=args.act, omega=1, args=args)
+        self.stem_t = NeRV_MLP(dim_list=[int(self.pe_t.embed_length), int(args.ch_t * 2), args.ch_t], bias=True, act=args.act, omega=1, args=args)
+
+        self.layers = nn.ModuleList()
+        ngf = self.fc_dim
+        ks_enc, ks_dec1, ks_dec2 = [int(x) for x in args.ks.split("_")]
+        for i, stride in enumerate(args.dec_strds):
+            if i == 0:
+                new_ngf = int(ngf * expansion)
+            else:
+                new_ngf = int(max(ngf // (1 if stride == 1 else args.reduce), args.lower_width))
+            for j in range(args.dec_blks[i]):
+                self.layers.append(NeRVBlock(dec_block=True, conv_type=args.conv_type[1], ngf=ngf, new_ngf=new_ngf,
+                                             ks=min(ks_dec1 + 2 * i, ks_dec2), strd=1 if j else stride, bias=True, norm=args.norm,
+                                             act=args.act, sft_ngf=args.ch_t, args=args, dump_features=False))
+                ngf = new_ngf
+        self.head_layer = CustomConv2d(ngf, 3, 1, 1, bias=True, args=args)
+        self.out_bias = args.out_bias
+        self.outf = args.outf
+        self.time_decode = False        # True: synchronise and report wall-clock dec_time like the reference (:58-60)
+
+    def forward(self, input, input_embed=None, norm_idx=None):
+        dec_start = time.time()
+        t = input[:, None].float()
+        t_embed = self.pe_t(t)
+        output, t_embed = mlp_pair_forward([self.stem, self.stem_t], [t_embed, t_embed])
+        output = output.view(output.size(0), self.fc_dim, self.fc_h, self.fc_w)
+        out_list = []
+        output = decoder_layers_forward(self.layers, output, t_embed, out_list)
+        img_out = head_out(self.head_layer, output, self.out_bias)
+        if self.time_decode and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dec_time = time.time() - dec_start
+        return img_out, out_list, dec_time
+
+    def decoder_params(self):
+        return (sum([p.data.nelement() for p in self.parameters()])) / 1e6

@@ -1,0 +1,475 @@
+"""Autograd operators of the decoder path.  Every forward/backward here is a sequence of C-ABI calls into
+libbnerv_hip.so on torch's current HIP stream; torch supplies device memory, the stream and the autograd graph only.
+
+Operator <-> reference map (the Python modules in this package call these from the same places the reference calls
+ATen):
+  positional_encoding      PositionEncoding.forward              model_blocks.py:120-126
+  dense_grouped            NeRV_MLP / SFTLayer 1x1 convs         model_blocks.py:66-71, :92-105
+  conv2d_ps                CustomConv2d (+PixelShuffle)          lib/quant_ops.py:39-41, model_blocks.py:213-218
+  snerv_block              NeRVBlock.forward with TAT            model_blocks.py:34-39 + :83-89
+  tat_block                ResBlock_SFT.forward                  model_blocks.py:83-89
+  sft_affine               SFTLayer.forward (affine part)        model_blocks.py:101-105
+  head_tanh                head_layer + OutImg('tanh')           model_nerv.py:56-57, model_blocks.py:57-63
+  loss / psnr / msssim     loss_fn, psnr_fn_single, ms_ssim      hnerv_utils.py:335-403, :410-412
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# raw kernel wrappers
+# ----------------------------------------------------------------------------------------------------------------------
+def _conv(x, w, bias, out, *, B, Cin, Cout, H, W, k, in_mode, ep_mode, in_s=1, out_s=1, transposed=0, out2=None,
+          aux0=None, aux1=None, aux2=None, scale=None, shift=None, partial=None):
+    d = L.ConvDesc(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(out), L.ptr(out2), L.ptr(aux0), L.ptr(aux1), L.ptr(aux2),
+                   L.ptr(scale), L.ptr(shift), L.ptr(partial), B, Cin, Cout, H, W, k, in_mode, ep_mode, in_s, out_s,
+                   transposed, w.shape[0], w.shape[1])
+    L.check(L.load().bnerv_conv_igemm(L.stream(), C.byref(d)), "bnerv_conv_igemm")
+
+
+def _wgrad(x, g, dw, db, *, B, Cin, Cout, H, W, k, in_mode, g_mode, g_s=1, gaux=None, scale=None, shift=None):
+    lib = L.load()
+    nbytes = lib.bnerv_conv_wgrad_ws_bytes(B, Cin, Cout, H, W, k)
+    ws = _ws(nbytes, x.device)
+    d = L.WgradDesc(L.ptr(x), L.ptr(g), L.ptr(gaux), L.ptr(scale), L.ptr(shift), L.ptr(dw), L.ptr(db), L.ptr(ws), nbytes,
+                    B, Cin, Cout, H, W, k, in_mode, g_mode, g_s)
+    L.check(lib.bnerv_conv_wgrad(L.stream(), C.byref(d)), "bnerv_conv_wgrad")
+
+
+def _reduce_slabs(slabs, n_slabs, count, out):
+    L.check(L.load().bnerv_reduce_slabs(L.stream(), L.ptr(slabs), n_slabs, count, L.ptr(out)), "bnerv_reduce_slabs")
+
+
+def _tiles(H, W):
+    return L.load().bnerv_conv_tiles(H, W)
+
+
+def _bc(t, B, Cc):
+    """[B,C,1,1] / [B,C] modulation tensor -> contiguous fp32 [B,C]."""
+    t = L.f32c(t).reshape(B, Cc)
+    return t
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# positional encoding (no gradient: positions are data)
+# ----------------------------------------------------------------------------------------------------------------------
+def positional_encoding(pos, bases):
+    """pos [N,1] fp32 or fp64 on the device; bases fp32 [L] (built on the host by the reference expression).
+    Returns [N, 2L, 1, 1] fp32 = cat[sin(pos*bases), cos(pos*bases)]; fp64 positions use the fp64 product form."""
+    L.require_device(pos, "pos")
+    N, Lv = pos.shape[0], bases.numel()
+    bases = bases.to(device=pos.device, dtype=torch.float32).contiguous()
+    out = torch.empty(N, 2 * Lv, 1, 1, dtype=torch.float32, device=pos.device)
+    lib = L.load()
+    if pos.dtype == torch.float64:
+        L.check(lib.bnerv_pe_fwd_f64(L.stream(), L.ptr(pos.contiguous()), L.ptr(bases), L.ptr(out), N, Lv), "bnerv_pe_fwd_f64")
+    else:
+        p = pos.contiguous() if pos.dtype == torch.float32 else pos.float().contiguous()
+        L.check(lib.bnerv_pe_fwd_f32(L.stream(), L.ptr(p), L.ptr(bases), L.ptr(out), N, Lv), "bnerv_pe_fwd_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# grouped dense layers
+# ----------------------------------------------------------------------------------------------------------------------
+_ACT = {"none": L.ACT_NONE, None: L.ACT_NONE, "relu": L.ACT_RELU, "sin": L.ACT_SIN}
+
+
+class _DenseGrouped(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, acts, n, *tensors):
+        xs, ws, bs = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n]
+        lib = L.load()
+        B = xs[0].shape[0]
+        dev = xs[0].device
+        xc, wc, ys, auxs = [], [], [], []
+        descs = []
+        for i in range(n):
+            x = L.f32c(L.require_device(xs[i], "x")).reshape(B, -1)
+            w = L.f32c(ws[i]).reshape(ws[i].shape[0], -1)
+            b = None if bs[i] is None else L.f32c(bs[i])
+            O, I = w.shape
+            assert x.shape[1] == I, (x.shape, w.shape)
+            y = torch.empty(B, O, dtype=torch.float32, device=dev)
+            aux = torch.empty(B, O, dtype=torch.float32, device=dev) if acts[i] == L.ACT_SIN else None
+            descs.append(L.DenseFwdDesc(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(aux), I, O, acts[i], 0))
+            xc.append(x); wc.append(w); ys.append(y); auxs.append(aux)
+        for i0 in range(0, n, L.MAX_DENSE_GROUPS):
+            chunk = descs[i0:i0 + L.MAX_DENSE_GROUPS]
+            arr = (L.DenseFwdDesc * len(chunk))(*chunk)
+            L.check(lib.bnerv_dense_grouped_fwd(L.stream(), arr, len(chunk), B), "bnerv_dense_grouped_fwd")
+        ctx.acts, ctx.n, ctx.B = acts, n, B
+        ctx.has_b = [b is not None for b in bs]
+        ctx.xshapes = [tuple(x.shape) for x in xs]
+        ctx.wshapes = [tuple(w.shape) for w in ws]
+        ctx.same_x = all(x.data_ptr() == xc[0].data_ptr() and x.shape == xc[0].shape for x in xc)
+        ctx.save_for_backward(*xc, *wc, *ys, *auxs)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n, B, acts = ctx.n, ctx.B, ctx.acts
+        sv = ctx.saved_tensors
+        xc, wc, ys, auxs = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:4 * n]
+        lib = L.load()
+        dev = ys[0].device
+        need_x = [ctx.needs_input_grad[2 + i] for i in range(n)]
+        descs, keep = [], []
+        dws, dbs, dxps, nchunks = [], [], [], []
+        I0 = wc[0].shape[1]
+        shared = ctx.same_x and n > 1 and any(need_x) and all(w.shape[0] <= L.DENSE_DX_CHUNK and w.shape[1] == I0 for w in wc)
+        shared_buf = torch.empty(n, B, I0, dtype=torch.float32, device=dev) if shared else None
+        for i in range(n):
+            x, w = xc[i], wc[i]
+            O, I = w.shape
+            dy = dys[i]
+            if dy is None:
+                dy = torch.zeros(B, O, dtype=torch.float32, device=dev)
+            dy = L.f32c(dy).reshape(B, O)
+            dw = torch.empty(O, I, dtype=torch.float32, device=dev)
+            db = torch.empty(O, dtype=torch.float32, device=dev) if ctx.has_b[i] else None
+            dpre = torch.empty(B, O, dtype=torch.float32, device=dev)
+            nch = (O + L.DENSE_DX_CHUNK - 1) // L.DENSE_DX_CHUNK
+            if shared:
+                dxp = shared_buf[i]
+            elif need_x[i]:
+                dxp = torch.empty(nch, B, I, dtype=torch.float32, device=dev)
+            else:
+                dxp = None
+            descs.append(L.DenseBwdDesc(L.ptr(x), L.ptr(w), L.ptr(ys[i]), L.ptr(auxs[i]), L.ptr(dy), L.ptr(dpre), L.ptr(dw), L.ptr(db),
+                                        L.ptr(dxp), I, O, acts[i], 0))
+            keep.append((dy, dpre))
+            dws.append(dw); dbs.append(db); dxps.append(dxp); nchunks.append(nch)
+        for i0 in range(0, n, L.MAX_DENSE_GROUPS):
+            chunk = descs[i0:i0 + L.MAX_DENSE_GROUPS]
+            arr = (L.DenseBwdDesc * len(chunk))(*chunk)
+            L.check(lib.bnerv_dense_grouped_bwd(L.stream(), arr, len(chunk), B), "bnerv_dense_grouped_bwd")
+        dxs = [None] * n
+        if shared:
+            tot = torch.empty(B, I0, dtype=torch.float32, device=dev)
+            _reduce_slabs(shared_buf, n, B * I0, tot)
+            first = next(i for i in range(n) if need_x[i])
+            dxs[first] = tot               # the same tensor was passed n times: its whole gradient goes to one slot
+        else:
+            for i in range(n):
+                if dxps[i] is None:
+                    continue
+                if nchunks[i] == 1:
+                    dxs[i] = dxps[i][0]
+                else:
+                    I = wc[i].shape[1]
+                    tot = torch.empty(B, I, dtype=torch.float32, device=dev)
+                    _reduce_slabs(dxps[i], nchunks[i], B * I, tot)
+                    dxs[i] = tot
+        dws = [dw.reshape(sh) for dw, sh in zip(dws, ctx.wshapes)]
+        dxs = [None if dx is None else dx.reshape(sh) for dx, sh in zip(dxs, ctx.xshapes)]
+        return (None, None) + tuple(dxs) + tuple(dws) + tuple(dbs)
+
+
+def dense_grouped(xs, ws, bs, acts):
+    """Evaluate n independent dense layers y_i = act_i(W_i x_i + b_i) in one launch.
+    xs[i]: [B, I_i(,1,1)], ws[i]: [O_i, I_i(,1,1)], bs[i]: [O_i] or None, acts[i] in {'none','relu','sin'}.
+    Returns a list of [B, O_i] tensors."""
+    n = len(xs)
+    a = tuple(_ACT[x] for x in acts)
+    return list(_DenseGrouped.apply(a, n, *xs, *ws, *bs))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# plain conv (+ bias, + optional pixel shuffle)
+# ----------------------------------------------------------------------------------------------------------------------
+class _Conv2dPS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, s):
+        x = L.f32c(L.require_device(x, "x")); w = L.f32c(w); b = None if b is None else L.f32c(b)
+        B, Cin, H, W = x.shape
+        Cout, k = w.shape[0], w.shape[-1]
+        out = torch.empty(B, Cout // (s * s), H * s, W * s, dtype=torch.float32, device=x.device)
+        _conv(x, w, b, out, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS, out_s=s)
+        ctx.save_for_backward(x, w)
+        ctx.s, ctx.has_b = s, b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        s = ctx.s
+        g = L.f32c(g)
+        B, Cin, H, W = x.shape
+        Cout, k = w.shape[0], w.shape[-1]
+        dw = torch.empty_like(w)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_b else None
+        _wgrad(x, g, dw, db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _conv(g, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1)
+        return dx, dw, db, None
+
+
+def conv2d_ps(x, w, b, shuffle=1):
+    """F.conv2d(x, w, b, stride 1, padding (k-1)//2) followed by PixelShuffle(shuffle); k in {1,3}."""
+    return _Conv2dPS.apply(x, w, b, int(shuffle))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# TAT residual block and the fused SNeRV block
+# ----------------------------------------------------------------------------------------------------------------------
+def _tat_forward(y0, s0, t0, s1, t1, w0, b0, w1, b1):
+    B, Cc, H, W = y0.shape
+    v = torch.empty_like(y0)
+    _conv(y0, w0, b0, v, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS, scale=s0, shift=t0)
+    out = torch.empty_like(y0)
+    _conv(v, w1, b1, out, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_GELU_AFFINE, ep_mode=L.EP_BIAS_RES, scale=s1, shift=t1, aux0=y0)
+    return v, out
+
+
+def _tat_backward(dout, y0, c0, v, s0, t0, s1, t1, w0, w1):
+    """Returns (dy0_or_du, ds0, dt0, ds1, dt1, dw0, db0, dw1, db1).  With c0 given the first result is
+    d/d(pre-sin) = (dout + dA0*(1+s0)) * c0, otherwise d/dy0."""
+    B, Cc, H, W = y0.shape
+    dev = y0.device
+    tiles = _tiles(H, W)
+    dw1 = torch.empty_like(w1); db1 = torch.empty(Cc, dtype=torch.float32, device=dev)
+    _wgrad(v, dout, dw1, db1, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_GELU_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s1, shift=t1)
+    dv = torch.empty_like(y0)
+    part = torch.empty(tiles, B, 2, Cc, dtype=torch.float32, device=dev)
+    _conv(dout, w1, None, dv, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU, transposed=1,
+          aux0=v, scale=s1, partial=part)
+    st1 = torch.empty(B, 2, Cc, dtype=torch.float32, device=dev)
+    _reduce_slabs(part, tiles, B * 2 * Cc, st1)
+    dw0 = torch.empty_like(w0); db0 = torch.empty(Cc, dtype=torch.float32, device=dev)
+    _wgrad(y0, dv, dw0, db0, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s0, shift=t0)
+    du = torch.empty_like(y0)
+    part0 = torch.empty(tiles, B, 2, Cc, dtype=torch.float32, device=dev)
+    _conv(dv, w0, None, du, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN, transposed=1,
+          aux0=y0, aux1=dout, aux2=c0, scale=s0, partial=part0)
+    st0 = torch.empty(B, 2, Cc, dtype=torch.float32, device=dev)
+    _reduce_slabs(part0, tiles, B * 2 * Cc, st0)
+    return du, st0[:, 0], st0[:, 1], st1[:, 0], st1[:, 1], dw0, db0, dw1, db1
+
+
+class _TATBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, s0, t0, s1, t1, w0, b0, w1, b1):
+        x0 = L.f32c(L.require_device(x0, "x0"))
+        B, Cc = x0.shape[:2]
+        s0, t0, s1, t1 = (_bc(t, B, Cc) for t in (s0, t0, s1, t1))
+        w0, b0, w1, b1 = (L.f32c(t) for t in (w0, b0, w1, b1))
+        v, out = _tat_forward(x0, s0, t0, s1, t1, w0, b0, w1, b1)
+        ctx.save_for_backward(x0, v, s0, t0, s1, t1, w0, w1)
+        ctx.mshape = (B, Cc, 1, 1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x0, v, s0, t0, s1, t1, w0, w1 = ctx.saved_tensors
+        dx0, ds0, dt0, ds1, dt1, dw0, db0, dw1, db1 = _tat_backward(L.f32c(dout), x0, None, v, s0, t0, s1, t1, w0, w1)
+        m = ctx.mshape
+        return dx0, ds0.reshape(m), dt0.reshape(m), ds1.reshape(m), dt1.reshape(m), dw0, db0, dw1, db1
+
+
+def tat_block(x0, scale0, shift0, scale1, shift1, w0, b0, w1, b1):
+    """x0 + conv1(sft1(gelu(conv0(sft0(x0)))))  with sft_i(a) = a*(scale_i+1)+shift_i  (ResBlock_SFT.forward)."""
+    return _TATBlock.apply(x0, scale0, shift0, scale1, shift1, w0, b0, w1, b1)
+
+
+class _SNeRVBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wu, bu, s0, t0, s1, t1, w0, b0, w1, b1, stride):
+        x = L.f32c(L.require_device(x, "x"))
+        wu, w0, b0, w1, b1 = (L.f32c(t) for t in (wu, w0, b0, w1, b1))
+        bu = None if bu is None else L.f32c(bu)
+        B, Cin, H, W = x.shape
+        Ct, k = wu.shape[0], wu.shape[-1]
+        s = stride
+        Cc = Ct // (s * s)
+        s0, t0, s1, t1 = (_bc(t, B, Cc) for t in (s0, t0, s1, t1))
+        y0 = torch.empty(B, Cc, H * s, W * s, dtype=torch.float32, device=x.device)
+        c0 = torch.empty_like(y0)
+        _conv(x, wu, bu, y0, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_SIN, out_s=s, out2=c0)
+        v, out = _tat_forward(y0, s0, t0, s1, t1, w0, b0, w1, b1)
+        ctx.save_for_backward(x, y0, c0, v, s0, t0, s1, t1, wu, w0, w1)
+        ctx.s, ctx.has_bu, ctx.mshape = s, bu is not None, (B, Cc, 1, 1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y0, c0, v, s0, t0, s1, t1, wu, w0, w1 = ctx.saved_tensors
+        s = ctx.s
+        du, ds0, dt0, ds1, dt1, dw0, db0, dw1, db1 = _tat_backward(L.f32c(dout), y0, c0, v, s0, t0, s1, t1, w0, w1)
+        B, Cin, H, W = x.shape
+        Ct, k = wu.shape[0], wu.shape[-1]
+        dwu = torch.empty_like(wu)
+        dbu = torch.empty(Ct, dtype=torch.float32, device=x.device) if ctx.has_bu else None
+        _wgrad(x, du, dwu, dbu, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _conv(du, wu, None, dx, B=B, Cin=Ct, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1)
+        m = ctx.mshape
+        return dx, dwu, dbu, ds0.reshape(m), dt0.reshape(m), ds1.reshape(m), dt1.reshape(m), dw0, db0, dw1, db1, None
+
+
+def snerv_block(x, w_up, b_up, scale0, shift0, scale1, shift1, w0, b0, w1, b1, stride):
+    """tat_block(sin(PixelShuffle_stride(conv(x, w_up, b_up))))  -- NeRVBlock.forward with act='sin', norm='none'."""
+    return _SNeRVBlock.apply(x, w_up, b_up, scale0, shift0, scale1, shift1, w0, b0, w1, b1, int(stride))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# stand-alone TAT affine
+# ----------------------------------------------------------------------------------------------------------------------
+class _SFTAffine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        x = L.f32c(L.require_device(x, "x"))
+        B, Cc = x.shape[:2]
+        HW = x[0, 0].numel()
+        sc, sh = _bc(scale, B, Cc), _bc(shift, B, Cc)
+        y = torch.empty_like(x)
+        L.check(L.load().bnerv_sft_affine_fwd(L.stream(), L.ptr(x), L.ptr(sc), L.ptr(sh), L.ptr(y), B, Cc, HW), "bnerv_sft_affine_fwd")
+        ctx.save_for_backward(x, sc)
+        ctx.mshape = tuple(scale.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, sc = ctx.saved_tensors
+        g = L.f32c(g)
+        B, Cc = x.shape[:2]
+        HW = x[0, 0].numel()
+        dx = torch.empty_like(x)
+        part = torch.empty(L.SFT_CHUNKS, 2, B * Cc, dtype=torch.float32, device=x.device)
+        L.check(L.load().bnerv_sft_affine_bwd(L.stream(), L.ptr(x), L.ptr(sc), L.ptr(g), L.ptr(dx), L.ptr(part), B, Cc, HW), "bnerv_sft_affine_bwd")
+        tot = torch.empty(2, B * Cc, dtype=torch.float32, device=x.device)
+        _reduce_slabs(part, L.SFT_CHUNKS, 2 * B * Cc, tot)
+        return dx, tot[0].reshape(ctx.mshape), tot[1].reshape(ctx.mshape)
+
+
+def sft_affine(x, scale, shift):
+    return _SFTAffine.apply(x, scale, shift)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# head conv + OutImg('tanh')
+# ----------------------------------------------------------------------------------------------------------------------
+class _HeadTanh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = L.f32c(L.require_device(x, "x")); w = L.f32c(w); b = None if b is None else L.f32c(b)
+        B, Cin, H, W = x.shape
+        Cout, k = w.shape[0], w.shape[-1]
+        img = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+        _conv(x, w, b, img, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_TANH)
+        ctx.save_for_backward(x, w, img)
+        ctx.has_b = b is not None
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, img = ctx.saved_tensors
+        g = L.f32c(g)
+        B, Cin, H, W = x.shape
+        Cout, k = w.shape[0], w.shape[-1]
+        dw = torch.empty_like(w)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_b else None
+        _wgrad(x, g, dw, db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_TANHGRAD, gaux=img)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _conv(g, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_TANHGRAD, ep_mode=L.EP_PLAIN, transposed=1, aux0=img)
+        return dx, dw, db
+
+
+def head_tanh(x, w, b):
+    """tanh(conv(x, w, b)) * 0.5 + 0.5   (head_layer followed by OutImg(..., 'tanh'))."""
+    return _HeadTanh.apply(x, w, b)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# loss / metrics
+# ----------------------------------------------------------------------------------------------------------------------
+LOSS_COEFFS = {            # (c_l1, c_l2, c_ms, c_fft) per hnerv_utils.py:338-385
+    "L1": (1.0, 0.0, 0.0, 0.0),
+    "L2": (0.0, 1.0, 0.0, 0.0),
+    "L1_freq": (60.0, 0.0, 0.0, 1.0),
+    "Fusion10": (0.7, 0.0, 0.3, 0.0),
+    "Fusion11": (0.9, 0.0, 0.1, 0.0),
+    "Fusion12": (0.8, 0.0, 0.2, 0.0),
+    "Fusion10_freq": (60 * 0.7, 0.0, 60 * 0.3, 1.0),
+}
+
+_fft_ready = set()
+
+
+def prepare_loss(H, W):
+    """Build the FFT twiddle tables for HxW frames (must happen outside hipGraph capture)."""
+    if (H, W) not in _fft_ready:
+        L.check(L.load().bnerv_fft_prepare(H, W), "bnerv_fft_prepare")
+        _fft_ready.add((H, W))
+
+
+class _Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, coeffs):
+        pred = L.f32c(L.require_device(pred, "pred")); target = L.f32c(target.detach())
+        B, Cc, H, W = pred.shape
+        c1, c2, cm, cf = coeffs
+        lib = L.load()
+        if cf:
+            prepare_loss(H, W)
+        need_grad = ctx.needs_input_grad[0]
+        nbytes = lib.bnerv_loss_ws_bytes(B, Cc, H, W, int(cm != 0), int(cf != 0))
+        ws = _ws(nbytes, pred.device)
+        grad = torch.empty_like(pred) if need_grad else None
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        stats = torch.empty(B, 4, dtype=torch.float32, device=pred.device)
+        d = L.LossDesc(L.ptr(pred), L.ptr(target), L.ptr(grad), L.ptr(loss), L.ptr(stats), L.ptr(ws), nbytes, B, Cc, H, W, c1, c2, cm, cf)
+        L.check(lib.bnerv_loss_fwd_bwd(L.stream(), C.byref(d)), "bnerv_loss_fwd_bwd")
+        ctx.grad = grad
+        ctx.mark_non_differentiable(stats)
+        return loss.reshape(()), stats
+
+    @staticmethod
+    def backward(ctx, gl, _gs):
+        g = ctx.grad
+        ctx.grad = None
+        return (g * gl if g is not None else None), None, None
+
+
+def loss_with_stats(pred, target, loss_type="Fusion10_freq"):
+    """Returns (batch-mean loss [scalar tensor], stats [B,4] = {loss_b, sum|d|, sum d^2, ms_ssim_b})."""
+    if loss_type not in LOSS_COEFFS:
+        raise NotImplementedError(f"loss type {loss_type!r} is not on the HIP path; supported: {sorted(LOSS_COEFFS)}")
+    return _Loss.apply(pred, target, LOSS_COEFFS[loss_type])
+
+
+def psnr(output, gt):
+    """-10*log10(mean_{CHW}(output-gt)^2 + 1e-9) per sample, on the device (no host sync)."""
+    output = L.f32c(L.require_device(output.detach(), "output")); gt = L.f32c(gt.detach())
+    B, Cc, H, W = output.shape
+    lib = L.load()
+    nbytes = lib.bnerv_psnr_ws_bytes(B, Cc, H, W)
+    ws = _ws(nbytes, output.device)
+    out = torch.empty(B, dtype=torch.float32, device=output.device)
+    L.check(lib.bnerv_psnr(L.stream(), L.ptr(output), L.ptr(gt), L.ptr(out), L.ptr(ws), nbytes, B, Cc, H, W), "bnerv_psnr")
+    return out
+
+
+def msssim(x, y):
+    """ms_ssim(x, y, data_range=1, size_average=False) per sample, on the device."""
+    x = L.f32c(L.require_device(x.detach(), "x")); y = L.f32c(y.detach())
+    B, Cc, H, W = x.shape
+    lib = L.load()
+    nbytes = lib.bnerv_loss_ws_bytes(B, Cc, H, W, 1, 0)
+    ws = _ws(nbytes, x.device)
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    L.check(lib.bnerv_msssim(L.stream(), L.ptr(x), L.ptr(y), L.ptr(out), L.ptr(ws), nbytes, B, Cc, H, W), "bnerv_msssim")
+    return out

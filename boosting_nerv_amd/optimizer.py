@@ -1,0 +1,143 @@
+"""Adan optimizer -- host-side mirror of the reference's optimizer.py:39-235 (same constructor signature, defaults,
+param_group / state key names: 'step', 'exp_avg', 'exp_avg_sq', 'exp_avg_diff', 'neg_pre_grad'), with the update itself
+done by ONE fused multi-tensor HIP kernel per <=48 tensors (bnerv_adan_multi_tensor) instead of ~17 torch._foreach
+launches (optimizer.py:296-362).  This is the slot the reference reserves for the external `fused_adan` CUDA extension
+(optimizer.py:365-395), which it never ships.
+
+`step()` = `prepare_step()` (host: step count, bias corrections, lr -> a 5-float device buffer, via a pinned async copy)
++ `launch_step()` (kernel launches only -> capturable in a hipGraph; every scalar that changes per step is read from the
+device buffer, so a captured step replays with a moving LR schedule)."""
+import ctypes as C
+import math
+
+import torch
+from torch.optim.optimizer import Optimizer
+
+from . import _lib as L
+
+
+class Adan(Optimizer):
+    _RING = 512
+
+    def __init__(self, params, lr=1e-3, betas=(0.98, 0.92, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=0.0,
+                 no_prox=False, foreach: bool = True, fused: bool = False):
+        if not 0.0 <= max_grad_norm:
+            raise ValueError("Invalid Max grad norm: {}".format(max_grad_norm))
+        if not 0.0 <= lr:
+            raise ValueError("Invalid learning rate: {}".format(lr))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {}".format(eps))
+        for i in range(3):
+            if not 0.0 <= betas[i] < 1.0:
+                raise ValueError("Invalid beta parameter at index {}: {}".format(i, betas[i]))
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm, no_prox=no_prox,
+                        foreach=foreach, fused=fused)
+        super().__init__(params, defaults)
+        self._sched = {}          # group index -> (pinned host [5], device [5])
+        self._chunk_cache = {}    # group index -> (key, [AdanChunk])
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        for group in self.param_groups:
+            group.setdefault("no_prox", False)
+
+    @torch.no_grad()
+    def restart_opt(self):
+        for group in self.param_groups:
+            group["step"] = 0
+            for p in group["params"]:
+                if p.requires_grad:
+                    state = self.state[p]
+                    state["exp_avg"] = torch.zeros_like(p)
+                    state["exp_avg_sq"] = torch.zeros_like(p)
+                    state["exp_avg_diff"] = torch.zeros_like(p)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _clip_coef(self):
+        if self.defaults["max_grad_norm"] <= 0:
+            return 1.0
+        # optimizer.py:136-156: global-norm clipping (a device sync, exactly as in the reference; off in every recipe)
+        device = self.param_groups[0]["params"][0].device
+        total = torch.zeros(1, device=device)
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    total.add_(p.grad.pow(2).sum())
+        total = torch.sqrt(total)
+        return torch.clamp(self.defaults["max_grad_norm"] / (total + self.param_groups[-1]["eps"]), max=1.0).item()
+
+    @torch.no_grad()
+    def prepare_step(self):
+        """Host side of a step: advance the step count and publish {lr, bc1, bc2, sqrt(bc3), first_step} to the device."""
+        for gi, group in enumerate(self.param_groups):
+            beta1, beta2, beta3 = group["betas"]
+            group["step"] = group.get("step", 0) + 1
+            bc1 = 1.0 - beta1 ** group["step"]
+            bc2 = 1.0 - beta2 ** group["step"]
+            bc3 = 1.0 - beta3 ** group["step"]
+            dev = group["params"][0].device
+            L.require_device(group["params"][0], "parameter")
+            if gi not in self._sched:
+                # a RING of pinned slots: the async copy of step k may still be queued when the host prepares step k+1
+                self._sched[gi] = (torch.zeros(self._RING, 5, dtype=torch.float32).pin_memory(), torch.zeros(5, dtype=torch.float32, device=dev))
+            ring, devbuf = self._sched[gi]
+            host = ring[group["step"] % self._RING]
+            host[0], host[1], host[2], host[3] = group["lr"], bc1, bc2, math.sqrt(bc3)
+            host[4] = 1.0 if group["step"] == 1 else 0.0
+            devbuf.copy_(host, non_blocking=True)
+
+    def _ensure_state(self, p, step, clip):
+        state = self.state[p]
+        if len(state) == 0:
+            state["exp_avg"] = torch.zeros_like(p)
+            state["exp_avg_sq"] = torch.zeros_like(p)
+            state["exp_avg_diff"] = torch.zeros_like(p)
+        if "neg_pre_grad" not in state:
+            # step 1: the kernel's first_step flag substitutes -g; later first appearances follow optimizer.py:190-192
+            state["neg_pre_grad"] = torch.zeros_like(p) if step <= 1 else p.grad.clone().mul_(-clip)
+        return state
+
+    @torch.no_grad()
+    def launch_step(self, clip=1.0):
+        """Device side of a step: one fused kernel per <=48 tensors.  No host<->device traffic, no sync."""
+        lib = L.load()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+            cached = self._chunk_cache.get(gi)
+            if cached is None or cached[0] != key:
+                chunks = []
+                for i0 in range(0, len(ps), L.ADAN_MAX_TENSORS):
+                    ck = L.AdanChunk()
+                    sub = ps[i0:i0 + L.ADAN_MAX_TENSORS]
+                    for j, p in enumerate(sub):
+                        if not (p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32 and p.grad.dtype == torch.float32):
+                            raise L.BnervError("fused Adan needs contiguous fp32 parameters and gradients")
+                        st = self._ensure_state(p, group.get("step", 1), clip)
+                        ck.p[j], ck.g[j] = p.data_ptr(), p.grad.data_ptr()
+                        ck.exp_avg[j], ck.exp_avg_sq[j] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                        ck.exp_avg_diff[j], ck.neg_pre_grad[j] = st["exp_avg_diff"].data_ptr(), st["neg_pre_grad"].data_ptr()
+                        ck.n[j] = p.numel()
+                    ck.n_tensors = len(sub)
+                    chunks.append(ck)
+                self._chunk_cache[gi] = (key, chunks)
+            else:
+                chunks = cached[1]
+            beta1, beta2, beta3 = group["betas"]
+            hyper = L.AdanHyper(beta1, beta2, beta3, group["eps"], group["weight_decay"], clip, int(group["no_prox"]),
+                                self._sched[gi][1].data_ptr())
+            for ck in chunks:
+                L.check(lib.bnerv_adan_multi_tensor(L.stream(), C.byref(ck), C.byref(hyper)), "bnerv_adan_multi_tensor")
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        clip = self._clip_coef()
+        self.prepare_step()
+        self.launch_step(clip)
+        return loss

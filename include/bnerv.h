@@ -1,0 +1,255 @@
+/*
+ * bnerv.h -- C-ABI of libbnerv_hip.so: the MI355X (gfx950) kernels of the Boosting-NeRV conditional-decoder
+ * train path.  This is the drop-in boundary.
+ *
+ * The reference (Xinjie-Q/Boosting-NeRV) is pure Python/PyTorch and has NO FFI: every arithmetic op on the path is an
+ * ATen call made from the Python files cited below.  Each entry point here replaces the ATen call sequence of one
+ * reference call site; the Python host package (boosting_nerv_amd/) binds them with ctypes and mirrors the reference's
+ * module API (INTEGRATION.md shows the binding a reference maintainer would add).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and ints; no torch types.  All tensors are DEVICE pointers to contiguous fp32 NCHW
+ *     (OIHW for weights) unless stated otherwise; the caller owns every buffer (no ownership transfer, no allocation
+ *     here); workspaces are passed in explicitly and their sizes are given by the matching *_ws_bytes() helper.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the call never synchronises.
+ *   - Return 0 on success, negative BNERV_E_* on failure; bnerv_last_error() returns a thread-local message.
+ *   - Thread-safe per stream; no global mutable state except read-only twiddle tables created through bnerv_fft_*.
+ */
+#ifndef BNERV_H
+#define BNERV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BNERV_ABI_VERSION 1
+
+#define BNERV_OK 0
+#define BNERV_E_ARG (-1)      /* bad argument / unsupported shape */
+#define BNERV_E_LAUNCH (-2)   /* hip launch error */
+#define BNERV_E_WS (-3)       /* workspace too small */
+
+int bnerv_abi_version(void);
+const char* bnerv_last_error(void);
+/* name of the gfx arch the code object was built for ("gfx950") */
+const char* bnerv_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Positional encoding.  Replaces PositionEncoding.forward (model_blocks.py:120-126):
+ *   v = pos * bases ; out = cat[sin v, cos v]  -> [N, 2L]
+ * f32 form: pos fp32, ONE IEEE fp32 multiply, accurate sinf/cosf (model_nerv.py:47-48, model_enerv.py:286-292).
+ * f64 form: pos fp64, product and sin/cos in fp64, result cast to fp32 (HNeRV_Boost, model_hnerv.py:241).
+ * `bases` is the fp32 table built by the host with the reference's own torch expression (model_blocks.py:113-117).
+ * No backward: pos carries no gradient.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int bnerv_pe_fwd_f32(void* stream, const float* pos, const float* bases, float* out, int N, int L);
+int bnerv_pe_fwd_f64(void* stream, const double* pos, const float* bases, float* out, int N, int L);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Grouped dense layers on [B, I] vectors (1x1 convs on [B,C,1,1]).  Replaces the CustomConv2d(kernel_size=1) calls of
+ * NeRV_MLP (model_blocks.py:66-71: stem / stem_t / t_branch) and of SFTLayer's four 1x1 convs (model_blocks.py:92-105).
+ * One launch evaluates up to BNERV_MAX_DENSE_GROUPS independent layers  y = act(W x + b).
+ *   act: 0 none, 1 relu, 2 sin.   aux (sin only, may be NULL): cos(Wx+b), saved for the backward.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define BNERV_MAX_DENSE_GROUPS 40
+#define BNERV_ACT_NONE 0
+#define BNERV_ACT_RELU 1
+#define BNERV_ACT_SIN 2
+
+typedef struct {
+    const float* x;   /* [B, I] */
+    const float* w;   /* [O, I] */
+    const float* b;   /* [O] or NULL */
+    float* y;         /* [B, O] */
+    float* aux;       /* [B, O] or NULL */
+    int I, O, act, _pad;
+} bnerv_dense_fwd_desc;
+
+typedef struct {
+    const float* x;    /* [B, I]  layer input */
+    const float* w;    /* [O, I] */
+    const float* y;    /* [B, O]  layer output (relu mask) */
+    const float* aux;  /* [B, O]  cos(pre) for sin */
+    const float* dy;   /* [B, O]  incoming gradient */
+    float* dpre;       /* [B, O]  scratch: gradient wrt pre-activation (written) */
+    float* dw;         /* [O, I]  written */
+    float* db;         /* [O]     written (may be NULL) */
+    float* dx_part;    /* [nchunk, B, I] partial input gradients (NULL: not needed); nchunk = ceil(O / BNERV_DENSE_DX_CHUNK) */
+    int I, O, act, _pad;
+} bnerv_dense_bwd_desc;
+
+#define BNERV_DENSE_DX_CHUNK 64
+
+int bnerv_dense_grouped_fwd(void* stream, const bnerv_dense_fwd_desc* groups, int n_groups, int B);
+int bnerv_dense_grouped_bwd(void* stream, const bnerv_dense_bwd_desc* groups, int n_groups, int B);
+
+/* Stand-alone TAT affine  y = x*(scale[b,c]+1) + shift[b,c]  (SFTLayer.forward, model_blocks.py:101-105) and its backward:
+ *   dx = g*(scale+1);  part[chunk][0][b,c] = sum_chunk g*x;  part[chunk][1][b,c] = sum_chunk g
+ * finish with bnerv_reduce_slabs(part, BNERV_SFT_CHUNKS, 2*B*C, out) -> out[0][b,c] = dscale, out[1][b,c] = dshift.
+ * (Inside the decoder blocks the affine is fused into the conv prologues; these two exist for the module-level API.) */
+#define BNERV_SFT_CHUNKS 32
+int bnerv_sft_affine_fwd(void* stream, const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW);
+int bnerv_sft_affine_bwd(void* stream, const float* x, const float* scale, const float* g, float* dx, float* part, int B, int C, int HW);
+
+/* out[i] = sum_{s<n_slabs} slabs[s*count + i]   (deterministic finish of every split reduction in this library) */
+int bnerv_reduce_slabs(void* stream, const float* slabs, int n_slabs, int count, float* out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution (fp32 MFMA 16x16x4), stride 1, square kernel k in {1,3}, zero padding (k-1)/2, with fused
+ * input prologue and output epilogue.  One kernel family serves the forward conv and the data gradient.
+ * Replaces CustomConv2d.forward = F.conv2d (lib/quant_ops.py:39-41) as used by UpConv (model_blocks.py:196-220),
+ * ResBlock_SFT (model_blocks.py:74-89), Conv_Up_Block (model_enerv.py:73-102), DownConv 'conv' (model_blocks.py:184-185)
+ * and head_layer (model_nerv.py:41,56), together with the elementwise ops around it:
+ *   SFTLayer affine x*(scale+1)+shift (model_blocks.py:101-105), GELU (model_blocks.py:81), PixelShuffle + Sin
+ *   (model_blocks.py:213-218, :129-134), residual add (model_blocks.py:89), OutImg tanh (model_blocks.py:57-63),
+ * and, for the data gradient, autograd's backward of the same.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* input prologues */
+#define BNERV_IN_PLAIN 0         /* a = x */
+#define BNERV_IN_AFFINE 1        /* a = x*(1+scale[b,c]) + shift[b,c]          (padding applies AFTER the affine) */
+#define BNERV_IN_GELU_AFFINE 2   /* a = gelu(x)*(1+scale[b,c]) + shift[b,c] */
+#define BNERV_IN_UNSHUFFLE 3     /* a[c*s*s+i*s+j][y][x] = x[c][y*s+i][x*s+j]  (pixel-unshuffle gather, s = in_s) */
+#define BNERV_IN_TANHGRAD 4      /* a = x * 0.5*(1-(2*aux0-1)^2)               (x = dL/dimg, aux0 = img = OutImg output) */
+/* output epilogues (v = conv result, o = output element) */
+#define BNERV_EP_BIAS 0          /* out = v + bias                              (optionally pixel-shuffled by out_s) */
+#define BNERV_EP_BIAS_SIN 1      /* u = v + bias; out = sin u; out2 = cos u     (pixel-shuffled by out_s) */
+#define BNERV_EP_BIAS_RES 2      /* out = v + bias + aux0 */
+#define BNERV_EP_BIAS_TANH 3     /* out = tanh(v + bias)*0.5 + 0.5 */
+#define BNERV_EP_PLAIN 4         /* out = v */
+#define BNERV_EP_DGELU 5         /* out = v*(1+scale[b,c])*gelu'(aux0);   partial: ds += v*gelu(aux0), dt += v */
+#define BNERV_EP_DSIN 6          /* t = aux1 + v*(1+scale[b,c]); out = t*aux2 (aux2 NULL: 1); partial: ds += v*aux0, dt += v */
+
+typedef struct {
+    const float* x;       /* input, conv-space [B, Cin, H, W]  (IN_UNSHUFFLE: stored as [B, Cin/s^2, H*s, W*s]) */
+    const float* w;       /* weight tensor [wCo, wCi, k, k] (OIHW, as in state_dict) */
+    const float* bias;    /* [Cout] or NULL */
+    float* out;           /* conv-space [B, Cout, H, W], stored pixel-shuffled as [B, Cout/s^2, H*s, W*s] when out_s>1 */
+    float* out2;          /* EP_BIAS_SIN: cos(u), same layout as out (may be NULL) */
+    const float* aux0;    /* see epilogue / prologue tables */
+    const float* aux1;
+    const float* aux2;
+    const float* scale;   /* [B, Cin] for IN_AFFINE / IN_GELU_AFFINE;  [B, Cout] for EP_DGELU / EP_DSIN */
+    const float* shift;   /* [B, Cin] for IN_AFFINE / IN_GELU_AFFINE */
+    float* partial;       /* EP_DGELU / EP_DSIN: [tiles][B][2][Cout] per-tile partial sums (written); finish with
+                             bnerv_reduce_slabs(partial, tiles, B*2*Cout, out) -> out[b][0][c] = ds, out[b][1][c] = dt */
+    int B, Cin, Cout, H, W;
+    int k;                /* 1 or 3 */
+    int in_mode, ep_mode;
+    int in_s, out_s;      /* shuffle factors (1 = none) */
+    int transposed;       /* 0: forward  (Cout=wCo, Cin=wCi, W(co,ci,t) = w[co][ci][t]);
+                             1: data gradient (Cout=wCi, Cin=wCo, W(co,ci,t) = w[ci][co][k*k-1-t]) */
+    int wCo, wCi;
+} bnerv_conv_desc;
+
+/* number of spatial tiles per sample (rows of `partial`) for an H x W conv-space image */
+int bnerv_conv_tiles(int H, int W);
+int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* d);
+
+/* Weight + bias gradient (autograd's backward of F.conv2d wrt weight/bias at the same call sites):
+ *   dw[co][ci][t] = sum_{b,p} g[b][co][p] * a[b][ci][p + t - pad],  db[co] = sum_{b,p} g[b][co][p]
+ * a = prologue(x) (IN_PLAIN / IN_AFFINE / IN_GELU_AFFINE), g gathered with pixel-unshuffle g_s or through tanh'
+ * (g_mode BNERV_IN_TANHGRAD with gaux = img).  Split over spatial tiles into slabs, finished deterministically. */
+typedef struct {
+    const float* x;       /* [B, Cin, H, W] */
+    const float* g;       /* [B, Cout, H, W] conv-space, stored shuffled [B, Cout/s^2, H*s, W*s] when g_s>1 */
+    const float* gaux;    /* img for BNERV_IN_TANHGRAD */
+    const float* scale;   /* [B, Cin] */
+    const float* shift;   /* [B, Cin] */
+    float* dw;            /* [Cout, Cin, k, k] written */
+    float* db;            /* [Cout] written (may be NULL) */
+    void* ws;             /* workspace of bnerv_conv_wgrad_ws_bytes() bytes */
+    size_t ws_bytes;
+    int B, Cin, Cout, H, W, k;
+    int in_mode;          /* prologue on x */
+    int g_mode;           /* BNERV_IN_PLAIN / BNERV_IN_UNSHUFFLE / BNERV_IN_TANHGRAD */
+    int g_s;
+} bnerv_wgrad_desc;
+
+size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int k);
+int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* d);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Loss and metrics.  Replaces loss_fn (hnerv_utils.py:335-397; variants L1, L2, L1_freq, Fusion10, Fusion10_freq)
+ * including its autograd backward, and psnr_fn_single (hnerv_utils.py:400-403).
+ *   loss_b = c_l1 * mean|d| + c_l2 * mean d^2 + c_ms * (1 - ms_ssim_b) + c_fft * mean|FFT2(pred)-FFT2(target)|_{re,im}
+ * with d = pred - target; the reported loss is mean_b loss_b (batch_average=True) and `grad` = d(loss)/d(pred).
+ *   L1: c_l1=1   L2: c_l2=1   L1_freq: c_l1=60,c_fft=1   Fusion10: c_l1=.7,c_ms=.3   Fusion10_freq: c_l1=42,c_ms=18,c_fft=1
+ * MS-SSIM follows pytorch_msssim 0.2.1 (win 11, sigma 1.5, 5 levels) -- third-party, PARITY UNPINNED.
+ * The 2-D DFT is a mixed-radix LDS FFT; H and W may have any prime factors <= BNERV_FFT_MAX_RADIX.
+ * stats_out: [B, 4] = {loss_b, sum|d|, sum d^2, ms_ssim_b};  loss_out: [1].
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define BNERV_FFT_MAX_RADIX 31
+#define BNERV_MSSSIM_LEVELS 5
+
+typedef struct {
+    const float* pred;    /* [B, C, H, W] */
+    const float* target;  /* [B, C, H, W] */
+    float* grad;          /* [B, C, H, W] written (may be NULL: value only) */
+    float* loss_out;      /* [1] */
+    float* stats_out;     /* [B, 4] */
+    void* ws;
+    size_t ws_bytes;
+    int B, C, H, W;
+    float c_l1, c_l2, c_ms, c_fft;
+} bnerv_loss_desc;
+
+size_t bnerv_loss_ws_bytes(int B, int C, int H, int W, int use_ms, int use_fft);
+/* Build the read-only FFT twiddle tables for H x W frames ahead of time.  Tables are otherwise built on first use,
+ * which allocates and copies synchronously -- not allowed while `stream` is being captured into a hipGraph. */
+int bnerv_fft_prepare(int H, int W);
+int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* d);
+/* per-sample MS-SSIM only (evaluate(): msssim_fn_single, hnerv_utils.py:410-412); out [B] */
+int bnerv_msssim(void* stream, const float* x, const float* y, float* out, void* ws, size_t ws_bytes, int B, int C, int H, int W);
+/* psnr[b] = -10 log10(mean_{CHW}(out-gt)^2 + 1e-9)  (hnerv_utils.py:400-403); ws: bnerv_psnr_ws_bytes() */
+size_t bnerv_psnr_ws_bytes(int B, int C, int H, int W);
+int bnerv_psnr(void* stream, const float* out, const float* gt, float* psnr, void* ws, size_t ws_bytes, int B, int C, int H, int W);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fused multi-tensor Adan step.  Replaces Adan.step -> _multi_tensor_adan (optimizer.py:125-235, :296-362), i.e. the
+ * slot the reference reserves for the external `fused_adan` extension (optimizer.py:365-395).
+ * Per tensor: p, g, exp_avg, exp_avg_sq, exp_avg_diff, neg_pre_grad (all n floats).  `first_step` != 0 makes
+ * neg_pre_grad := -g before the update (optimizer.py:190-192).  Scalars are those computed at optimizer.py:171-173,
+ * :208-226.  lr is read from DEVICE memory (lr_dev[0]) so a captured hipGraph replays with a changing schedule.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define BNERV_ADAN_MAX_TENSORS 48
+typedef struct {
+    float* p[BNERV_ADAN_MAX_TENSORS];
+    const float* g[BNERV_ADAN_MAX_TENSORS];
+    float* exp_avg[BNERV_ADAN_MAX_TENSORS];
+    float* exp_avg_sq[BNERV_ADAN_MAX_TENSORS];
+    float* exp_avg_diff[BNERV_ADAN_MAX_TENSORS];
+    float* neg_pre_grad[BNERV_ADAN_MAX_TENSORS];
+    int n[BNERV_ADAN_MAX_TENSORS];
+    int n_tensors;
+} bnerv_adan_chunk;
+
+typedef struct {
+    float beta1, beta2, beta3;
+    float eps, weight_decay;
+    float clip_global_grad_norm;
+    int no_prox;
+    /* bias corrections depend on the step count; like lr they are read from device memory:
+       sched_dev = {lr, bias_correction1, bias_correction2, sqrt(bias_correction3), first_step(0/1)} */
+    const float* sched_dev;
+} bnerv_adan_hyper;
+
+int bnerv_adan_multi_tensor(void* stream, const bnerv_adan_chunk* chunk, const bnerv_adan_hyper* h);
+
+/* flat-bucket helpers for the data-parallel gradient exchange (replaces DDP's bucket copy, train_nerv_all.py:254):
+ * gather `n_tensors` gradients into one contiguous bucket scaled by `scale`, and scatter it back. */
+typedef struct {
+    float* t[BNERV_ADAN_MAX_TENSORS * 2];
+    int n[BNERV_ADAN_MAX_TENSORS * 2];
+    int off[BNERV_ADAN_MAX_TENSORS * 2];
+    int n_tensors;
+} bnerv_bucket_chunk;
+int bnerv_bucket_gather(void* stream, const bnerv_bucket_chunk* c, float* bucket, float scale);
+int bnerv_bucket_scatter(void* stream, const bnerv_bucket_chunk* c, const float* bucket, float scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BNERV_H */

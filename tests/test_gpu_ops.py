@@ -1,0 +1,290 @@
+"""GPU parity tests (``-m gpu``): every HIP operator, called through the C-ABI, against the CPU oracle on the same seeded
+inputs, plus the golden fixtures produced by the real reference.  Tolerance per SURVEY 8(d): rtol 1e-3 (atol scaled to
+the tensor's magnitude) -- fp32 arithmetic, different summation order than MKLDNN."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import group, load_golden
+from oracle import cpu_ref, msssim_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RT = 1e-3
+
+
+def close(a, b, rtol=RT, atol=None, msg=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (msg, a.shape, b.shape)
+    if atol is None:
+        atol = 1e-5 + 1e-4 * float(b.abs().max())
+    err = (a - b).abs()
+    bad = err > atol + rtol * b.abs()
+    assert not bad.any(), f"{msg}: {int(bad.sum())}/{a.numel()} off, max abs err {float(err.max()):.3e}, ref max {float(b.abs().max()):.3e}"
+
+
+def gpu(t):
+    return t.detach().to(DEV).requires_grad_(t.requires_grad)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from boosting_nerv_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------------------------------------------------------ PE
+def test_pe_against_reference_golden(ops):
+    g = load_golden("pe.npz")
+    bases = torch.from_numpy(g["bases"])
+    t64 = torch.from_numpy(g["t64"])
+    o32 = ops.positional_encoding(t64[:, None].float().to(DEV), bases).view(3, -1).cpu()
+    o64 = ops.positional_encoding(t64[:, None].to(DEV), bases).view(3, -1).cpu()
+    oxy = ops.positional_encoding(torch.from_numpy(g["xy"]).to(DEV), bases).view(16, -1).cpu()
+    # sin/cos of arguments up to 1.4e8: libm implementations may differ by an ulp of the RESULT, nothing more
+    for name, got, ref in (("f32", o32, g["out_f32"]), ("f64", o64, g["out_f64"]), ("xy", oxy, g["out_xy"])):
+        err = np.abs(got.numpy() - ref).max()
+        assert err < 2e-6, (name, err)
+
+
+# --------------------------------------------------------------------------------------------------------------- dense
+@pytest.mark.parametrize("B", [1, 3])
+def test_dense_grouped_fwd_bwd(ops, B):
+    g = torch.Generator().manual_seed(3)
+    specs = [(160, 256, "sin"), (160, 64, "sin"), (32, 32, "relu"), (32, 12, "none"), (256, 1152, "sin"), (32, 95, "none")]
+    xs = [torch.randn(B, i, generator=g).requires_grad_(True) for i, _, _ in specs]
+    ws = [(torch.randn(o, i, 1, 1, generator=g) / math.sqrt(i)).requires_grad_(True) for i, o, _ in specs]
+    bs = [torch.randn(o, generator=g).requires_grad_(True) for _, o, _ in specs]
+    cots = [torch.randn(B, o, generator=g) for _, o, _ in specs]
+    ref = [cpu_ref._act(F.linear(x, w.flatten(1), b), a) for x, w, b, (_, _, a) in zip(xs, ws, bs, specs)]
+    rg = torch.autograd.grad(ref, xs + ws + bs, cots)
+    xg, wg, bg = [gpu(t) for t in xs], [gpu(t) for t in ws], [gpu(t) for t in bs]
+    out = ops.dense_grouped(xg, wg, bg, [a for _, _, a in specs])
+    for o, r in zip(out, ref):
+        close(o, r, msg="dense fwd")
+    gg = torch.autograd.grad(out, xg + wg + bg, [c.to(DEV) for c in cots])
+    for i, (a, b) in enumerate(zip(gg, rg)):
+        close(a, b, msg=f"dense grad {i}")
+
+
+def test_dense_shared_input_gradient(ops):
+    """32 SFT first layers read the same condition vector: its gradient is the sum over groups."""
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(2, 32, 1, 1, generator=g).requires_grad_(True)
+    ws = [(torch.randn(32, 32, 1, 1, generator=g) / 6).requires_grad_(True) for _ in range(7)]
+    bs = [torch.randn(32, generator=g).requires_grad_(True) for _ in range(7)]
+    ref = sum(torch.relu(F.conv2d(z, w, b)).sum() * (i + 1) for i, (w, b) in enumerate(zip(ws, bs)))
+    rz, = torch.autograd.grad(ref, [z])
+    zg = gpu(z)
+    out = ops.dense_grouped([zg] * 7, [gpu(w) for w in ws], [gpu(b) for b in bs], ["relu"] * 7)
+    tot = sum(o.sum() * (i + 1) for i, o in enumerate(out))
+    gz, = torch.autograd.grad(tot, [zg])
+    close(gz, rz, msg="shared dz")
+
+
+# ---------------------------------------------------------------------------------------------------------------- conv
+CONV_CASES = [  # B, Cin, Cout_total, H, W, k, s
+    (1, 12, 12, 16, 64, 3, 1), (2, 12, 48, 9, 33, 3, 2), (1, 15, 48, 11, 40, 3, 2), (2, 30, 750, 9, 16, 3, 5),
+    (1, 9, 63, 5, 6, 3, 3), (2, 20, 132, 6, 9, 1, 2), (1, 95, 100, 9, 16, 1, 5), (1, 55, 55, 17, 35, 3, 1),
+    (1, 3, 3, 1, 1, 3, 1), (1, 70, 18, 8, 32, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_ps_fwd_bwd(ops, case):
+    B, Cin, Ct, H, W, k, s = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(Ct, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).requires_grad_(True)
+    b = torch.randn(Ct, generator=g).requires_grad_(True)
+    ref = cpu_ref.upconv(x, w, b, s)
+    cot = torch.randn(ref.shape, generator=g)
+    rg = torch.autograd.grad(ref, [x, w, b], cot)
+    xg, wg, bg = gpu(x), gpu(w), gpu(b)
+    out = ops.conv2d_ps(xg, wg, bg, s)
+    close(out, ref, msg="conv fwd")
+    gg = torch.autograd.grad(out, [xg, wg, bg], cot.to(DEV))
+    for n, a, r in zip("xwb", gg, rg):
+        close(a, r, msg=f"conv d{n}")
+
+
+def test_sft_affine(ops):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 12, 19, 37, generator=g).requires_grad_(True)
+    sc = torch.randn(2, 12, 1, 1, generator=g).requires_grad_(True)
+    sh = torch.randn(2, 12, 1, 1, generator=g).requires_grad_(True)
+    ref = cpu_ref.sft_affine(x, sc, sh)
+    cot = torch.randn(ref.shape, generator=g)
+    rg = torch.autograd.grad(ref, [x, sc, sh], cot)
+    xs = [gpu(t) for t in (x, sc, sh)]
+    out = ops.sft_affine(*xs)
+    close(out, ref, msg="sft fwd")
+    for n, a, r in zip(("x", "scale", "shift"), torch.autograd.grad(out, xs, cot.to(DEV)), rg):
+        close(a, r, msg=f"sft d{n}")
+
+
+def _tat_inputs(B, Cc, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).requires_grad_(True)
+    x0 = mk(B, Cc, H, W)
+    mods = [mk(B, Cc, 1, 1, sc=0.5) for _ in range(4)]
+    w0, w1 = mk(Cc, Cc, 3, 3, sc=1 / math.sqrt(9 * Cc)), mk(Cc, Cc, 3, 3, sc=1 / math.sqrt(9 * Cc))
+    b0, b1 = mk(Cc, sc=0.1), mk(Cc, sc=0.1)
+    return x0, mods, w0, b0, w1, b1, g
+
+
+def _tat_ref(x0, mods, w0, b0, w1, b1):
+    s0, t0, s1, t1 = mods
+    f = F.gelu(F.conv2d(x0 * (s0 + 1) + t0, w0, b0, padding=1))
+    return x0 + F.conv2d(f * (s1 + 1) + t1, w1, b1, padding=1)
+
+
+@pytest.mark.parametrize("shape", [(1, 12, 16, 64), (2, 15, 11, 13), (1, 30, 45, 80), (2, 38, 9, 40)])
+def test_tat_block(ops, shape):
+    x0, mods, w0, b0, w1, b1, g = _tat_inputs(*shape, seed=7)
+    ref = _tat_ref(x0, mods, w0, b0, w1, b1)
+    cot = torch.randn(ref.shape, generator=g)
+    leaves = [x0] + mods + [w0, b0, w1, b1]
+    rg = torch.autograd.grad(ref, leaves, cot)
+    gl = [gpu(t) for t in leaves]
+    out = ops.tat_block(gl[0], gl[1], gl[2], gl[3], gl[4], gl[5], gl[6], gl[7], gl[8])
+    close(out, ref, msg="tat fwd")
+    names = ["x0", "s0", "t0", "s1", "t1", "w0", "b0", "w1", "b1"]
+    for n, a, r in zip(names, torch.autograd.grad(out, gl, cot.to(DEV)), rg):
+        close(a, r, msg=f"tat d{n}")
+
+
+@pytest.mark.parametrize("case", [(1, 12, 12, 16, 64, 3, 1), (2, 12, 12, 9, 33, 3, 2), (1, 30, 15, 9, 16, 3, 5), (1, 20, 33, 6, 9, 1, 2), (1, 9, 7, 5, 6, 3, 3)])
+def test_snerv_block(ops, case):
+    B, Cin, Cc, H, W, k, s = case
+    x0, mods, w0, b0, w1, b1, g = _tat_inputs(B, Cc, H * s, W * s, seed=11)
+    x = torch.randn(B, Cin, H, W, generator=g).requires_grad_(True)
+    wu = (torch.randn(Cc * s * s, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).requires_grad_(True)
+    bu = (torch.randn(Cc * s * s, generator=g) * 0.1).requires_grad_(True)
+    ref = _tat_ref(torch.sin(cpu_ref.upconv(x, wu, bu, s)), mods, w0, b0, w1, b1)
+    cot = torch.randn(ref.shape, generator=g)
+    leaves = [x, wu, bu] + mods + [w0, b0, w1, b1]
+    rg = torch.autograd.grad(ref, leaves, cot)
+    gl = [gpu(t) for t in leaves]
+    out = ops.snerv_block(*gl, s)
+    close(out, ref, msg="snerv fwd")
+    names = ["x", "wu", "bu", "s0", "t0", "s1", "t1", "w0", "b0", "w1", "b1"]
+    for n, a, r in zip(names, torch.autograd.grad(out, gl, cot.to(DEV)), rg):
+        close(a, r, msg=f"snerv d{n}")
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_head_tanh(ops, k):
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 12, 21, 45, generator=g).requires_grad_(True)
+    w = (torch.randn(3, 12, k, k, generator=g) / math.sqrt(12 * k * k)).requires_grad_(True)
+    b = torch.randn(3, generator=g).requires_grad_(True)
+    ref = cpu_ref.out_img(F.conv2d(x, w, b, padding=(k - 1) // 2))
+    cot = torch.randn(ref.shape, generator=g)
+    rg = torch.autograd.grad(ref, [x, w, b], cot)
+    gl = [gpu(t) for t in (x, w, b)]
+    out = ops.head_tanh(*gl)
+    close(out, ref, msg="head fwd")
+    for n, a, r in zip("xwb", torch.autograd.grad(out, gl, cot.to(DEV)), rg):
+        close(a, r, msg=f"head d{n}")
+
+
+def test_blocks_against_reference_goldens():
+    """The module-level API (same classes / state_dict keys as the reference) on the reference's own golden vectors."""
+    from oracle import configs
+    from boosting_nerv_amd import model_blocks as mb
+    from boosting_nerv_amd.model_enerv import Conv_Up_Block
+    npz = load_golden("blocks.npz")
+    args = configs.tiny_nerv()
+
+    def run(name, module):
+        b = group(npz, name + "/")
+        module.load_state_dict({k[3:]: v for k, v in b.items() if k.startswith("sd/")})
+        module.to(DEV)
+        x = b["x"].to(DEV).requires_grad_(True)
+        z = b["z"].to(DEV).requires_grad_(True)
+        y = module((x, z))
+        close(y, b["y"], msg=f"{name} fwd")
+        params = dict(module.named_parameters())
+        gs = torch.autograd.grad(y, [x, z] + list(params.values()), b["cot"].to(DEV))
+        close(gs[0], b["dx"], msg=f"{name} dx")
+        close(gs[1], b["dz"], msg=f"{name} dz")
+        for (pn, _), gval in zip(params.items(), gs[2:]):
+            close(gval, b[f"grad/{pn}"], msg=f"{name} grad {pn}")
+
+    run("sft_c12", mb.SFTLayer(32, 12, 1, "relu", 1, args=args))
+    run("tat_c15", mb.ResBlock_SFT(15, 15, cond_ch=32, in_act="relu", out_act="gelu", omega=1, args=args))
+    for name, ngf, new_ngf, s, k in (("blk_s1_k3_c12", 12, 12, 1, 3), ("blk_s2_k3_c15_12", 15, 12, 2, 3), ("blk_s3_k3_c9_7", 9, 7, 3, 3),
+                                     ("blk_s5_k1_c30", 10, 10, 5, 1), ("blk_s2_k1_c20_33", 20, 33, 2, 1)):
+        run(name, mb.NeRVBlock(dec_block=True, conv_type="pshuffel_3x3", ngf=ngf, new_ngf=new_ngf, ks=k, strd=s, bias=True, norm="none",
+                               act="sin", sft_ngf=32, args=args))
+    run("conv_up_block", Conv_Up_Block(ngf=8, new_ngf=24, ks=3, stride=5, bias=True, norm="none", act="sin", conv_type="pshuffel_3x3",
+                                       sft_ngf=32, args=args))
+    run("hnerv_dec0", mb.NeRVBlock(dec_block=False, conv_type="conv", ngf=4, new_ngf=10, ks=0, strd=1, bias=True, norm="none", act="sin",
+                                   sft_ngf=32, args=configs.tiny_hnerv()))
+
+
+# ---------------------------------------------------------------------------------------------------------------- loss
+@pytest.mark.parametrize("lt", ["L1", "L2", "L1_freq", "Fusion10", "Fusion10_freq"])
+@pytest.mark.parametrize("tag", ["small", "odd"])
+def test_loss_against_goldens_and_oracle(ops, lt, tag):
+    npz = load_golden("loss.npz")
+    pred = torch.from_numpy(npz[f"{tag}/pred"]).clone().requires_grad_(True)
+    tgt = torch.from_numpy(npz[f"{tag}/target"])
+    ref = cpu_ref.loss_fn(pred, tgt, lt)
+    rgrad, = torch.autograd.grad(ref, [pred])
+    pg = gpu(pred)
+    loss, stats = ops.loss_with_stats(pg, tgt.to(DEV), lt)
+    if f"{tag}/{lt}/loss" in npz.files:      # value produced by the real reference's loss_fn
+        gold = float(npz[f"{tag}/{lt}/loss"])
+        assert abs(loss.item() - gold) <= 2e-4 * abs(gold), (loss.item(), gold)
+    assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item()), (loss.item(), ref.item())
+    ggrad, = torch.autograd.grad(loss, [pg])
+    close(ggrad, rgrad, rtol=2e-3, atol=2e-3 * float(rgrad.abs().max()), msg=f"{lt} grad")
+    close(ops.psnr(pg, tgt.to(DEV)), cpu_ref.psnr_fn_single(pred, tgt), rtol=1e-5, atol=1e-3, msg="psnr")
+    if "Fusion" in lt:
+        close(ops.msssim(pg, tgt.to(DEV)), msssim_ref.ms_ssim(pred.detach(), tgt, data_range=1, size_average=False), rtol=1e-4, atol=1e-5, msg="msssim")
+
+
+def test_fft_loss_full_size_properties(ops):
+    """720x1280 and 1080x1920 (BASELINE sizes): value against the golden of the reference (720p) and linearity /
+    Parseval-type properties that do not need the oracle."""
+    npz = load_golden("loss.npz")
+    g = torch.Generator().manual_seed(int(npz["720p/seed"]))
+    tgt = torch.rand(1, 3, 720, 1280, generator=g)
+    pred = (tgt + 0.1 * torch.randn(tgt.shape, generator=g)).clamp(0, 1)
+    for lt in ("L1", "L2", "L1_freq", "Fusion10_freq"):
+        pg = pred.to(DEV).requires_grad_(True)
+        loss, _ = ops.loss_with_stats(pg, tgt.to(DEV), lt)
+        gold = float(npz[f"720p/{lt}/loss"])
+        assert abs(loss.item() - gold) <= 3e-4 * abs(gold), (lt, loss.item(), gold)
+        gg, = torch.autograd.grad(loss, [pg])
+        f = gg.flatten().cpu()
+        idx = torch.from_numpy(npz[f"720p/{lt}/grad.idx"])
+        ref = torch.from_numpy(npz[f"720p/{lt}/grad.val"])
+        close(f[idx], ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()), msg=f"720p {lt} grad samples")
+    # a single DC offset: F(d) is one bin of size c*H*W -> loss_fft = |c| * H*W / (H*W*2) = |c|/2, for every size
+    for H, W in ((1080, 1920), (720, 1280), (165, 203)):
+        t = torch.rand(1, 3, H, W, generator=g).to(DEV)
+        loss, _ = ops.loss_with_stats((t + 0.25).requires_grad_(True), t, "L1_freq")
+        assert abs(loss.item() - (60 * 0.25 + 0.125)) < 1e-3, (H, W, loss.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------- Adan
+def test_adan_against_reference_trajectory():
+    from boosting_nerv_amd.optimizer import Adan
+    npz = load_golden("optim.npz")
+    params = [torch.from_numpy(npz[f"p0/{i}"]).to(DEV).requires_grad_(True) for i in range(3)]
+    opt = Adan(params, lr=0.003)
+    for step in range(6):
+        for i, p in enumerate(params):
+            p.grad = torch.from_numpy(npz[f"g{step}/{i}"]).to(DEV)
+        for group_ in opt.param_groups:
+            group_["lr"] = 0.003 * (0.1 + 0.15 * step)
+        opt.step()
+        for i, p in enumerate(params):
+            close(p, torch.from_numpy(npz[f"p{step + 1}/{i}"]), rtol=2e-5, atol=2e-6, msg=f"adan step {step} tensor {i}")
