@@ -1,0 +1,99 @@
+"""The train step of train_nerv_all.py:328-350 as one object: forward -> loss -> backward -> (gradient all-reduce) -> Adan,
+with per-step PSNR accumulated on the device.  After a few eager steps the fixed-shape step is captured into hipGraphs and
+replayed (≈100 short kernels per step: launch latency, not arithmetic, is what a Python-driven loop would pay for).
+
+  world == 1 :  one graph   [fwd, loss, bwd, Adan]
+  world  > 1 :  two graphs  [fwd, loss, bwd, bucket-gather]  --eager RCCL all-reduce of ONE flat bucket--  [bucket-scatter, Adan]
+
+Everything that changes per step and is not data (lr, Adan bias corrections) lives in device memory written by
+Adan.prepare_step(), so the captured kernels never see a stale scalar."""
+import torch
+
+from . import hnerv_utils as hu
+from .dp import GradBucket
+
+
+class TrainStep:
+    def __init__(self, model, optimizer, loss_type, takes_image, batch_shape, device, use_graph=True, warmup_eager=3,
+                 process_group=None, world_size=1, clip_max_norm=0.0):
+        self.model, self.opt, self.loss_type = model, optimizer, loss_type
+        self.takes_image = takes_image                       # HNeRV_Boost consumes the frame; NeRV/ENeRV the frame index
+        self.dev = device
+        B, C, H, W = batch_shape
+        self.static_img = torch.zeros(B, C, H, W, dtype=torch.float32, device=device)
+        self.static_idx = torch.zeros(B, dtype=torch.float64, device=device)
+        self.use_graph = use_graph and clip_max_norm <= 0
+        self.clip_max_norm = clip_max_norm
+        self.warmup_eager = warmup_eager
+        self.n_calls = 0
+        self.graph_a = self.graph_b = None
+        self.loss_out = self.psnr_out = None
+        self.world = world_size
+        self.bucket = GradBucket(model.parameters(), process_group) if world_size > 1 else None
+        self.params = [p for p in model.parameters() if p.requires_grad]
+
+    # ---- pieces -------------------------------------------------------------------------------------------------------
+    def _fwd_bwd(self):
+        self.opt.zero_grad(set_to_none=True)
+        inp = self.static_img if self.takes_image else self.static_idx
+        img_out, _, _ = self.model(inp, norm_idx=self.static_idx)
+        loss = hu.loss_fn(img_out, self.static_img, self.loss_type)
+        loss.backward()
+        self.loss_out = loss.detach()
+        self.psnr_out = hu.psnr_fn_device(img_out.detach(), self.static_img)
+
+    def _eager(self):
+        self._fwd_bwd()
+        if self.bucket is not None:
+            self.bucket.allreduce_mean()
+        if self.clip_max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(self.params, self.clip_max_norm)
+        self.opt.prepare_step()
+        self.opt.launch_step()
+
+    def _capture(self):
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        self.graph_a = torch.cuda.CUDAGraph()
+        if self.bucket is None:
+            with torch.cuda.graph(self.graph_a, pool=pool):
+                self._fwd_bwd()
+                self.opt.launch_step()
+        else:
+            import ctypes as C
+            from . import _lib as L
+            lib = L.load()
+            with torch.cuda.graph(self.graph_a, pool=pool):
+                self._fwd_bwd()
+                for p in self.params:
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                for ck in self.bucket._build():
+                    L.check(lib.bnerv_bucket_gather(L.stream(), C.byref(ck), L.ptr(self.bucket.bucket), 1.0 / self.world), "bucket_gather")
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=pool):
+                for ck in self.bucket._build():
+                    L.check(lib.bnerv_bucket_scatter(L.stream(), C.byref(ck), L.ptr(self.bucket.bucket), 1.0), "bucket_scatter")
+                self.opt.launch_step()
+
+    # ---- one step ------------------------------------------------------------------------------------------------------
+    def __call__(self, img, norm_idx):
+        """img [B,3,H,W] fp32 and norm_idx [B] fp64, already on the device.  Returns (loss, psnr[B]) device tensors that are
+        overwritten by the next call."""
+        self.static_img.copy_(img, non_blocking=True)
+        self.static_idx.copy_(norm_idx, non_blocking=True)
+        if not self.use_graph or self.n_calls < self.warmup_eager:
+            self._eager()
+        else:
+            if self.graph_a is None:
+                self.opt.prepare_step()         # host side of THIS step (the capture below records its kernels, runs nothing)
+                self._capture()
+            else:
+                self.opt.prepare_step()
+            self.graph_a.replay()
+            if self.graph_b is not None:
+                import torch.distributed as dist
+                dist.all_reduce(self.bucket.bucket, op=dist.ReduceOp.SUM, group=self.bucket.group)
+                self.graph_b.replay()
+        self.n_calls += 1
+        return self.loss_out, self.psnr_out

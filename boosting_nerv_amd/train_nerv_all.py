@@ -1,0 +1,606 @@
+"""Train / eval driver -- drop-in for the reference's train_nerv_all.py: every flag of its CLI (train_nerv_all.py:28-110)
+with the same defaults, the same derived fields (fc_dim solver :193-217, exp_id/outf :118-137), the same train loop
+semantics (:322-410) and evaluate() metrics (:451-619), so scripts/regression/**.sh run unchanged.  Differences, all
+MI355X-motivated and listed in DESIGN.md:
+  * the step runs through engine.TrainStep (HIP kernels, hipGraph replay, device-side PSNR, no per-step host sync);
+  * data parallelism is one flat-bucket RCCL all-reduce per step (dp.GradBucket) instead of DistributedDataParallel;
+    launch with -d as the reference (mp.spawn) or under torchrun (RANK/WORLD_SIZE in the environment);
+  * `--data_path synthetic:bunny|uvg|NxHxW` selects the in-repo synthetic clip; frames are kept resident in HBM;
+  * evaluation metrics of all ranks are combined correctly (the reference drops the all-reduce result, :554-556).
+TensorBoard, GIF dumps and the seaborn histogram branch are reporting-only and optional/absent."""
+import argparse
+import csv
+import heapq
+import os
+import random
+import shutil
+from copy import deepcopy
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.optim as optim
+import torch.utils.data
+import yaml
+from torch.utils.data import Subset
+
+from .engine import TrainStep
+from .hnerv_utils import (RoundTensor, TransformInput, VideoDataSet, adjust_lr, all_reduce, data_split, msssim_fn_batch,
+                          psnr_fn_batch, quant_tensor, worker_init_fn)
+from .model_enerv import ENeRV_Boost
+from .model_hnerv import HNeRV, HNeRV_Boost
+from .model_nerv import NeRV_Boost
+
+
+def build_parser():
+    parser = argparse.ArgumentParser()
+    # Dataset parameters
+    parser.add_argument('--data_path', type=str, default='', help='data path for vid (or synthetic:bunny|uvg|NxHxW)')
+    parser.add_argument('--vid', type=str, default='k400_train0', help='video id')
+    parser.add_argument('--shuffle_data', action='store_true', help='randomly shuffle the frame idx')
+    parser.add_argument('--data_split', type=str, default='1_1_1', help='Valid_train/total_train/all data split')
+    parser.add_argument('--crop_list', type=str, default='640_1280', help='video crop size')
+    parser.add_argument('--resize_list', type=str, default='-1', help='video resize size')
+    # architecture
+    parser.add_argument('--model', type=str, default='', help='model name')
+    parser.add_argument('--embed', type=str, default='', help='empty string for HNeRV, and base value/embed_length for NeRV position encoding')
+    parser.add_argument('--ks', type=str, default='0_3_3', help='kernel size for encoder and decoder')
+    parser.add_argument('--enc_blks', type=int, default=1, help='the number of encoder blocks')
+    parser.add_argument('--enc_strds', type=int, nargs='+', default=[], help='stride list for encoder')
+    parser.add_argument('--enc_dim', type=str, default='64_16', help='enc latent dim and embedding ratio')
+    parser.add_argument('--modelsize', type=float, default=1.5, help='model parameters size: model size + embedding parameters')
+    parser.add_argument('--saturate_stages', type=int, default=-1, help='saturate stages for model size computation')
+    parser.add_argument('--lfreq', type=str, default="pi", help='frequency multiplier of the positional encoding')
+    parser.add_argument('--fc_dim', type=int, default=None, help='channel width of the stem output')
+    parser.add_argument('--fc_hw', type=str, default='9_16', help='out size (h,w) for mlp')
+    parser.add_argument('--reduce', type=float, default=1.2, help='chanel reduction for next stage')
+    parser.add_argument('--lower_width', type=int, default=32, help='lowest channel width for output feature maps')
+    parser.add_argument('--dec_strds', type=int, nargs='+', default=[5, 3, 2, 2, 2], help='strides list for decoder')
+    parser.add_argument('--dec_blks', type=int, nargs='+', default=[1, 1, 1, 1, 1], help='block number for decoder')
+    parser.add_argument("--conv_type", default=['convnext', 'pshuffel'], type=str, nargs="+", help='conv type for encoder/decoder',
+                        choices=['pshuffel', 'conv', 'convnext', 'interpolate', 'pshuffel_3x3'])
+    parser.add_argument('--norm', default='none', type=str, help='norm layer for generator', choices=['none', 'bn', 'in'])
+    parser.add_argument('--act', type=str, default='gelu', help='activation to use',
+                        choices=['relu', 'leaky', 'leaky01', 'relu6', 'gelu', 'swish', 'softplus', 'hardswish', 'sin', 'ressin'])
+    parser.add_argument('--sft_block', type=str, default='none', help='TAT block type')
+    parser.add_argument('--ch_t', type=int, default=32, help='sft in channels')
+    parser.add_argument('--block_dim', type=int, default=128, help='transformer dims in the enerv model')
+    # training
+    parser.add_argument('-j', '--workers', type=int, help='number of data loading workers', default=4)
+    parser.add_argument('-b', '--batchSize', type=int, default=1, help='input batch size')
+    parser.add_argument('--start_epoch', type=int, default=-1, help='starting epoch')
+    parser.add_argument('--not_resume', action='store_true', help='not resume from latest checkpoint')
+    parser.add_argument('-e', '--epochs', type=int, default=5, help='Epoch number')
+    parser.add_argument('--block_params', type=str, default='1_1', help='residual blocks and percentile to save')
+    parser.add_argument('--lr', type=float, default=0.001, help='learning rate')
+    parser.add_argument('--lr_type', type=str, default='cosine_0.1_1_0.1', help='learning rate type')
+    parser.add_argument('--loss', type=str, default='Fusion6', help='loss type')
+    parser.add_argument('--out_bias', default='tanh', type=str, help='using sigmoid/tanh/0.5 for output prediction')
+    parser.add_argument('--optim_type', default='adan', type=str, help='Adan | Adam')
+    parser.add_argument('--clip_max_norm', default=0., type=float, help='clip_max_norm')
+    parser.add_argument('--inpanting', default='none', type=str, help='do inpanting')
+    parser.add_argument('--interpolation', action='store_true', default=False, help='do interpolation')
+    parser.add_argument('--embed_inter', action='store_true', default=False, help='do interpolation')
+    parser.add_argument('--cabac', action='store_true', default=False)
+    # evaluation
+    parser.add_argument('--quant', action='store_true', default=False, help='enable quantization')
+    parser.add_argument('--eval_only', action='store_true', default=False, help='do evaluation only')
+    parser.add_argument('--eval_freq', type=int, default=10, help='evaluation frequency')
+    parser.add_argument('--quant_model_bit', type=int, default=8, help='bit length for model quantization')
+    parser.add_argument('--quant_embed_bit', type=int, default=6, help='bit length for embedding quantization')
+    parser.add_argument('--quant_axis', type=int, default=0, help='quantization axis (-1 means per tensor)')
+    parser.add_argument('--dump_images', action='store_true', default=False, help='dump the prediction images')
+    parser.add_argument('--dump_videos', action='store_true', default=False, help='concat the prediction images into video')
+    parser.add_argument('--eval_fps', action='store_true', default=False, help='fwd multiple times to test the fps')
+    parser.add_argument('--encoder_file', default='', type=str, help='specify the embedding file')
+    parser.add_argument('--dump_values', action='store_true', default=False)
+    parser.add_argument('--dump_features', action='store_true', default=False)
+    # distributed
+    parser.add_argument('--manualSeed', type=int, default=1, help='manual seed')
+    parser.add_argument('-d', '--distributed', action='store_true', default=False, help='distributed training')
+    # logging
+    parser.add_argument('--debug', action='store_true', help='debug status, earlier for train/eval')
+    parser.add_argument('-p', '--print-freq', default=50, type=int)
+    parser.add_argument('--weight', default='None', type=str, help='pretrained weights for ininitialization')
+    parser.add_argument('--overwrite', action='store_true', help='overwrite the output dir if already exists')
+    parser.add_argument('--outf', default='unify', help='folder to output images and model checkpoints')
+    parser.add_argument('--suffix', default='', help="suffix str for outf")
+    # MI355X-side switches (not in the reference)
+    parser.add_argument('--no_graph', action='store_true', help='disable hipGraph replay of the train step')
+    parser.add_argument('--host_frames', action='store_true', help='stream frames through the DataLoader instead of keeping them in HBM')
+    return parser
+
+
+def solve_fc_dim(args, final_size, full_data_length):
+    """The reference's inline size solver (train_nerv_all.py:193-217): channel width of the stem such that decoder params +
+    embedding params ~= --modelsize.  Returns (fc_dim, embed_param) and rewrites args.enc_dim as the reference does."""
+    if ('pe' in args.embed or 'le' in args.embed) and "HNeRV_Boost" not in args.model:
+        embed_param = 0
+        embed_dim = int(args.embed.split('_')[-1]) * 2
+        fc_param = np.prod([int(x) for x in args.fc_hw.split('_')])
+    else:
+        total_enc_strds = np.prod(args.enc_strds)
+        embed_hw = final_size / total_enc_strds ** 2
+        enc_dim1, embed_ratio = [float(x) for x in args.enc_dim.split('_')]
+        embed_dim = int(embed_ratio * args.modelsize * 1e6 / full_data_length / embed_hw) if embed_ratio < 1 else int(embed_ratio)
+        embed_param = float(embed_dim) / total_enc_strds ** 2 * final_size * full_data_length
+        if args.interpolation:
+            embed_param = embed_param / 2
+        args.enc_dim = f'{int(enc_dim1)}_{embed_dim}'
+        fc_param = (np.prod(args.enc_strds) // np.prod(args.dec_strds)) ** 2 * 9
+    decoder_size = args.modelsize * 1e6 - embed_param
+    ch_reduce = 1. / args.reduce
+    dec_ks1, dec_ks2 = [int(x) for x in args.ks.split('_')[1:]]
+    fix_ch_stages = len(args.dec_strds) if args.saturate_stages == -1 else args.saturate_stages
+    a = ch_reduce * sum([ch_reduce ** (2 * i) * s ** 2 * min((2 * i + dec_ks1), dec_ks2) ** 2 for i, s in enumerate(args.dec_strds[:fix_ch_stages])])
+    b = embed_dim * fc_param
+    c = args.lower_width ** 2 * sum([s ** 2 * min(2 * (fix_ch_stages + i) + dec_ks1, dec_ks2) ** 2 for i, s in enumerate(args.dec_strds[fix_ch_stages:])])
+    fc_dim = args.fc_dim if args.fc_dim is not None else int(np.roots([a, b, c - decoder_size]).max())
+    return fc_dim, embed_param
+
+
+def build_model(args):
+    if args.model == "NeRV_Boost":
+        args.expansion = 1
+        return NeRV_Boost(1, args=args)
+    if args.model == "ENeRV_Boost":
+        args.expansion = 3
+        return ENeRV_Boost(3, args=args)
+    if args.model == "HNeRV_Boost":
+        return HNeRV_Boost(args)
+    if args.model == "HNeRV":
+        return HNeRV(args)
+    raise ValueError(f"unknown --model {args.model!r}")
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    torch.set_printoptions(precision=4)
+    if args.debug:
+        args.eval_freq = 1
+        args.outf = 'output/debug'
+    else:
+        args.outf = os.path.join('output', args.outf)
+    args.enc_strd_str, args.dec_strd_str = ','.join([str(x) for x in args.enc_strds]), ','.join([str(x) for x in args.dec_strds])
+    args.quant_str = f'quant_M{args.quant_model_bit}_E{args.quant_embed_bit}'
+    args.exp_id = exp_id = f'{args.vid}/Size{args.modelsize}'
+    args.outf = os.path.join(args.outf, exp_id)
+    if args.overwrite and os.path.isdir(args.outf):
+        print('Will overwrite the existing output dir!')
+        shutil.rmtree(args.outf)
+    os.makedirs(args.outf, exist_ok=True)
+    port = hash(args.exp_id) % 20000 + 10000
+    args.init_method = f'tcp://127.0.0.1:{port}'
+    print(f'init_method: {args.init_method}', flush=True)
+    torch.set_printoptions(precision=2)
+    args.ngpus_per_node = torch.cuda.device_count()
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:      # launched by torchrun: one process per GPU already
+        args.distributed = True
+        args.ngpus_per_node = int(os.environ["WORLD_SIZE"])
+        args.init_method = "env://"
+        train(int(os.environ.get("LOCAL_RANK", 0)), args)
+    elif args.distributed and args.ngpus_per_node > 1:
+        mp.spawn(train, nprocs=args.ngpus_per_node, args=(args,))
+    else:
+        train(None, args)
+
+
+def data_to_gpu(x, device):
+    return x.to(device, non_blocking=True)
+
+
+class _IndexOnly(torch.utils.data.Dataset):
+    """Same length / indices as the full dataset but returns only (idx, norm_idx): frames stay resident in HBM."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        return {'idx': idx, 'norm_idx': float(idx + 1) / self.n}
+
+
+def train(local_rank, args):
+    torch.manual_seed(args.manualSeed)
+    np.random.seed(args.manualSeed)
+    random.seed(args.manualSeed)
+    if not torch.cuda.is_available():
+        raise RuntimeError("train_nerv_all: no ROCm GPU visible -- the decoder path has no CPU fallback")
+    world = 1
+    if args.distributed and args.ngpus_per_node > 1:
+        rank = int(os.environ["RANK"]) if args.init_method == "env://" else local_rank
+        dist.init_process_group(backend='nccl', init_method=args.init_method, world_size=args.ngpus_per_node, rank=rank)
+        torch.cuda.set_device(local_rank)
+        world = args.ngpus_per_node
+        if args.batchSize < world:
+            raise ValueError(f"-b {args.batchSize} with {world} GPUs gives a per-GPU batch of 0 (the reference needs -b >= #GPUs, :168)")
+        args.batchSize = int(args.batchSize / world)
+    is_main = local_rank in [0, None]
+    device = torch.device('cuda', local_rank if local_rank is not None else 0)
+
+    args.metric_names = ['pred_seen_psnr', 'pred_seen_ssim', 'pred_unseen_psnr', 'pred_unseen_ssim',
+                         'quant_seen_psnr', 'quant_seen_ssim', 'quant_unseen_psnr', 'quant_unseen_ssim']
+    best_metric_list = [torch.tensor(0) for _ in range(len(args.metric_names))]
+
+    # dataloaders (same construction order as the reference: full loader, split, train loader -- then the model)
+    full_dataset = VideoDataSet(args)
+    args.final_size = full_dataset.final_size
+    args.full_data_length = len(full_dataset)
+    resident = not args.host_frames and not full_dataset.embed_inter
+    loader_ds = _IndexOnly(len(full_dataset)) if resident else full_dataset
+    workers = 0 if resident else args.workers
+    sampler = torch.utils.data.distributed.DistributedSampler(loader_ds) if world > 1 else None
+    full_dataloader = torch.utils.data.DataLoader(loader_ds, batch_size=args.batchSize, shuffle=False, num_workers=workers,
+                                                  pin_memory=True, sampler=sampler, drop_last=False, worker_init_fn=worker_init_fn)
+    split_num_list = [int(x) for x in args.data_split.split('_')]
+    train_ind_list, args.val_ind_list = data_split(list(range(args.full_data_length)), split_num_list, args.shuffle_data, 0)
+    args.dump_vis = (args.dump_images or args.dump_videos)
+    train_dataset = Subset(loader_ds, train_ind_list)
+    train_sampler = torch.utils.data.distributed.DistributedSampler(train_dataset) if world > 1 else None
+    train_dataloader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batchSize, shuffle=(train_sampler is None),
+                                                   num_workers=workers, pin_memory=True, sampler=train_sampler, drop_last=True,
+                                                   worker_init_fn=worker_init_fn)
+
+    args.fc_dim, embed_param = solve_fc_dim(args, args.final_size, args.full_data_length)
+    model = build_model(args)
+
+    if is_main:
+        with open(os.path.join(args.outf, 'args.yaml'), 'w') as f:
+            f.write(yaml.safe_dump({k: v for k, v in args.__dict__.items() if isinstance(v, (int, float, str, bool, list, type(None)))},
+                                   default_flow_style=False))
+        encoder_param = (sum([p.data.nelement() for p in model.encoder.parameters()]) / 1e6)
+        decoder_param = model.decoder_params()
+        total_param = decoder_param + embed_param / 1e6
+        args.encoder_param, args.decoder_param, args.total_param = encoder_param, decoder_param, total_param
+        param_str = f'Encoder_{round(encoder_param, 2)}M_Decoder_{round(decoder_param, 4)}M_Total_{round(total_param, 4)}M'
+        print(f'{args}\n {param_str}', flush=True)
+        with open('{}/rank0.txt'.format(args.outf), 'a') as f:
+            f.write(str(model) + '\n' + f'{param_str}\n')
+    writer = None
+    if is_main:
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            writer = SummaryWriter(os.path.join(args.outf, param_str, 'tensorboard'))
+        except Exception:
+            writer = None
+
+    print("Use GPU: {} for training".format(local_rank))
+    model = model.to(device)
+    if args.optim_type == "Adam":
+        optimizer = optim.Adam(model.parameters(), lr=args.lr)
+    elif args.optim_type == "Adan":
+        from .optimizer import Adan
+        optimizer = Adan(model.parameters(), lr=args.lr)
+    else:
+        raise ValueError(f"--optim_type {args.optim_type!r}: pass Adan or Adam (the reference's default 'adan' matches neither branch, :260-264)")
+    args.transform_func = TransformInput(args)
+
+    # resume
+    checkpoint = None
+    if args.weight != 'None':
+        print("=> loading checkpoint '{}'".format(args.weight))
+        checkpoint = torch.load(args.weight, map_location='cpu')
+        new_ckt = {k.replace('blocks.0.', '').replace('module.', ''): v for k, v in checkpoint['state_dict'].items()}
+        model.load_state_dict(new_ckt, strict=False)
+        print("=> loaded checkpoint '{}' (epoch {})".format(args.weight, checkpoint['epoch']))
+    if not args.not_resume:
+        checkpoint_path = os.path.join(args.outf, 'model_latest.pth')
+        if os.path.isfile(checkpoint_path):
+            checkpoint = torch.load(checkpoint_path, map_location='cpu')
+            model.load_state_dict(checkpoint['state_dict'])
+            print("=> Auto resume loaded checkpoint '{}' (epoch {})".format(checkpoint_path, checkpoint['epoch']))
+        else:
+            print("=> No resume checkpoint found at '{}'".format(checkpoint_path))
+    if args.start_epoch < 0:
+        if checkpoint is not None:
+            args.start_epoch = checkpoint['epoch']
+        args.start_epoch = max(args.start_epoch, 0)
+
+    frames_dev = None
+    if resident:
+        frames_dev = torch.stack([full_dataset[i]['img'] for i in range(len(full_dataset))]).to(device)
+    args._frames_dev = frames_dev
+
+    if args.eval_only:
+        results_list, hw = evaluate(model, full_dataloader, local_rank, args, args.dump_vis, huffman_coding=True)
+        print_str = f'PSNR for output {hw} for quant {args.quant_str}: '
+        for i, (metric_name, best_metric_value, metric_value) in enumerate(zip(args.metric_names, best_metric_list, results_list)):
+            best_metric_value = best_metric_value if best_metric_value > metric_value.max() else metric_value.max()
+            print_str += f'best_{metric_name}: {RoundTensor(best_metric_value, 2 if "psnr" in metric_name else 4)} | '
+            best_metric_list[i] = best_metric_value
+        if is_main:
+            print(print_str, flush=True)
+            with open('{}/eval.txt'.format(args.outf), 'a') as f:
+                f.write(print_str + '\n\n')
+            args.train_time, args.cur_epoch = 0, args.epochs
+            Dump2CSV(args, best_metric_list, results_list, [torch.tensor(0)], 'eval.csv')
+        return
+
+    h, w = [int(x) for x in args.crop_list.split('_')[:2]]
+    takes_image = 'pe' not in args.embed or "HNeRV_Boost" in args.model
+    step = TrainStep(model, optimizer, args.loss, takes_image, (args.batchSize, 3, h, w), device, use_graph=not args.no_graph and args.optim_type == "Adan",
+                     world_size=world, clip_max_norm=args.clip_max_norm) if args.optim_type == "Adan" and args.transform_func.identity else None
+
+    start = datetime.now()
+    time_list, psnr_list = [], []
+    results_list = [torch.zeros(1) for _ in args.metric_names]
+    for epoch in range(args.start_epoch, args.epochs):
+        model.train()
+        epoch_start_time = datetime.now()
+        psnr_sum = torch.zeros((), dtype=torch.float32, device=device)      # accumulated on the device: no per-step sync
+        psnr_cnt = 0
+        n_iter = len(train_dataloader)
+        for i, sample in enumerate(train_dataloader):
+            if i > 10 and args.debug:
+                break
+            norm_idx, img_idx = data_to_gpu(sample['norm_idx'], device), data_to_gpu(sample['idx'], device)
+            img_data = frames_dev[img_idx] if resident else data_to_gpu(sample['img'], device)
+            cur_epoch = (epoch + float(i) / n_iter) / args.epochs
+            lr = adjust_lr(optimizer, cur_epoch, i, args)
+            if step is not None:
+                _, psnr_b = step(img_data, norm_idx)
+            else:      # generic path (Adam, inpainting masks): same kernels, eager
+                img_in, img_gt, inpaint_mask = args.transform_func(img_data, img_idx)
+                cur_input = img_in if takes_image else norm_idx
+                img_out, _, _ = model(cur_input, norm_idx=norm_idx)
+                from .hnerv_utils import loss_fn, psnr_fn_device
+                if inpaint_mask is not None:
+                    final_loss = loss_fn(img_out * inpaint_mask, img_gt * inpaint_mask, args.loss)
+                else:
+                    final_loss = loss_fn(img_out, img_gt, args.loss)
+                optimizer.zero_grad()
+                final_loss.backward()
+                if args.clip_max_norm > 0:
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_max_norm)
+                optimizer.step()
+                psnr_b = psnr_fn_device(img_out.detach(), img_gt)
+            psnr_sum += psnr_b.sum()
+            psnr_cnt += psnr_b.numel()
+            if i % args.print_freq == 0 or i == n_iter - 1:
+                pred_psnr = (psnr_sum / psnr_cnt).cpu()          # the only host sync of the loop, every print_freq steps
+                print_str = '[{}] Rank:{}, Epoch[{}/{}], Step [{}/{}], lr:{:.2e} pred_PSNR: {}'.format(
+                    datetime.now().strftime("%Y/%m/%d %H:%M:%S"), local_rank, epoch + 1, args.epochs, i + 1, n_iter, lr, RoundTensor(pred_psnr, 4))
+                print(print_str, flush=True)
+                if is_main:
+                    with open('{}/rank0.txt'.format(args.outf), 'a') as f:
+                        f.write(print_str + '\n')
+        pred_psnr = psnr_sum / max(psnr_cnt, 1)
+        if world > 1:
+            pred_psnr = all_reduce([pred_psnr.clone()])[0]
+        pred_psnr = pred_psnr.cpu()
+        if is_main:
+            epoch_end_time = datetime.now()
+            if writer is not None:
+                writer.add_scalar(f'Train/pred_PSNR_{h}X{w}', pred_psnr, epoch + 1)
+                writer.add_scalar('Train/lr', lr, epoch + 1)
+            print("Time/epoch: \tCurrent:{:.2f} \tAverage:{:.2f}".format((epoch_end_time - epoch_start_time).total_seconds(),
+                                                                        (epoch_end_time - start).total_seconds() / (epoch + 1 - args.start_epoch)))
+            time_list.append((epoch_end_time - epoch_start_time).total_seconds())
+
+        if (epoch + 1) % args.eval_freq == 0 or (args.epochs - epoch) in [1, 3, 5]:
+            results_list, hw = evaluate(model, full_dataloader, local_rank, args, args.dump_vis if epoch == args.epochs - 1 else False,
+                                        True if epoch == args.epochs - 1 else False)
+            if is_main:
+                print_str = f'Eval at epoch {epoch + 1} for {hw}: '
+                for i, (metric_name, best_metric_value, metric_value) in enumerate(zip(args.metric_names, best_metric_list, results_list)):
+                    best_metric_value = best_metric_value if best_metric_value > metric_value.max() else metric_value.max()
+                    if 'psnr' in metric_name:
+                        if writer is not None:
+                            writer.add_scalar(f'Val/{metric_name}_{hw}', metric_value.max(), epoch + 1)
+                            writer.add_scalar(f'Val/best_{metric_name}_{hw}', best_metric_value, epoch + 1)
+                        if metric_name == 'pred_seen_psnr':
+                            psnr_list.append(metric_value.max())
+                    print_str += f'{metric_name}: {RoundTensor(metric_value, 4)} | '
+                    best_metric_list[i] = best_metric_value
+                print(print_str, flush=True)
+                with open('{}/rank0.txt'.format(args.outf), 'a') as f:
+                    f.write(print_str + '\n')
+
+        if is_main:
+            torch.save({'epoch': epoch + 1, 'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict()},
+                       '{}/model_latest.pth'.format(args.outf))
+            if (epoch + 1) % args.epochs == 0:
+                args.cur_epoch = epoch + 1
+                args.train_time = str(datetime.now() - start)
+                Dump2CSV(args, best_metric_list, results_list, psnr_list, f'epoch{epoch + 1}.csv')
+
+    print_str = "Training complete in: " + str(datetime.now() - start)
+    total_time_seconds = float(sum(time_list))
+    print_str += "\n Training wo evaluation complete in: {}, {}s".format(convert(total_time_seconds), total_time_seconds)
+    print(print_str)
+    if is_main:
+        with open('{}/rank0.txt'.format(args.outf), 'a') as f:
+            f.write(print_str + '\n')
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def convert(seconds):
+    seconds = seconds % (24 * 3600)
+    hour = seconds // 3600
+    seconds %= 3600
+    return "%d:%02d:%02d" % (hour, seconds // 60, seconds % 60)
+
+
+def Dump2CSV(args, best_results_list, results_list, psnr_list, filename='results.csv'):
+    g = lambda k, d=0: getattr(args, k, d)
+    result_dict = {'Vid': args.vid, 'CurEpoch': g('cur_epoch'), 'Time': g('train_time'), 'FPS': g('fps'), 'Split': args.data_split,
+                   'Embed': args.embed, 'Crop': args.crop_list, 'Resize': args.resize_list, 'Lr_type': args.lr_type, 'LR (E-3)': args.lr * 1e3,
+                   'Batch': args.batchSize, 'Size (M)': f'{round(g("encoder_param"), 2)}_{round(g("decoder_param"), 2)}_{round(g("total_param"), 2)}',
+                   'ModelSize': args.modelsize, 'Epoch': args.epochs, 'Loss': args.loss, 'Act': args.act, 'Norm': args.norm, 'FC': args.fc_hw,
+                   'Reduce': args.reduce, 'ENC_type': args.conv_type[0], 'ENC_strds': args.enc_strd_str, 'KS': args.ks, 'enc_dim': args.enc_dim,
+                   'DEC': args.conv_type[1], 'DEC_strds': args.dec_strd_str, 'lower_width': args.lower_width, 'Quant': args.quant_str,
+                   'bits/param': g('bits_per_param'), 'bits/param w/ overhead': g('full_bits_per_param'), 'bits/pixel': g('total_bpp'),
+                   f'PSNR_list_{args.eval_freq}': ','.join([RoundTensor(v, 2) for v in psnr_list])}
+    result_dict.update({f'best_{k}': RoundTensor(v, 4) for k, v in zip(args.metric_names, best_results_list)})
+    result_dict.update({f'{k}': RoundTensor(v, 4) for k, v in zip(args.metric_names, results_list)})
+    csv_path = os.path.join(args.outf, filename)
+    print(f'results dumped to {csv_path}')
+    with open(csv_path, 'w', newline='') as f:
+        wr = csv.writer(f)
+        wr.writerow([''] + list(result_dict.keys()))
+        wr.writerow([0] + list(result_dict.values()))
+
+
+def _huffman_total_bits(counts):
+    """sum_i count_i * code_length_i of a Huffman code built over the data symbols plus one EOF symbol of count 1 -- what
+    the reference obtains from dahuffman's HuffmanCodec.from_data + get_code_table (train_nerv_all.py:593-605).  Any optimal
+    Huffman code has the same total, so tie-breaking does not matter."""
+    n = len(counts)
+    heap = [(int(c), i, [i]) for i, c in enumerate(list(counts) + [1])]      # last leaf = EOF
+    depth = [0] * (n + 1)
+    heapq.heapify(heap)
+    uid = n + 1
+    while len(heap) > 1:
+        a = heapq.heappop(heap)
+        b = heapq.heappop(heap)
+        for leaf in a[2] + b[2]:
+            depth[leaf] += 1
+        heapq.heappush(heap, (a[0] + b[0], uid, a[2] + b[2]))
+        uid += 1
+    return sum(int(c) * d for c, d in zip(counts, depth[:n]))
+
+
+@torch.no_grad()
+def evaluate(model, full_dataloader, local_rank, args, dump_vis=False, huffman_coding=False):
+    img_embed_list = []
+    model_list, quant_ckt = quant_model(model, args)
+    metric_list = [[] for _ in range(len(args.metric_names))]
+    frames_dev = getattr(args, '_frames_dev', None)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    dequant_vid_embed = None
+    fps, hw = 0.0, (0, 0)
+    for model_ind, cur_model in enumerate(model_list):
+        time_list = []
+        cur_model.eval()
+        cur_model.time_decode = True
+        device = next(cur_model.parameters()).device
+        if dump_vis:
+            visual_dir = f'{args.outf}/visualize_model' + ('_quant' if model_ind else '_orig')
+            os.makedirs(visual_dir, exist_ok=True)
+        for i, sample in enumerate(full_dataloader):
+            if i > 10 and args.debug:
+                break
+            norm_idx, img_idx = data_to_gpu(sample['norm_idx'], device), data_to_gpu(sample['idx'], device)
+            img_data = frames_dev[img_idx] if frames_dev is not None else data_to_gpu(sample['img'], device)
+            img_data, img_gt, inpaint_mask = args.transform_func(img_data, img_idx)
+            takes_image = 'pe' not in args.embed or "HNeRV_Boost" in args.model
+            cur_input = img_data if takes_image else norm_idx
+            embed_in = dequant_vid_embed[i] if model_ind and "HNeRV" in args.model else None
+            if args.interpolation and args.embed_inter and 'pre_img' in sample and img_idx.item() in args.val_ind_list:
+                img_out, embed_list, dec_time = cur_model(cur_input, embed_in, pre_img=data_to_gpu(sample['pre_img'], device),
+                                                          post_img=data_to_gpu(sample['post_img'], device), norm_idx=norm_idx)
+            else:
+                img_out, embed_list, dec_time = cur_model(cur_input, embed_in, norm_idx=norm_idx)
+            if model_ind == 0:
+                img_embed_list.append(embed_list[0])
+            time_list.append(dec_time)
+            if args.eval_fps:
+                time_list.pop()
+                for _ in range(100):
+                    _, _, dec_time = cur_model(cur_input, embed_list[0], norm_idx=norm_idx)
+                    time_list.append(dec_time)
+            pred_psnr, pred_ssim = psnr_fn_batch([img_out], img_gt), msssim_fn_batch([img_out], img_gt)
+            for metric_idx, cur_v in enumerate([pred_psnr, pred_ssim]):
+                for batch_i, cur_img_idx in enumerate(img_idx.tolist()):
+                    metric_idx_start = 2 if cur_img_idx in args.val_ind_list else 0
+                    metric_list[metric_idx_start + metric_idx + 4 * model_ind].append(cur_v[:, batch_i])
+            if dump_vis:
+                _save_images(img_out, img_idx, pred_psnr, visual_dir, i, args)
+            if i % args.print_freq == 0 or i == len(full_dataloader) - 1:
+                fps = args.batchSize / (sum(time_list) / len(time_list))
+                print_str = '[{}] Rank:{}, Eval at Step [{}/{}] , FPS {}, '.format(datetime.now().strftime("%Y/%m/%d %H:%M:%S"), local_rank, i + 1,
+                                                                                   len(full_dataloader), round(fps, 1))
+                for v_name, v_list in zip(args.metric_names, metric_list):
+                    cur_value = torch.stack(v_list, dim=-1).mean(-1) if len(v_list) else torch.zeros(1)
+                    print_str += f'{v_name}: {RoundTensor(cur_value, 4)} | '
+                if local_rank in [0, None]:
+                    print(print_str, flush=True)
+                    with open('{}/rank0.txt'.format(args.outf), 'a') as f:
+                        f.write(print_str + '\n')
+        if model_ind == 0:
+            if "HNeRV" in args.model:
+                vid_embed = torch.cat(img_embed_list, 0)
+                quant_embed, dequant_emved = quant_tensor(vid_embed, args.quant_embed_bit)
+                dequant_vid_embed = dequant_emved.split(args.batchSize, dim=0)
+            else:
+                quant_embed = None
+        args.fps = fps
+        hw = tuple(img_data.shape[-2:])
+        cur_model.time_decode = False
+        cur_model.train()
+    # mean of per-frame values (== the reference's results_list, :550), combined over ranks by sum/count
+    results_list = []
+    for v_list in metric_list:
+        if len(v_list):
+            s = torch.stack(v_list, dim=1).sum(1)
+            n = torch.tensor([float(len(v_list))])
+        else:
+            s, n = torch.zeros(1), torch.zeros(1)
+        if world > 1:
+            dev = next(model.parameters()).device
+            s, n = s.to(dev), n.to(dev)
+            dist.all_reduce(s)
+            dist.all_reduce(n)
+            s, n = s.cpu(), n.cpu()
+        results_list.append(s / n.clamp(min=1))
+
+    if local_rank in [0, None] and quant_ckt is not None and huffman_coding:
+        quant_v_list, tmin_scale_len = [], 0
+        if "HNeRV" in args.model and quant_embed is not None:
+            quant_v_list.append(quant_embed['quant'].flatten().cpu())
+            tmin_scale_len += quant_embed['min'].nelement() + quant_embed['scale'].nelement()
+        for k, layer_wt in quant_ckt.items():
+            quant_v_list.append(layer_wt['quant'].flatten().cpu())
+            tmin_scale_len += layer_wt['min'].nelement() + layer_wt['scale'].nelement()
+        allv = torch.cat(quant_v_list).to(torch.int64)
+        counts = torch.bincount(allv, minlength=1)
+        counts = counts[counts > 0].tolist()
+        total_bits = _huffman_total_bits(counts)
+        args.bits_per_param = total_bits / allv.numel()
+        total_bits += tmin_scale_len * 16
+        args.full_bits_per_param = total_bits / allv.numel()
+        args.total_bpp = total_bits / args.final_size / args.full_data_length
+        print_str = f'After quantization and encoding: \n bits per parameter: {round(args.full_bits_per_param, 2)}, bits per pixel: {round(args.total_bpp, 4)}'
+        print(print_str, flush=True)
+        with open('{}/rank0.txt'.format(args.outf), 'a') as f:
+            f.write(print_str + '\n')
+    return results_list, hw
+
+
+def _save_images(img_out, img_idx, pred_psnr, visual_dir, i, args):
+    from PIL import Image
+    for batch_ind in range(img_out.shape[0]):
+        full_ind = i * args.batchSize + batch_ind
+        psnr_s = ','.join([str(round(x[batch_ind].item(), 2)) for x in pred_psnr])
+        arr = (img_out[batch_ind].clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+        Image.fromarray(arr).save(f'{visual_dir}/pred_{full_ind:04d}_{psnr_s}.png')
+
+
+def quant_model(model, args):                                                         # reference train_nerv_all.py:622-642
+    model_list = [deepcopy(model)]
+    if args.quant_model_bit == -1:
+        return model_list, None
+    cur_model = deepcopy(model)
+    quant_ckt, cur_ckt = [cur_model.state_dict() for _ in range(2)]
+    encoder_k_list = []
+    for k, v in cur_ckt.items():
+        if 'encoder' in k:
+            encoder_k_list.append(k)
+        else:
+            quant_v, new_v = quant_tensor(v, args.quant_model_bit)
+            quant_ckt[k] = quant_v
+            cur_ckt[k] = new_v
+    for encoder_k in encoder_k_list:
+        del quant_ckt[encoder_k]
+    cur_model.load_state_dict(cur_ckt)
+    model_list.append(cur_model)
+    return model_list, quant_ckt
+
+
+if __name__ == '__main__':
+    main()

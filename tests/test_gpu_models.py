@@ -1,0 +1,192 @@
+"""GPU parity tests (``-m gpu``) of the whole decoder path: the three Boost models (module API, same state_dict as the
+reference) against golden vectors of the REAL reference, the full BASELINE C1 shape, and short training trajectories
+(eager and hipGraph replay) against the CPU oracle with identical seeds and frame order."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import check_summary, group, load_golden
+from oracle import configs, cpu_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(name, args):
+    from boosting_nerv_amd.model_enerv import ENeRV_Boost
+    from boosting_nerv_amd.model_hnerv import HNeRV_Boost
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    if args.model == "NeRV_Boost":
+        return NeRV_Boost(1, args=args)
+    if args.model == "ENeRV_Boost":
+        return ENeRV_Boost(3, args=args)
+    return HNeRV_Boost(args)
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny_nerv", configs.tiny_nerv), ("tiny_enerv", configs.tiny_enerv), ("tiny_hnerv", configs.tiny_hnerv)])
+def test_tiny_models_against_reference_goldens(name, cfg):
+    from boosting_nerv_amd import hnerv_utils as hu
+    npz = load_golden(name + ".npz")
+    args = cfg()
+    torch.manual_seed(1)
+    model = _build(name, args)
+    sd = {k: v for k, v in group(npz, "sd/").items()}
+    # seeded construction reproduces the reference's parameters (init ORDER parity): bit for bit for the decoder; the
+    # ConvNeXt encoder goes through trunc_normal_ (erfinv), whose last bit depends on the host CPU's vector ISA
+    for k, v in model.state_dict().items():
+        if k.startswith("encoder."):
+            torch.testing.assert_close(v, sd[k], rtol=0, atol=1e-6, msg=k)
+        else:
+            assert torch.equal(v, sd[k]), k
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    frame = torch.rand(2, 3, 180, 320, generator=torch.Generator().manual_seed(int(npz["frame_seed"]))).to(DEV)
+    norm_idx = torch.from_numpy(npz["norm_idx"]).to(DEV)
+    inp = frame if args.model == "HNeRV_Boost" else norm_idx
+    img, lst, _ = model(inp, norm_idx=norm_idx)
+    check_summary(img, npz, "img", 1e-3, 1e-5)
+    for i, t in enumerate(lst):
+        check_summary(t, npz, f"list{i}", 1e-3, 2e-5)
+    loss = hu.loss_fn(img, frame, "L1_freq")
+    gold = float(npz["loss_L1_freq"])
+    assert abs(loss.item() - gold) < 3e-4 * abs(gold), (loss.item(), gold)
+    torch.testing.assert_close(hu.psnr_fn_single(img, frame), torch.from_numpy(npz["psnr"]), rtol=1e-4, atol=2e-3)
+    loss.backward()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        gn = float(npz[f"gnorm/{k}"])
+        if gn < 0:
+            continue
+        got = p.grad.double().norm().item()
+        assert abs(got - gn) <= 5e-3 * gn + 1e-6, (k, got, gn)
+        if f"grad/{k}" in npz.files:
+            ref = torch.from_numpy(npz[f"grad/{k}"])
+            err = (p.grad.cpu() - ref).abs().max().item()
+            worst = max(worst, err / (gn + 1e-12))
+            assert err <= 5e-3 * max(gn, float(ref.abs().max())) + 1e-6, (k, err, gn)
+
+
+def test_c1_full_size_against_reference_golden():
+    """BASELINE config C1/C2 (NeRV-boost 1.5M, 720x1280): seeded init identical to the reference, forward / loss / gradient
+    norms against the reference's own run."""
+    import hashlib
+    from boosting_nerv_amd import hnerv_utils as hu
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    npz = load_golden("full_models.npz")
+    torch.manual_seed(1)
+    model = NeRV_Boost(1, args=configs.c1())
+    h = hashlib.sha256()
+    for k, v in model.state_dict().items():
+        h.update(k.encode())
+        h.update(v.numpy().tobytes())
+    assert h.hexdigest() == str(npz["c1/sd_sha256"])
+    assert sum(p.numel() for p in model.parameters()) == int(npz["c1/n_params"]) == 1489577
+    model = model.to(DEV)
+    frame = torch.rand(1, 3, 720, 1280, generator=torch.Generator().manual_seed(5)).to(DEV)
+    norm_idx = torch.tensor([37 / 132], dtype=torch.float64, device=DEV)
+    img, lst, _ = model(norm_idx, norm_idx=norm_idx)
+    check_summary(img, npz, "c1/img", 1e-3, 1e-5)
+    for i, t in enumerate(lst):
+        check_summary(t, npz, f"c1/list{i}", 1e-3, 2e-5)
+    loss = hu.loss_fn(img, frame, "L1_freq")
+    gold = float(npz["c1/loss_L1_freq"])
+    assert abs(loss.item() - gold) < 3e-4 * abs(gold)
+    assert abs(hu.psnr_fn_single(img, frame).item() - float(npz["c1/psnr"][0])) < 0.02     # the +-0.02 dB bar
+    loss.backward()
+    for k, p in model.named_parameters():
+        gn = float(npz[f"c1/gnorm/{k}"])
+        got = p.grad.double().norm().item()
+        assert abs(got - gn) <= 5e-3 * gn + 1e-6, (k, got, gn)
+
+
+@pytest.mark.parametrize("name,cfg", [("c3", configs.c3), ("c4", configs.c4)])
+def test_big_models_init_and_step_run(name, cfg):
+    """C3 (HNeRV-boost 3M) and C4 (E-NeRV-boost 3M) at 1080x1920: seeded init hash equals the reference's; one full train
+    step runs and produces finite values (the per-block arithmetic is covered by the block/tiny-model parity tests)."""
+    import hashlib
+    from boosting_nerv_amd import hnerv_utils as hu
+    from boosting_nerv_amd.optimizer import Adan
+    npz = load_golden("full_models.npz")
+    args = cfg()
+    torch.manual_seed(1)
+    model = _build(name, args)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(npz[f"{name}/keys"]) and [",".join(map(str, v.shape)) for v in sd.values()] == list(npz[f"{name}/shapes"])
+    assert sum(p.numel() for p in model.parameters()) == int(npz[f"{name}/n_params"])
+    if name != "c3":     # c3's ConvNeXt init (trunc_normal_/erfinv) is not bit-stable across host CPUs; c4 is
+        h = hashlib.sha256()
+        for k, v in sd.items():
+            h.update(k.encode())
+            h.update(v.numpy().tobytes())
+        assert h.hexdigest() == str(npz[f"{name}/sd_sha256"])
+    else:
+        first = next(iter(sd.values())).flatten()[:8]
+        torch.testing.assert_close(first, torch.from_numpy(npz["c3/first_vals"]), rtol=0, atol=1e-6)
+    model = model.to(DEV)
+    opt = Adan(model.parameters(), lr=1e-3)
+    frame = torch.rand(1, 3, 1080, 1920, generator=torch.Generator().manual_seed(5)).to(DEV)
+    norm_idx = torch.tensor([37 / 600], dtype=torch.float64, device=DEV)
+    inp = frame if args.model == "HNeRV_Boost" else norm_idx
+    img, _, _ = model(inp, norm_idx=norm_idx)
+    assert img.shape == (1, 3, 1080, 1920)
+    loss = hu.loss_fn(img, frame, "Fusion10_freq")
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss).item()
+    assert all(torch.isfinite(p).all().item() for p in model.parameters())
+
+
+def _oracle_trajectory(sd0, frames, norm_idxs, order, lrs, loss_type):
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    adan = cpu_ref.AdanState(list(sd.values()), lr=lrs[0])
+    losses, psnrs = [], []
+    for step, fi in enumerate(order):
+        adan.lr = lrs[step]
+        l, p, _ = cpu_ref.train_step("NeRV_Boost", sd, adan, frames[fi:fi + 1], norm_idxs[fi:fi + 1], loss_type)
+        losses.append(l.item())
+        psnrs.append(p.item())
+    return losses, psnrs, {k: v.detach() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_trajectory_matches_oracle(use_graph):
+    """8 Adan steps of the tiny NeRV_Boost on 4 synthetic frames with a moving LR: per-step loss/PSNR and final parameters
+    against the CPU oracle (same init, same frame order).  The graph variant also proves that a captured step replays with
+    new data, new lr and new bias corrections."""
+    from boosting_nerv_amd.engine import TrainStep
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    from boosting_nerv_amd.optimizer import Adan
+    from boosting_nerv_amd.synth import SyntheticVideo
+    vid = SyntheticVideo(4, 180, 320)
+    frames = torch.stack([vid.frame(i) for i in range(4)])
+    norm_idxs = torch.tensor([(i + 1) / 4 for i in range(4)], dtype=torch.float64)
+    order = [2, 0, 3, 1, 1, 3, 0, 2]
+    lrs = [0.003 * (0.1 + 0.1 * s) for s in range(len(order))]
+    torch.manual_seed(1)
+    model = NeRV_Boost(1, args=configs.tiny_nerv())
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    ref_l, ref_p, ref_sd = _oracle_trajectory(sd0, frames, norm_idxs, order, lrs, "Fusion10_freq")
+    model = model.to(DEV)
+    opt = Adan(model.parameters(), lr=lrs[0])
+    step = TrainStep(model, opt, "Fusion10_freq", False, (1, 3, 180, 320), torch.device(DEV), use_graph=use_graph, warmup_eager=2)
+    fd, nd = frames.to(DEV), norm_idxs.to(DEV)
+    for s, fi in enumerate(order):
+        for g in opt.param_groups:
+            g["lr"] = lrs[s]
+        loss, psnr = step(fd[fi:fi + 1], nd[fi:fi + 1])
+        assert abs(loss.item() - ref_l[s]) <= 2e-3 * abs(ref_l[s]), (s, loss.item(), ref_l[s])
+        assert abs(psnr.item() - ref_p[s]) <= 0.02, (s, psnr.item(), ref_p[s])
+    if use_graph:
+        assert step.graph_a is not None
+    # Adan's update m/sqrt(n) is sign-like where a gradient is ~0, so single elements may differ by a fraction of sum(lr);
+    # the bulk must agree tightly
+    for k, p in model.state_dict().items():
+        d = (p.cpu() - ref_sd[k]).abs()
+        assert d.max().item() <= 0.1 * sum(lrs), (k, d.max().item())
+        assert d.mean().item() <= 2e-5, (k, d.mean().item())
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
