@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py -- train frames/sec of the Boosting-NeRV conditional-decoder path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W                       (1 GPU)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (N GPUs, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch: forward of the decoder, Fusion10_freq loss, backward, [one flat-bucket
+RCCL all-reduce when N > 1], fused Adan -- exactly train_nerv_all.py:328-348 of the reference -- on frames already resident
+in HBM.  Workload at N=1: BASELINE configs[1] = NeRV-boost 1.5M on a Bunny-shaped synthetic clip (132 x 3x720x1280), batch
+1 per GPU (the reference recipe's `-b 1`; `-b N -d` on N GPUs), weak scaling.  Prints ONE JSON line on rank 0.
+
+Extra objects on the line:
+  roofline      the dominant kernel (fp32 MFMA implicit-GEMM 3x3 conv 12->12 at 720x1280), timed live with HIP events on
+                the stream it is launched on, against its algorithmic flops / the dense fp32 MFMA peak
+  cpu_baseline  the CPU oracle (oracle/cpu_ref.py: the reference's algorithm in plain fp32 torch) running the SAME train step
+                on this box's host cores for a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+RECIPES = {
+    # scripts/regression/bunny/nerv_boost.sh:4-9 (--modelsize 0.8 -> "1.5M")
+    "c1": dict(n=132, h=720, w=1280, flags="--model NeRV_Boost --sft_block res_sft --ch_t 32 --optim_type Adan --conv_type convnext pshuffel_3x3 "
+               "--act sin --norm none --crop_list 720_1280 --resize_list -1 --loss Fusion10_freq --embed pe_1.25_80 --fc_hw 9_16 "
+               "--dec_strds 5 2 2 2 2 --ks 0_3_3 --reduce 2 --dec_blks 1 1 2 2 2 --modelsize 0.8 -e 300 --eval_freq 30 --lower_width 12 -b 1 --lr 0.003",
+               name="NeRV-boost 1.5M"),
+    # scripts/regression/UVG/hnerv_boost.sh:7-12 (--modelsize 2.8 -> "3M")
+    "c3": dict(n=600, h=1080, w=1920, flags="--model HNeRV_Boost --sft_block res_sft --ch_t 32 --optim_type Adan --conv_type convnext pshuffel_3x3 "
+               "--act sin --norm none --crop_list 1080_1920 --resize_list -1 --loss Fusion10_freq --embed pe_1.25_80 --enc_strds 5 3 2 2 2 "
+               "--enc_dim 64_16 --dec_strds 5 3 2 2 2 --ks 0_1_5 --reduce 1.2 --dec_blks 1 1 2 2 2 --modelsize 2.8 -e 300 --eval_freq 30 "
+               "--lower_width 12 -b 1 --lr 0.003", name="HNeRV-boost 3M"),
+    # scripts/regression/UVG/enerv_boost.sh:7-12 (--modelsize 1.8 -> "3M")
+    "c4": dict(n=600, h=1080, w=1920, flags="--model ENeRV_Boost --sft_block res_sft --ch_t 32 --block_dim 128 --optim_type Adan "
+               "--conv_type convnext pshuffel_3x3 --act sin --norm none --crop_list 1080_1920 --resize_list -1 --loss Fusion10_freq "
+               "--embed pe_1.25_80 --fc_hw 9_16 --dec_strds 5 3 2 2 2 --ks 0_3_3 --reduce 2 --dec_blks 1 1 2 2 2 --modelsize 1.8 -e 300 "
+               "--eval_freq 30 --lower_width 12 -b 1 --lr 0.0015", name="E-NeRV-boost 3M"),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
+PEAK_HBM_GBS = 8000.0
+
+
+def build(cfg_name):
+    from boosting_nerv_amd import train_nerv_all as T
+    r = RECIPES[cfg_name]
+    args = T.build_parser().parse_args(r["flags"].split() + ["--data_path", f"synthetic:{r['n']}x{r['h']}x{r['w']}", "--vid", "bench"])
+    args.final_size = r["h"] * r["w"]
+    args.full_data_length = r["n"]
+    args.outf = "bench"
+    args.fc_dim, _ = T.solve_fc_dim(args, args.final_size, args.full_data_length)
+    torch.manual_seed(args.manualSeed)
+    return args, T.build_model(args)
+
+
+def dominant_kernel_roofline(dev, reps=30):
+    """TAT conv0 forward of the last stage: [affine prologue -> 3x3 conv 12->12 -> bias] at 720x1280, the most frequent heavy
+    launch of a C1 step (5 forward + 4 data-gradient launches of this shape per step share the same kernel body).
+    Algorithmic work per launch (SURVEY 8(d) convention: 2*MACs; activations once in + once out + weights, 4 B each):
+      flops = 2 * 12*12*9 * 720*1280 = 2.389 GFLOP ;  bytes = (12 + 12)*720*1280*4 + 12*12*9*4 = 88.5 MB  (AI = 27 flop/B)
+    AI is above the ridge (157.3 TF / 8 TB/s = 19.7 flop/B) -> bounded by the fp32 MFMA peak."""
+    from boosting_nerv_amd import ops, _lib as L
+    B, Cc, H, W = 1, 12, 720, 1280
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(B, Cc, H, W, generator=g).to(dev)
+    w = (torch.randn(Cc, Cc, 3, 3, generator=g) / 10).to(dev)
+    b = torch.randn(Cc, generator=g).to(dev)
+    sc, sh = torch.randn(B, Cc, generator=g).to(dev) * 0.1, torch.randn(B, Cc, generator=g).to(dev) * 0.1
+    out = torch.empty_like(x)
+    run = lambda: ops._conv(x, w, b, out, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS, scale=sc, shift=sh)
+    for _ in range(5):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # current stream == launch stream
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / reps
+    flops = 2.0 * Cc * Cc * 9 * H * W
+    nbytes = (2 * Cc * H * W + Cc * Cc * 9) * 4.0
+    ach = flops / t / 1e12
+    return {"kernel": "conv_igemm_kernel<3,IN_AFFINE,EP_BIAS,1> 12->12 3x3 @720x1280", "bound": "mfma", "achieved": round(ach, 2),
+            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(t * 1e6, 2), "algorithmic_GB_per_s": round(nbytes / t / 1e9, 1), "flops_per_launch": flops,
+            "bytes_per_launch": nbytes}
+
+
+def cpu_baseline(args, model_cpu_sd, frames, norm_idxs, budget_s=20.0, max_steps=8):
+    from oracle import cpu_ref
+    ncores = min(os.cpu_count() or 1, 64)      # one thread per physical core at most: SMT siblings / >64 threads slow the MKLDNN convs down
+    torch.set_num_threads(ncores)
+    sd = {k: v.clone().float().requires_grad_(True) for k, v in model_cpu_sd.items()}
+    adan = cpu_ref.AdanState(list(sd.values()), lr=args.lr)
+    kind = args.model
+    cpu_ref.train_step(kind, sd, adan, frames[0:1], norm_idxs[0:1], args.loss)       # warm-up
+    n, t0 = 0, time.time()
+    while n < max_steps and (time.time() - t0) < budget_s:
+        i = (n + 1) % frames.shape[0]
+        cpu_ref.train_step(kind, sd, adan, frames[i:i + 1], norm_idxs[i:i + 1], args.loss)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full train steps (fwd + {args.loss} + bwd + Adan) of the same model/frame size after 1 warm-up, oracle/cpu_ref.py on torch CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c1", choices=sorted(RECIPES))
+    ap.add_argument("--no_graph", action="store_true")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if a.gpus > 1 and world == 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+
+    from boosting_nerv_amd.dp import shard_indices
+    from boosting_nerv_amd.engine import TrainStep
+    from boosting_nerv_amd.hnerv_utils import adjust_lr
+    from boosting_nerv_amd.optimizer import Adan
+    from boosting_nerv_amd.synth import SyntheticVideo
+
+    args, model = build(a.config)
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+    n_params = sum(p.numel() for p in model.parameters())
+    model = model.to(dev)
+    opt = Adan(model.parameters(), lr=args.lr)
+    r = RECIPES[a.config]
+    vid = SyntheticVideo(r["n"], r["h"], r["w"])
+    my_idx = shard_indices(r["n"], rank, world, seed=0)            # DistributedSampler's shard of the frame set (all frames at N=1)
+    keep = my_idx[:min(len(my_idx), 48 if r["h"] > 720 else 132)]
+    frames = torch.stack([vid.frame(i, device=dev) for i in keep])  # resident in HBM before the timed region
+    norm = torch.tensor([(i + 1) / r["n"] for i in keep], dtype=torch.float64, device=dev)
+    takes_image = "HNeRV" in args.model
+    per_gpu_batch = 1
+    step = TrainStep(model, opt, args.loss, takes_image, (per_gpu_batch, 3, r["h"], r["w"]), dev, use_graph=not a.no_graph,
+                     warmup_eager=3, world_size=world)
+    args.epochs = 300
+    n_iter = len(keep)
+
+    def run(k0, k):
+        for s in range(k0, k0 + k):
+            i = s % n_iter
+            adjust_lr(opt, (s / n_iter) / args.epochs, i, args)
+            step(frames[i:i + 1], norm[i:i + 1])
+
+    run(0, max(a.warmup, 5))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    run(max(a.warmup, 5), a.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    loss, psnr = step.loss_out.item(), step.psnr_out.mean().item()
+    if rank == 0:
+        frames_total = a.steps * per_gpu_batch * world
+        out = {"metric": "train frames/sec", "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+               "warmup": max(a.warmup, 5), "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+               "config": {"workload": f"{r['name']} ({n_params} params, fc_dim {args.fc_dim}) train step on a synthetic "
+                                      f"{'Bunny' if a.config == 'c1' else 'UVG'}-shaped clip {r['n']}x3x{r['h']}x{r['w']}: decoder fwd + {args.loss} + bwd + "
+                                      f"{'flat-bucket RCCL all-reduce + ' if world > 1 else ''}fused Adan; frames resident in HBM",
+                          "baseline_config": {"c1": "configs[1]", "c3": "configs[2]", "c4": "configs[3]"}[a.config], "global_batch": per_gpu_batch * world,
+                          "per_gpu_batch": per_gpu_batch, "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
+                          "last_loss": round(loss, 4), "last_train_psnr_db": round(psnr, 3)}}
+        out["roofline"] = dominant_kernel_roofline(dev) if a.config == "c1" else None
+        if world == 1 and not a.no_cpu_baseline:
+            fcpu = torch.stack([vid.frame(i) for i in keep[:4]])
+            ncpu = torch.tensor([(i + 1) / r["n"] for i in keep[:4]], dtype=torch.float64)
+            out["cpu_baseline"] = cpu_baseline(args, sd_cpu, fcpu, ncpu)
+            out["gpu_over_cpu"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,12 +138,24 @@ __global__ __launch_bounds__(256) void sft_affine_bwd_kernel(const float* __rest
     if (threadIdx.x < 2) part[((size_t)chunk * 2 + threadIdx.x) * BC + bc] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
 
-__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int count, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+// out[i] = sum_k slabs[k*count + i]: EPB consecutive elements x (256/EPB) slab lanes per block, fixed combination order
+template <int EPB>
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int count, float* __restrict__ out) {
+    constexpr int LANES = 256 / EPB;
+    __shared__ float red[LANES][EPB];
+    const int e = threadIdx.x % EPB, lane = threadIdx.x / EPB;
+    const int i = blockIdx.x * EPB + e;
     float s = 0.f;
-    for (int k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * count + i];
-    out[i] = s;
+    if (i < count)
+        for (int k = lane; k < n_slabs; k += LANES) s += slabs[(size_t)k * count + i];
+    red[lane][e] = s;
+    __syncthreads();
+    if (lane == 0 && i < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < LANES; ++k) t += red[k][e];
+        out[i] = t;
+    }
 }
 
 }  // namespace
@@ -223,7 +235,10 @@ extern "C" int bnerv_sft_affine_bwd(void* stream, const float* x, const float* s
 
 extern "C" int bnerv_reduce_slabs(void* stream, const float* slabs, int n_slabs, int count, float* out) {
     BNERV_REQUIRE(slabs && out && n_slabs > 0 && count > 0, "reduce_slabs: bad args");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs, count, out);
+    if (count >= 2048 || n_slabs <= 16)
+        hipLaunchKernelGGL(reduce_slabs_kernel<32>, dim3(cdiv(count, 32)), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs, count, out);
+    else
+        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(cdiv(count, 4)), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs, count, out);
     BNERV_LAUNCH_CHECK("reduce_slabs");
     return BNERV_OK;
 }

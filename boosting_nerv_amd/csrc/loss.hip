@@ -29,7 +29,7 @@ namespace {
 // =====================================================================================================================
 // L1 / L2 statistics
 // =====================================================================================================================
-constexpr int NSB = 64;   // partial blocks per sample
+constexpr int NSB = 512;  // partial blocks per sample
 
 __global__ __launch_bounds__(256) void diff_stats_kernel(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ part, int n_per_sample) {
     const int b = blockIdx.y;
@@ -51,13 +51,16 @@ __global__ __launch_bounds__(256) void diff_stats_kernel(const float* __restrict
     }
 }
 
-__global__ void psnr_final_kernel(const float* __restrict__ part, float* __restrict__ psnr, int B, int n_per_sample) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+// one wave per sample: lane-strided partial sums, then a wave reduction in fp64
+__global__ __launch_bounds__(64) void psnr_final_kernel(const float* __restrict__ part, float* __restrict__ psnr, int B, int n_per_sample) {
+    const int b = blockIdx.x;
     double s2 = 0.0;
-    for (int k = 0; k < NSB; ++k) s2 += (double)part[((size_t)b * NSB + k) * 2 + 1];
-    const float mse = (float)(s2 / (double)n_per_sample);
-    psnr[b] = -10.0f * log10f(mse + 1e-9f);
+    for (int k = threadIdx.x; k < NSB; k += 64) s2 += (double)part[((size_t)b * NSB + k) * 2 + 1];
+    s2 = wave_sum_d(s2);
+    if (threadIdx.x == 0) {
+        const float mse = (float)(s2 / (double)n_per_sample);
+        psnr[b] = -10.0f * log10f(mse + 1e-9f);
+    }
 }
 
 // grad = k1*sign(d) + k2*d     (losses without the MS-SSIM term)
@@ -546,12 +549,14 @@ struct FinalArgs {
     int B, C, n_per_sample, ncolblk;
     float c_l1, c_l2, c_ms, c_fft;
 };
-__global__ void loss_final_kernel(const FinalArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one wave: lane-strided sums over the partial arrays (independent loads in flight), wave reductions in fp64
+__global__ __launch_bounds__(64) void loss_final_kernel(const FinalArgs a) {
+    const int lane = threadIdx.x;
     double total = 0.0;
     for (int b = 0; b < a.B; ++b) {
         double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < NSB; ++k) { s1 += (double)a.stats_part[((size_t)b * NSB + k) * 2]; s2 += (double)a.stats_part[((size_t)b * NSB + k) * 2 + 1]; }
+        for (int k = lane; k < NSB; k += 64) { s1 += (double)a.stats_part[((size_t)b * NSB + k) * 2]; s2 += (double)a.stats_part[((size_t)b * NSB + k) * 2 + 1]; }
+        s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
         double l = (double)a.c_l1 * (s1 / a.n_per_sample) + (double)a.c_l2 * (s2 / a.n_per_sample);
         double ms = 0.0;
         if (a.msval) {
@@ -561,14 +566,17 @@ __global__ void loss_final_kernel(const FinalArgs a) {
         }
         if (a.fft_part) {
             double f = 0.0;
-            for (int c = 0; c < a.C; ++c)
-                for (int k = 0; k < a.ncolblk; ++k) f += (double)a.fft_part[(size_t)(b * a.C + c) * a.ncolblk + k];
+            const int nf = a.C * a.ncolblk;
+            for (int k = lane; k < nf; k += 64) f += (double)a.fft_part[(size_t)b * nf + k];
+            f = wave_sum_d(f);
             l += (double)a.c_fft * f / (2.0 * (double)a.n_per_sample);
         }
-        a.stats_out[b * 4 + 0] = (float)l; a.stats_out[b * 4 + 1] = (float)s1; a.stats_out[b * 4 + 2] = (float)s2; a.stats_out[b * 4 + 3] = (float)ms;
+        if (lane == 0) {
+            a.stats_out[b * 4 + 0] = (float)l; a.stats_out[b * 4 + 1] = (float)s1; a.stats_out[b * 4 + 2] = (float)s2; a.stats_out[b * 4 + 3] = (float)ms;
+        }
         total += l;
     }
-    a.loss_out[0] = (float)(total / a.B);
+    if (lane == 0) a.loss_out[0] = (float)(total / a.B);
 }
 __global__ void msssim_final_kernel(const float* __restrict__ msval, float* __restrict__ out, int B, int C) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -769,7 +777,7 @@ extern "C" int bnerv_psnr(void* stream, const float* o, const float* gt, float* 
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_stats(st, o, gt, (float*)ws, B, C * H * W);
     if (rc) return rc;
-    hipLaunchKernelGGL(psnr_final_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, (const float*)ws, psnr, B, C * H * W);
+    hipLaunchKernelGGL(psnr_final_kernel, dim3(B), dim3(64), 0, st, (const float*)ws, psnr, B, C * H * W);
     BNERV_LAUNCH_CHECK("psnr_final");
     return BNERV_OK;
 }

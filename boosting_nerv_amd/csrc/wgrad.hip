@@ -139,32 +139,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WArgs wa) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[n], acc[m][n], 0, 0, 0);
         }
     }
-    // slab[(block*4 + wave)][co][n]; D layout: lane holds rows (cout) 4*kq..4*kq+3 of column (n) li
-    float* slab = wa.slab + (size_t)(blockIdx.x * 4 + wave) * Cout * wa.ncols;
+    // cross-wave reduction through LDS (fixed order => deterministic), then ONE slab per block:
+    // slab[block][co][n]; D layout: lane holds rows (cout) 4*kq..4*kq+3 of column (n) li
+    __syncthreads();
+    float* s_red = smem;                                      // [4 waves][MTW*16][NTW*16]  (fits: <= 4*64*64 floats only for (4,4); checked on host)
+    constexpr int RW = NTW * 16, RSZ = MTW * 16 * RW;
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const int col = n_base + n * 16 + li;
-            if (col >= wa.ncols) continue;
+        for (int n = 0; n < NTW; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co_base + m * 16 + 4 * kq + r;
-                if (co < Cout) slab[(size_t)co * wa.ncols + col] = acc[m][n][r];
-            }
-        }
+            for (int r = 0; r < 4; ++r) s_red[wave * RSZ + (m * 16 + 4 * kq + r) * RW + n * 16 + li] = acc[m][n][r];
+    __syncthreads();
+    float* slab = wa.slab + (size_t)blockIdx.x * Cout * wa.ncols;
+    for (int idx = tid; idx < RSZ; idx += 256) {
+        const int row = idx / RW, colq = idx - row * RW;
+        const int co = co_base + row, col = n_base + colq;
+        if (co < Cout && col < wa.ncols)
+            slab[(size_t)co * wa.ncols + col] = (s_red[idx] + s_red[RSZ + idx]) + (s_red[2 * RSZ + idx] + s_red[3 * RSZ + idx]);
+    }
 }
 
-// finish: dw[co][n] = sum_slabs, db[co] = column nW
-__global__ void wgrad_finish_kernel(const float* __restrict__ slab, int n_slabs, int Cout, int ncols, float* __restrict__ dw, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// finish: dw[co][n] = sum_slabs, db[co] = column nW.  32 consecutive elements x 8 slab lanes per block: coalesced 128-B rows,
+// 8-way parallel over slabs, fixed combination order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ slab, int n_slabs, int Cout, int ncols, float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float red[8][32];
+    const int e = threadIdx.x & 31, lane = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;
     const int count = Cout * ncols;
-    if (i >= count) return;
     float s = 0.f;
-    for (int k = 0; k < n_slabs; ++k) s += slab[(size_t)k * count + i];
-    const int co = i / ncols, n = i - co * ncols;
-    if (n < ncols - 1) dw[(size_t)co * (ncols - 1) + n] = s;
-    else if (db) db[co] = s;
+    if (i < count)
+        for (int k = lane; k < n_slabs; k += 8) s += slab[(size_t)k * count + i];
+    red[lane][e] = s;
+    __syncthreads();
+    if (lane == 0 && i < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][e];
+        const int co = i / ncols, n = i - co * ncols;
+        if (n < ncols - 1) dw[(size_t)co * (ncols - 1) + n] = t;
+        else if (db) db[co] = t;
+    }
 }
 
 struct Plan { int mtw, ntw, n_mgroups, n_ngroups, nsplit; };
@@ -181,7 +196,7 @@ Plan make_plan(int B, int Cin, int Cout, int H, int W, int k) {
     p.n_ngroups = cdiv(nt, p.ntw);
     const int total_tiles = B * cdiv(H, TH) * cdiv(W, TW);
     const int groups = p.n_mgroups * p.n_ngroups;
-    int target = 768 / groups;                   // ~3 blocks per CU in flight over all groups
+    int target = 512 / groups;                   // ~2 blocks per CU in flight over all groups
     if (target < 1) target = 1;
     p.nsplit = total_tiles < target ? total_tiles : target;
     return p;
@@ -190,7 +205,9 @@ Plan make_plan(int B, int Cin, int Cout, int H, int W, int k) {
 template <int KS, int IN, int GM, int MTW, int NTW>
 int launch_w(hipStream_t st, const WArgs& wa, const Plan& p) {
     using G = Geo<KS>;
-    constexpr size_t lds = ((size_t)MTW * 16 * CSG + (size_t)MAXPL * G::PLANE) * sizeof(float);
+    constexpr size_t lds_main = (size_t)MTW * 16 * CSG + (size_t)MAXPL * G::PLANE;
+    constexpr size_t lds_red = (size_t)4 * MTW * 16 * NTW * 16;
+    constexpr size_t lds = (lds_main > lds_red ? lds_main : lds_red) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<KS, IN, GM, MTW, NTW>),
@@ -233,7 +250,7 @@ int launch_modes(hipStream_t st, const WArgs& wa, const Plan& p) {
 extern "C" size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int k) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (k != 1 && k != 3)) return 0;
     const Plan p = make_plan(B, Cin, Cout, H, W, k);
-    return (size_t)p.nsplit * 4 * Cout * (Cin * k * k + 1) * sizeof(float);
+    return (size_t)p.nsplit * Cout * (Cin * k * k + 1) * sizeof(float);
 }
 
 extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
@@ -260,7 +277,7 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
     int rc = d.k == 1 ? launch_modes<1>(st, wa, p) : launch_modes<3>(st, wa, p);
     if (rc != BNERV_OK) return rc;
     const int count = d.Cout * wa.ncols;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(cdiv(count, 256)), dim3(256), 0, st, wa.slab, p.nsplit * 4, d.Cout, wa.ncols, d.dw, d.db);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(cdiv(count, 32)), dim3(256), 0, st, wa.slab, p.nsplit, d.Cout, wa.ncols, d.dw, d.db);
     BNERV_LAUNCH_CHECK("wgrad_finish");
     return BNERV_OK;
 }

@@ -448,8 +448,8 @@ def Dump2CSV(args, best_results_list, results_list, psnr_list, filename='results
 
 def _huffman_total_bits(counts):
     """sum_i count_i * code_length_i of a Huffman code built over the data symbols plus one EOF symbol of count 1 -- what
-    the reference obtains from dahuffman's HuffmanCodec.from_data + get_code_table (train_nerv_all.py:593-605).  Any optimal
-    Huffman code has the same total, so tie-breaking does not matter."""
+    the reference obtains from dahuffman's HuffmanCodec.from_data + get_code_table (train_nerv_all.py:593-605).  Every optimal
+    code has the same total over all leaves; which tie the EOF leaf wins can move the data-only total by a bit or two."""
     n = len(counts)
     heap = [(int(c), i, [i]) for i, c in enumerate(list(counts) + [1])]      # last leaf = EOF
     depth = [0] * (n + 1)
