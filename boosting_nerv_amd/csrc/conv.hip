@@ -6,14 +6,18 @@
 //     D[pixel][cout] = sum_{tap, cin} A[pixel][(tap,cin)] * Wt[(tap,cin)][cout]
 // M = pixels (16 consecutive x per MFMA tile), N = cout (16 per tile), K = taps*Cin walked 4 at a time.
 //
-// Block = 256 threads = 4 waves, one 8x32 spatial tile x NTB*16 output channels.
-//   LDS:  s_in  [16 ch][ROWS x RS halo tile], channel-planar, plane stride == 16 (mod 32) so the four k-lanes of one
-//               ds_read_b32 hit disjoint bank halves (conflict-free A-fragment reads)
-//         s_w   [tap][q][n][64]  B fragments in lane order (one conflict-free ds_read_b32 per fragment)
-//         s_out [cout][8x32 (+4)] accumulator tile, re-laid so the copy-out walks the FINAL layout row by row
-//               (coalesced stores and coalesced aux reads for every epilogue, pixel-shuffle included).
-// Each wave owns 2 rows x 32 px = 4 M-tiles; acc[4][NTB] (f32x4 each) lives in registers for the whole K loop.
-// HBM traffic is the algorithmic minimum + halo: input read once per cout-group, output written once.
+// PERSISTENT blocks (256 threads = 4 waves) walk work items (cout-group, sample, 8x32 spatial tile); each XCD owns a
+// contiguous range of items so neighbouring tiles (shared halo rows) meet in one L2.
+//   LDS  s_in  [16 ch][ROWS][RS]   channel-planar halo tile.  RS = 40 (3x3): columns cover x0-4 .. x0+35 so that every row is
+//                                  10 ALIGNED float4 segments (one global_load_dwordx4 + one ds_write_b128 each); plane stride
+//                                  400 == 16 (mod 32) -> the four k-lanes of an A-fragment ds_read_b32 hit disjoint bank halves.
+//        s_w   [tap][q][n][64]     B fragments in lane order; RESIDENT for the whole block when the layer's weights fit
+//                                  (every C<=16 layer, i.e. all the high-resolution stages), restaged per K-chunk otherwise.
+//        s_out [16 cout][8x32 +4]  one cout-tile of accumulators, re-laid so the copy-out walks the FINAL layout with float4
+//                                  stores / float4 aux reads (pixel-shuffle x2 included).
+// Software pipeline (single K-chunk layers): the global loads of tile t+1 are issued into registers BEFORE the MFMA phase
+// of tile t and written to LDS after it, so HBM/L2 latency hides under the matrix pipe.
+// Each wave owns 2 rows x 32 px = 4 M-tiles; acc[4][NTB] (f32x4) stays in registers for the whole K loop.
 #include "common.h"
 
 namespace {
@@ -21,110 +25,553 @@ namespace {
 constexpr int TH = 8, TW = 32;     // spatial tile
 constexpr int CC = 16;             // input channels per K chunk
 constexpr int NQ = CC / 4;
+constexpr int CS = TH * TW + 4;    // s_out channel stride (floats): 16-B aligned, spreads ds_write_b128 over all banks
+constexpr int W_RESIDENT_MAX = 12288;   // floats (48 KB) of B fragments kept resident per block
 
 template <int KS> struct Geo {
     static constexpr int PAD = (KS - 1) / 2;
     static constexpr int ROWS = TH + 2 * PAD;
-    static constexpr int RS = TW + 2 * PAD;
-    static constexpr int PLANE_RAW = ROWS * RS;
-    static constexpr int PLANE = ((PLANE_RAW - 16 + 31) / 32) * 32 + 16;   // >= PLANE_RAW and == 16 (mod 32)
+    static constexpr int XOFF = (KS == 3) ? 4 : 0;             // left margin, multiple of 4 -> aligned float4 segments
+    static constexpr int RS = TW + 2 * XOFF;                   // 40 / 32
+    static constexpr int SEGS = RS / 4;
+    static constexpr int PLANE_RAW = ROWS * RS;                // 400 / 256
+    static constexpr int PLANE = ((PLANE_RAW - 16 + 31) / 32) * 32 + 16;   // 400 / 272 : == 16 (mod 32)
     static constexpr int T = KS * KS;
+    static constexpr int COL0 = XOFF - PAD;                    // LDS column of input x = x0 + px + kx - PAD is px + kx + COL0
+    static constexpr int SLOTS = CC * ROWS * SEGS;             // float4 slots of a full chunk
+    static constexpr int NPRE = (SLOTS + 255) / 256;           // per-thread prefetch registers (float4)
 };
-constexpr int CS = TH * TW + 4;    // s_out channel stride (floats): 16-B aligned, spreads ds_write_b128 over all banks
 
 struct KArgs {
     bnerv_conv_desc d;
-    int tiles_x, tiles_y;
+    int tiles_x, tiles_y, ngroups, total_items;
+    int w_resident;       // 1: all B fragments of one cout-group stay in LDS
+    int nq_total;         // ceil(Cin/4) (resident stride)
+    int vec;              // 1: W % 4 == 0 and aligned pointers -> float4 staging and epilogue
+    int ksplit;           // >1: the K (input-channel chunk) range is split over `ksplit` work items; each writes a raw
+    int chunks_per_split; //     partial result to its slab in d.partial ([ksplit][B][Cout][H][W]), finished by reduce_slabs
 };
 
+struct Item { int g, b, ty0, tx0, tile, ks; };
+
+__device__ __forceinline__ Item decode_item(const KArgs& ka, int it) {
+    const int tiles = ka.tiles_x * ka.tiles_y;
+    Item r;
+    r.ks = 0;
+    if (ka.ksplit > 1) { r.ks = it % ka.ksplit; it /= ka.ksplit; }
+    r.tile = it % tiles;
+    const int rest = it / tiles;
+    r.b = rest % ka.d.B;
+    r.g = rest / ka.d.B;
+    r.ty0 = (r.tile / ka.tiles_x) * TH;
+    r.tx0 = (r.tile % ka.tiles_x) * TW;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- staging
 template <int IN>
-__device__ __forceinline__ float load_in(const bnerv_conv_desc& d, int b, int ci, int gy, int gx) {
+__device__ __forceinline__ float xform1(float v, float sc, float sh, float aux) {
+    if constexpr (IN == BNERV_IN_AFFINE) return v * sc + sh;
+    if constexpr (IN == BNERV_IN_GELU_AFFINE) return gelu_f(v) * sc + sh;
+    if constexpr (IN == BNERV_IN_TANHGRAD) { const float t = 2.0f * aux - 1.0f; return v * 0.5f * (1.0f - t * t); }
+    return v;
+}
+
+template <int IN>
+__device__ __forceinline__ float load_in_scalar(const bnerv_conv_desc& d, int b, int ci, int gy, int gx) {
     if constexpr (IN == BNERV_IN_UNSHUFFLE) {
         const int s = d.in_s, s2 = s * s;
         const int c = ci / s2, rem = ci - c * s2, i = rem / s, j = rem - i * s;
-        const size_t idx = (((size_t)b * (d.Cin / s2) + c) * (size_t)(d.H * s) + (size_t)(gy * s + i)) * (size_t)(d.W * s) + (size_t)(gx * s + j);
-        return d.x[idx];
+        return d.x[(((size_t)b * (d.Cin / s2) + c) * (size_t)(d.H * s) + (size_t)(gy * s + i)) * (size_t)(d.W * s) + (size_t)(gx * s + j)];
     } else {
         const size_t idx = (((size_t)b * d.Cin + ci) * d.H + gy) * (size_t)d.W + gx;
-        const float v = d.x[idx];
-        if constexpr (IN == BNERV_IN_PLAIN) return v;
-        if constexpr (IN == BNERV_IN_AFFINE) return v * (1.0f + d.scale[b * d.Cin + ci]) + d.shift[b * d.Cin + ci];
-        if constexpr (IN == BNERV_IN_GELU_AFFINE) return gelu_f(v) * (1.0f + d.scale[b * d.Cin + ci]) + d.shift[b * d.Cin + ci];
-        if constexpr (IN == BNERV_IN_TANHGRAD) {
-            const float t = 2.0f * d.aux0[idx] - 1.0f;
-            return v * 0.5f * (1.0f - t * t);
-        }
-        return v;
+        float sc = 1.f, sh = 0.f, aux = 0.f;
+        if constexpr (IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE) { sc = 1.0f + d.scale[b * d.Cin + ci]; sh = d.shift[b * d.Cin + ci]; }
+        if constexpr (IN == BNERV_IN_TANHGRAD) aux = d.aux0[idx];
+        return xform1<IN>(d.x[idx], sc, sh, aux);
     }
 }
 
+// generic (any W, any shuffle factor): one float per step, zero outside the image / beyond Cin
+template <int KS, int IN>
+__device__ __forceinline__ void stage_scalar(const bnerv_conv_desc& d, float* s_in, int b, int c0, int nch, int ty0, int tx0) {
+    using G = Geo<KS>;
+    for (int idx = threadIdx.x; idx < nch * G::PLANE_RAW; idx += 256) {
+        const int c = idx / G::PLANE_RAW;
+        const int rem = idx - c * G::PLANE_RAW;
+        const int r = rem / G::RS, col = rem - r * G::RS;
+        const int gy = ty0 + r - G::PAD, gx = tx0 + col - G::XOFF, ci = c0 + c;
+        float v = 0.f;
+        if (ci < d.Cin && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W) v = load_in_scalar<IN>(d, b, ci, gy, gx);
+        s_in[c * G::PLANE + r * G::RS + col] = v;
+    }
+}
+
+// vector staging, split in two so the loads of the NEXT tile can fly under the MFMA phase of the current one.
+// PLAIN/AFFINE/GELU_AFFINE/TANHGRAD: slot = (channel, row, 4-px segment): one float4 (two for TANHGRAD).
+// UNSHUFFLE with in_s == 2: slot = (channel PAIR (c,i,j=0/1), row, segment): two float4 of the shuffled source row.
+template <int KS, int IN>
+struct VecStage {
+    using G = Geo<KS>;
+    static constexpr bool PAIR = (IN == BNERV_IN_UNSHUFFLE);
+    static constexpr bool TWO = PAIR || (IN == BNERV_IN_TANHGRAD);
+    static constexpr int NPRE = PAIR ? (G::SLOTS / 2 + 255) / 256 : G::NPRE;
+    f32x4 ra[NPRE], rb[TWO ? NPRE : 1];
+
+    __device__ __forceinline__ int nslots(int nch) const { return (PAIR ? nch / 2 : nch) * G::ROWS * G::SEGS; }
+
+    __device__ __forceinline__ void issue(const bnerv_conv_desc& d, int b, int c0, int nch, int ty0, int tx0) {
+        const int ns = nslots(nch);
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int sidx = threadIdx.x + k * 256;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (sidx < ns) {
+                const int c = sidx / (G::ROWS * G::SEGS);
+                const int rem = sidx - c * (G::ROWS * G::SEGS);
+                const int r = rem / G::SEGS, sg = rem - r * G::SEGS;
+                const int gy = ty0 + r - G::PAD, gx = tx0 - G::XOFF + 4 * sg;
+                if (gy >= 0 && gy < d.H && gx >= 0 && gx < d.W) {
+                    if constexpr (PAIR) {
+                        const int ci = c0 + 2 * c;                 // conv-space channel of the j = 0 plane
+                        if (ci < d.Cin) {
+                            const int cf = ci >> 2, i = (ci >> 1) & 1;
+                            const float* src = d.x + (((size_t)b * (d.Cin >> 2) + cf) * (size_t)(2 * d.H) + (size_t)(2 * gy + i)) * (size_t)(2 * d.W) + (size_t)(2 * gx);
+                            va = *reinterpret_cast<const f32x4*>(src);
+                            vb = *reinterpret_cast<const f32x4*>(src + 4);
+                        }
+                    } else {
+                        const int ci = c0 + c;
+                        if (ci < d.Cin) {
+                            const size_t idx = (((size_t)b * d.Cin + ci) * d.H + gy) * (size_t)d.W + gx;
+                            va = *reinterpret_cast<const f32x4*>(d.x + idx);
+                            if constexpr (IN == BNERV_IN_TANHGRAD) vb = *reinterpret_cast<const f32x4*>(d.aux0 + idx);
+                        }
+                    }
+                }
+            }
+            ra[k] = va;
+            if constexpr (TWO) rb[k] = vb;
+        }
+    }
+
+    __device__ __forceinline__ void commit(const bnerv_conv_desc& d, float* s_in, int b, int c0, int nch, int ty0, int tx0) {
+        const int ns = nslots(nch);
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int sidx = threadIdx.x + k * 256;
+            if (sidx < ns) {
+                const int c = sidx / (G::ROWS * G::SEGS);
+                const int rem = sidx - c * (G::ROWS * G::SEGS);
+                const int r = rem / G::SEGS, sg = rem - r * G::SEGS;
+                if constexpr (PAIR) {
+                    const f32x4 a = ra[k], bq = rb[k];
+                    float* dst = s_in + (2 * c) * G::PLANE + r * G::RS + 4 * sg;
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{a[0], a[2], bq[0], bq[2]};
+                    *reinterpret_cast<f32x4*>(dst + G::PLANE) = f32x4{a[1], a[3], bq[1], bq[3]};
+                } else {
+                    f32x4 v = ra[k];
+                    if constexpr (IN != BNERV_IN_PLAIN) {
+                        const int gy = ty0 + r - G::PAD, gx = tx0 - G::XOFF + 4 * sg, ci = c0 + c;
+                        const bool inside = ci < d.Cin && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;     // padding is applied AFTER the prologue
+                        if (inside) {
+                            float sc = 1.f, sh = 0.f;
+                            if constexpr (IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE) { sc = 1.0f + d.scale[b * d.Cin + ci]; sh = d.shift[b * d.Cin + ci]; }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = xform1<IN>(v[e], sc, sh, TWO ? rb[k][e] : 0.f);
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(s_in + c * G::PLANE + r * G::RS + 4 * sg) = v;
+                }
+            }
+        }
+    }
+};
+
+// B fragments: lane (j = l&15, kq = l>>4) <- W(co_base+16n+j, 4*(q0+q)+kq, tap)
+template <int KS, int NTB>
+__device__ __forceinline__ void stage_weights(const bnerv_conv_desc& d, float* s_w, int co_base, int q0, int nq, int qstride) {
+    using G = Geo<KS>;
+    for (int idx = threadIdx.x; idx < G::T * nq * NTB * 64; idx += 256) {
+        const int l = idx & 63;
+        int rest = idx >> 6;
+        const int n = rest % NTB; rest /= NTB;
+        const int q = rest % nq;
+        const int tap = rest / nq;
+        const int co = co_base + n * 16 + (l & 15), ci = (q0 + q) * 4 + (l >> 4);
+        float v = 0.f;
+        if (co < d.Cout && ci < d.Cin) {
+            v = d.transposed ? d.w[((size_t)ci * d.wCi + co) * G::T + (G::T - 1 - tap)]
+                             : d.w[((size_t)co * d.wCi + ci) * G::T + tap];
+        }
+        s_w[((tap * qstride + q) * NTB + n) * 64 + l] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- epilogue
+template <int EP>
+__device__ __forceinline__ float ep_value(const bnerv_conv_desc& d, float v, float bias, size_t o, float* out2v) {
+    if constexpr (EP == BNERV_EP_BIAS) return v + bias;
+    if constexpr (EP == BNERV_EP_BIAS_SIN) { float sv, cv; sincosf(v + bias, &sv, &cv); *out2v = cv; return sv; }
+    if constexpr (EP == BNERV_EP_BIAS_RES) return v + bias + d.aux0[o];
+    if constexpr (EP == BNERV_EP_BIAS_TANH) return tanhf(v + bias) * 0.5f + 0.5f;
+    return v;
+}
+
+// copy one cout-tile (16 conv-space channels starting at co0) from s_out to global, final layout.
+template <int EP>
+__device__ __forceinline__ void copy_out_tile(const KArgs& ka, const float* s_out, const Item& it, int co0) {
+    const bnerv_conv_desc& d = ka.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = d.H, W = d.W, Cout = d.Cout, b = it.b, ty0 = it.ty0, tx0 = it.tx0;
+    const int s = d.out_s;
+    float* outp = d.out;                                  // split-K partial results go to this item's slab instead
+    if constexpr (EP == BNERV_EP_PLAIN) { if (ka.ksplit > 1) outp = d.partial + (size_t)it.ks * d.B * Cout * H * W; }
+    if constexpr (EP == BNERV_EP_DGELU || EP == BNERV_EP_DSIN) {
+        // stride-1 only.  Pass k: wave w handles channel cl = 4k + w: 64 lanes = 8 rows x 8 float4 (vec) or 4 x 64 px (scalar);
+        // per-channel (ds, dt) partial sums need only a wave reduction.
+        for (int k = 0; k < 4; ++k) {
+            const int cl = k * 4 + wave, co = co0 + cl;
+            if (co >= Cout) continue;                       // wave-uniform
+            const float sc = 1.0f + d.scale[b * Cout + co];
+            float ps = 0.f, pt = 0.f;
+            if (ka.vec) {
+                const int py = lane >> 3, px = (lane & 7) * 4;
+                const int gy = ty0 + py, gx = tx0 + px;
+                if (gy < H && gx < W) {
+                    const size_t o = (((size_t)b * Cout + co) * H + gy) * (size_t)W + gx;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(s_out + cl * CS + py * TW + px);
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(d.aux0 + o);
+                    f32x4 r;
+                    if constexpr (EP == BNERV_EP_DGELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { r[e] = v[e] * sc * gelu_grad_f(a0[e]); ps = fmaf(v[e], gelu_f(a0[e]), ps); pt += v[e]; }
+                    } else {
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(d.aux1 + o);
+                        f32x4 a2 = {1.f, 1.f, 1.f, 1.f};
+                        if (d.aux2) a2 = *reinterpret_cast<const f32x4*>(d.aux2 + o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { r[e] = (a1[e] + v[e] * sc) * a2[e]; ps = fmaf(v[e], a0[e], ps); pt += v[e]; }
+                    }
+                    *reinterpret_cast<f32x4*>(d.out + o) = r;
+                }
+            } else {
+                for (int p = lane; p < TH * TW; p += 64) {
+                    const int py = p >> 5, px = p & 31, gy = ty0 + py, gx = tx0 + px;
+                    if (gy >= H || gx >= W) continue;
+                    const size_t o = (((size_t)b * Cout + co) * H + gy) * (size_t)W + gx;
+                    const float v = s_out[cl * CS + p];
+                    if constexpr (EP == BNERV_EP_DGELU) {
+                        const float pre = d.aux0[o];
+                        d.out[o] = v * sc * gelu_grad_f(pre);
+                        ps = fmaf(v, gelu_f(pre), ps);
+                    } else {
+                        d.out[o] = (d.aux1[o] + v * sc) * (d.aux2 ? d.aux2[o] : 1.0f);
+                        ps = fmaf(v, d.aux0[o], ps);
+                    }
+                    pt += v;
+                }
+            }
+            ps = wave_sum(ps);
+            pt = wave_sum(pt);
+            if (lane == 0) {
+                const size_t row = (size_t)it.tile * d.B + b;              // [tiles][B][2][Cout]
+                d.partial[(row * 2 + 0) * Cout + co] = ps;
+                d.partial[(row * 2 + 1) * Cout + co] = pt;
+            }
+        }
+    } else if (s == 1 && ka.vec) {
+        for (int idx = tid; idx < 16 * TH * (TW / 4); idx += 256) {
+            const int cl = idx >> 6, rem = idx & 63, py = rem >> 3, px = (rem & 7) * 4;
+            const int co = co0 + cl, gy = ty0 + py, gx = tx0 + px;
+            if (co >= Cout || gy >= H || gx >= W) continue;
+            const size_t o = (((size_t)b * Cout + co) * H + gy) * (size_t)W + gx;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(s_out + cl * CS + py * TW + px);
+            const float bias = (EP != BNERV_EP_PLAIN && d.bias) ? d.bias[co] : 0.f;
+            f32x4 r, r2;
+            if constexpr (EP == BNERV_EP_BIAS_RES) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(d.aux0 + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = v[e] + bias + a0[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float c2 = 0.f; r[e] = ep_value<EP>(d, v[e], bias, o + e, &c2); r2[e] = c2; }
+            }
+            *reinterpret_cast<f32x4*>(outp + o) = r;
+            if constexpr (EP == BNERV_EP_BIAS_SIN) { if (d.out2) *reinterpret_cast<f32x4*>(d.out2 + o) = r2; }
+        }
+    } else if (s == 2 && ka.vec) {
+        // PixelShuffle(2): final channel cf = co/4; output float4 = (px, j=0), (px, j=1), (px+1, j=0), (px+1, j=1) of row 2*py+i
+        const int Cf = Cout >> 2, HF = 2 * H, WF = 2 * W;
+        for (int idx = tid; idx < 4 * (2 * TH) * (TW / 2); idx += 256) {          // 4 final channels x 16 rows x 16 float4
+            const int cfl = idx >> 8, rem = idx & 255, orow = rem >> 4, q4 = rem & 15;
+            const int py = orow >> 1, i = orow & 1, px = q4 * 2;
+            const int cl0 = cfl * 4 + i * 2;
+            const int cf = (co0 >> 2) + cfl;
+            const int gy = 2 * ty0 + orow, gx = 2 * tx0 + 4 * q4;
+            if (cf >= Cf || gy >= HF || gx >= WF) continue;
+            const float* p0 = s_out + cl0 * CS + py * TW + px;
+            const float v00 = p0[0], v10 = p0[1], v01 = p0[CS], v11 = p0[CS + 1];
+            const float b0 = (EP != BNERV_EP_PLAIN && d.bias) ? d.bias[co0 + cl0] : 0.f;
+            const float b1 = (EP != BNERV_EP_PLAIN && d.bias) ? d.bias[co0 + cl0 + 1] : 0.f;
+            const size_t o = (((size_t)b * Cf + cf) * HF + gy) * (size_t)WF + gx;
+            f32x4 r, r2;
+            const float in4[4] = {v00, v01, v10, v11};
+            const float bs4[4] = {b0, b1, b0, b1};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float c2 = 0.f; r[e] = ep_value<EP>(d, in4[e], bs4[e], o + e, &c2); r2[e] = c2; }
+            *reinterpret_cast<f32x4*>(d.out + o) = r;
+            if constexpr (EP == BNERV_EP_BIAS_SIN) { if (d.out2) *reinterpret_cast<f32x4*>(d.out2 + o) = r2; }
+        }
+    } else {
+        // generic pixel-shuffle scatter (s = 3, 5, or unaligned widths): low-resolution stages only
+        const int s2 = s * s, Cf = Cout / s2, HF = H * s, WF = W * s;
+        for (int e = tid; e < 16 * TH * TW; e += 256) {
+            const int cl = e >> 8, p = e & 255, py = p >> 5, px = p & 31;
+            const int co = co0 + cl;
+            if (co >= Cout || ty0 + py >= H || tx0 + px >= W) continue;
+            const int c = co / s2, rem = co - c * s2, i = rem / s, j = rem - i * s;
+            const size_t o = (((size_t)b * Cf + c) * HF + (size_t)((ty0 + py) * s + i)) * (size_t)WF + (size_t)((tx0 + px) * s + j);
+            const float bias = (EP != BNERV_EP_PLAIN && d.bias) ? d.bias[co] : 0.f;
+            float c2 = 0.f;
+            outp[o] = ep_value<EP>(d, s_out[cl * CS + py * TW + px], bias, o, &c2);
+            if constexpr (EP == BNERV_EP_BIAS_SIN) { if (d.out2) d.out2[o] = c2; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- kernel
 template <int KS, int IN, int EP, int NTB>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const KArgs ka) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const KArgs ka) {
     using G = Geo<KS>;
     const bnerv_conv_desc& d = ka.d;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_in = smem;
-    float* s_w = smem + CC * G::PLANE;
-    float* s_out = smem;
+    float* s_in = smem;                                   // CC * PLANE
+    float* s_out = smem + CC * G::PLANE;                  // 16 * CS
+    float* s_w = s_out + 16 * CS;                         // resident: T*nq_total*NTB*64 ; else T*NQ*NTB*64
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int ty0 = (tile / ka.tiles_x) * TH, tx0 = (tile % ka.tiles_x) * TW;
-    const int ng = blockIdx.y, b = blockIdx.z;
-    const int H = d.H, W = d.W, Cin = d.Cin, Cout = d.Cout;
-    const int co_base = ng * NTB * 16;
+    const int Cin = d.Cin;
 
-    f32x4 acc[4][NTB];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < NTB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this block's item range: XCD x owns a contiguous slice of the item list; its blocks take it round-robin
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const int nlb = (gridDim.x - xcd + 7) >> 3;
+    const int per = ka.total_items >> 3, extra = ka.total_items & 7;
+    const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
 
     int abase[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) abase[m] = kq * G::PLANE + (2 * wave + (m >> 1)) * G::RS + (m & 1) * 16 + li;
+    for (int m = 0; m < 4; ++m) abase[m] = kq * G::PLANE + (2 * wave + (m >> 1)) * G::RS + (m & 1) * 16 + li + G::COL0;
 
-    for (int c0 = 0; c0 < Cin; c0 += CC) {
-        const int cc = min(CC, Cin - c0);
-        const int nq = (cc + 3) >> 2;
-        __syncthreads();
-        // ---- stage the input halo tile (prologue applied; zero outside the image = padding AFTER the prologue) ----
-        for (int idx = tid; idx < nq * 4 * G::PLANE_RAW; idx += 256) {
-            const int c = idx / G::PLANE_RAW;
-            const int rem = idx - c * G::PLANE_RAW;
-            const int r = rem / G::RS, col = rem - r * G::RS;
-            const int gy = ty0 + r - G::PAD, gx = tx0 + col - G::PAD, ci = c0 + c;
-            float v = 0.f;
-            if (ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = load_in<IN>(d, b, ci, gy, gx);
-            s_in[c * G::PLANE + r * G::RS + col] = v;
+    const int qstride = ka.w_resident ? ka.nq_total : NQ;
+    const bool vec_in = ka.vec && (IN != BNERV_IN_UNSHUFFLE || d.in_s == 2);
+    const bool piped = vec_in && Cin <= CC;               // one K chunk: software-pipelined path
+    const int nch1 = ((min(Cin, CC) + 3) >> 2) * 4;       // staged channels of the single chunk
+    VecStage<KS, IN> vs;
+    int cur_g = -1;
+
+    int itx = r0 + lb;
+    if (itx < r1 && piped) {
+        const Item it = decode_item(ka, itx);
+        vs.issue(d, it.b, 0, nch1, it.ty0, it.tx0);
+        vs.commit(d, s_in, it.b, 0, nch1, it.ty0, it.tx0);
+    }
+    for (; itx < r1; itx += nlb) {
+        const Item it = decode_item(ka, itx);
+        const int co_base = it.g * NTB * 16;
+        f32x4 acc[4][NTB];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < NTB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (ka.w_resident && cur_g != it.g) {
+            __syncthreads();                               // nobody still reads the previous group's fragments
+            stage_weights<KS, NTB>(d, s_w, co_base, 0, ka.nq_total, qstride);
+            cur_g = it.g;
         }
-        // ---- stage this chunk's weights as B fragments: lane (j = l&15, kq = l>>4) <- W(co_base+16n+j, c0+4q+kq, tap) ----
-        for (int idx = tid; idx < G::T * nq * NTB * 64; idx += 256) {
-            const int l = idx & 63;
-            int rest = idx >> 6;
-            const int n = rest % NTB; rest /= NTB;
-            const int q = rest % nq;
-            const int tap = rest / nq;
-            const int co = co_base + n * 16 + (l & 15), ci = c0 + q * 4 + (l >> 4);
-            float v = 0.f;
-            if (co < Cout && ci < Cin) {
-                v = d.transposed ? d.w[((size_t)ci * d.wCi + co) * G::T + (G::T - 1 - tap)]
-                                 : d.w[((size_t)co * d.wCi + ci) * G::T + tap];
+        const bool has_next = itx + nlb < r1;
+        Item nxt = it;
+        if (has_next) nxt = decode_item(ka, itx + nlb);
+
+        const int c_begin = ka.ksplit > 1 ? it.ks * ka.chunks_per_split * CC : 0;
+        const int c_end = ka.ksplit > 1 ? min(Cin, c_begin + ka.chunks_per_split * CC) : Cin;
+        for (int c0 = c_begin; c0 < c_end; c0 += CC) {
+            const int cc = min(CC, Cin - c0);
+            const int nq = (cc + 3) >> 2;
+            const int q0 = c0 >> 2;
+            if (!piped) {
+                __syncthreads();                           // previous chunk / tile fully consumed
+                if (vec_in) { vs.issue(d, it.b, c0, nq * 4, it.ty0, it.tx0); vs.commit(d, s_in, it.b, c0, nq * 4, it.ty0, it.tx0); }
+                else stage_scalar<KS, IN>(d, s_in, it.b, c0, nq * 4, it.ty0, it.tx0);
             }
-            s_w[((tap * NQ + q) * NTB + n) * 64 + l] = v;
+            if (!ka.w_resident) stage_weights<KS, NTB>(d, s_w, co_base, q0, nq, qstride);
+            __syncthreads();
+            if (piped && has_next) vs.issue(d, nxt.b, 0, nch1, nxt.ty0, nxt.tx0);      // flies under the MFMA phase
+            const int qb = ka.w_resident ? q0 : 0;
+#pragma unroll
+            for (int tap = 0; tap < G::T; ++tap) {
+                const int toff = (tap / KS) * G::RS + (tap % KS);
+                for (int q = 0; q < nq; ++q) {
+                    float bf[NTB], af[4];
+#pragma unroll
+                    for (int n = 0; n < NTB; ++n) bf[n] = s_w[((tap * qstride + qb + q) * NTB + n) * 64 + lane];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) af[m] = s_in[abase[m] + q * 4 * G::PLANE + toff];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < NTB; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[n], acc[m][n], 0, 0, 0);
+                }
+            }
         }
-        __syncthreads();
-        // ---- MFMA main loop ----
+
+        // ---- epilogue, one cout-tile at a time through s_out (D layout: lane holds pixels 4*kq..4*kq+3 of cout li) ----
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) {
+            if (co_base + n * 16 < d.Cout) {
+                if (n > 0) __syncthreads();                // previous cout-tile copied out
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int py = 2 * wave + (m >> 1), px = (m & 1) * 16 + 4 * kq;
+                    *reinterpret_cast<f32x4*>(&s_out[li * CS + py * TW + px]) = acc[m][n];
+                }
+                __syncthreads();                           // s_out complete; every wave is also done reading s_in / s_w(chunk)
+                if (n == 0 && piped && has_next) vs.commit(d, s_in, nxt.b, 0, nch1, nxt.ty0, nxt.tx0);
+                copy_out_tile<EP>(ka, s_out, it, co_base + n * 16);
+            }
+        }
+        __syncthreads();                                   // s_out free for the next item; s_in(next) visible
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- fast kernel
+// Single-K-chunk layers (Cin <= 16: every high-resolution stage of the NeRV-style decoders), float4-aligned rows.
+// Compared with the generic kernel above:
+//   * the K loop is FULLY unrolled (NQ1 = ceil(Cin/4) is a template constant): every ds_read carries an immediate offset,
+//     the loop body is ds_read_b32 x5 + MFMA x4 with no VALU at all;
+//   * the (channel,row,segment) geometry of each thread's staging slots is tile-invariant and computed ONCE per block
+//     (LDS offset, global offset relative to the tile origin); interior tiles skip every bounds check;
+//   * LDS is carved to the layer's real channel counts, so a 12->12 layer needs 38.6 KB -> 4 blocks per CU.
+template <int KS, int IN, int EP, int NTB, int NQ1>
+__global__ __launch_bounds__(256, (NTB == 1 ? (NQ1 <= 3 ? 4 : 3) : 2)) void conv_fast_kernel(const KArgs ka, const int ncs /* s_out channels */) {
+    using G = Geo<KS>;
+    constexpr int NCH = NQ1 * 4;
+    constexpr int NSLOT = NCH * G::ROWS * G::SEGS;
+    constexpr int NPRE = (NSLOT + 255) / 256;
+    constexpr bool TWO = (IN == BNERV_IN_TANHGRAD);
+    const bnerv_conv_desc& d = ka.d;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;                                   // NCH * PLANE
+    float* s_out = smem + NCH * G::PLANE;                 // ncs * CS
+    float* s_w = s_out + ncs * CS;                        // T * NQ1 * NTB * 64
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int Cin = d.Cin, H = d.H, W = d.W;
+
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const int nlb = (gridDim.x - xcd + 7) >> 3;
+    const int per = ka.total_items >> 3, extra = ka.total_items & 7;
+    const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
+
+    // tile-invariant slot geometry
+    int lds_off[NPRE], goff[NPRE], rsc[NPRE];            // rsc: row | seg << 8 | channel << 16 | valid << 31... (valid kept in sign)
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        const int sidx = tid + k * 256;
+        const int c = sidx / (G::ROWS * G::SEGS);
+        const int rem = sidx - c * (G::ROWS * G::SEGS);
+        const int r = rem / G::SEGS, sg = rem - r * G::SEGS;
+        const bool ok = sidx < NSLOT;
+        lds_off[k] = ok ? c * G::PLANE + r * G::RS + 4 * sg : -1;
+        goff[k] = (c * H + (r - G::PAD)) * W + 4 * sg - G::XOFF;
+        rsc[k] = r | (sg << 8) | (c << 16);
+    }
+    int abase[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) abase[m] = kq * G::PLANE + (2 * wave + (m >> 1)) * G::RS + (m & 1) * 16 + li + G::COL0;
+
+    f32x4 ra[NPRE], rb[TWO ? NPRE : 1];
+    auto issue = [&](const Item& it) {
+        const size_t tbase = ((size_t)it.b * Cin * H + it.ty0) * (size_t)W + it.tx0;
+        const bool interior = it.ty0 >= G::PAD && it.ty0 + TH + G::PAD <= H && it.tx0 >= G::XOFF && it.tx0 + TW + G::XOFF <= W;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            bool ok = lds_off[k] >= 0 && (rsc[k] >> 16) < Cin;
+            if (!interior) {
+                const int gy = it.ty0 + (rsc[k] & 255) - G::PAD, gx = it.tx0 - G::XOFF + 4 * ((rsc[k] >> 8) & 255);
+                ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            }
+            if (ok) {
+                va = *reinterpret_cast<const f32x4*>(d.x + tbase + goff[k]);
+                if constexpr (TWO) vb = *reinterpret_cast<const f32x4*>(d.aux0 + tbase + goff[k]);
+            }
+            ra[k] = va;
+            if constexpr (TWO) rb[k] = vb;
+        }
+    };
+    auto commit = [&](const Item& it) {
+        const bool interior = it.ty0 >= G::PAD && it.ty0 + TH + G::PAD <= H && it.tx0 >= G::XOFF && it.tx0 + TW + G::XOFF <= W;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            if (lds_off[k] < 0) continue;
+            f32x4 v = ra[k];
+            if constexpr (IN != BNERV_IN_PLAIN) {
+                const int ci = rsc[k] >> 16;
+                bool ok = ci < Cin;
+                if (!interior) {
+                    const int gy = it.ty0 + (rsc[k] & 255) - G::PAD, gx = it.tx0 - G::XOFF + 4 * ((rsc[k] >> 8) & 255);
+                    ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                }
+                if (ok) {                                  // padding is applied AFTER the prologue: outside stays 0
+                    float sc = 1.f, sh = 0.f;
+                    if constexpr (IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE) { sc = 1.0f + d.scale[it.b * Cin + ci]; sh = d.shift[it.b * Cin + ci]; }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = xform1<IN>(v[e], sc, sh, TWO ? rb[k][e] : 0.f);
+                }
+            }
+            *reinterpret_cast<f32x4*>(s_in + lds_off[k]) = v;
+        }
+    };
+
+    int cur_g = -1;
+    int itx = r0 + lb;
+    if (itx < r1) {
+        const Item it = decode_item(ka, itx);
+        issue(it);
+        commit(it);
+    }
+    for (; itx < r1; itx += nlb) {
+        const Item it = decode_item(ka, itx);
+        const int co_base = it.g * NTB * 16;
+        f32x4 acc[4][NTB];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < NTB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (cur_g != it.g) {
+            __syncthreads();
+            stage_weights<KS, NTB>(d, s_w, co_base, 0, NQ1, NQ1);
+            cur_g = it.g;
+        }
+        const bool has_next = itx + nlb < r1;
+        Item nxt = it;
+        if (has_next) nxt = decode_item(ka, itx + nlb);
+        __syncthreads();                                   // s_in(it) committed by every thread, weights staged
+        if (has_next) issue(nxt);                          // flies under the MFMA phase
 #pragma unroll
         for (int tap = 0; tap < G::T; ++tap) {
-            const int toff = (tap / KS) * G::RS + (tap % KS);
-            for (int q = 0; q < nq; ++q) {
+#pragma unroll
+            for (int q = 0; q < NQ1; ++q) {
                 float bf[NTB], af[4];
 #pragma unroll
-                for (int n = 0; n < NTB; ++n) bf[n] = s_w[((tap * NQ + q) * NTB + n) * 64 + lane];
+                for (int n = 0; n < NTB; ++n) bf[n] = s_w[((tap * NQ1 + q) * NTB + n) * 64 + lane];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) af[m] = s_in[abase[m] + q * 4 * G::PLANE + toff];
+                for (int m = 0; m < 4; ++m) af[m] = s_in[abase[m] + (q * 4 * G::PLANE + (tap / KS) * G::RS + (tap % KS))];
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -132,143 +579,97 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const KArgs ka) {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[n], acc[m][n], 0, 0, 0);
             }
         }
-    }
-
-    // ---- accumulators -> s_out[cout_local][py*32 + px]   (D layout: lane holds pixels 4*kq..4*kq+3 of cout li) ----
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < NTB; ++n) {
-            const int py = 2 * wave + (m >> 1), px = (m & 1) * 16 + 4 * kq;
-            *reinterpret_cast<f32x4*>(&s_out[(n * 16 + li) * CS + py * TW + px]) = acc[m][n];
-        }
-    __syncthreads();
-
-    // ---- copy-out in the final layout ----
-    const int s = d.out_s, s2 = s * s;
-    if constexpr (EP == BNERV_EP_DGELU || EP == BNERV_EP_DSIN) {
-        // stride-1 convs only: one pixel per thread per channel, plus per-channel (ds, dt) partial sums for this tile
-        float* s_red = smem + NTB * 16 * CS;      // [4 waves][NTB*16][2]
-        const int py = tid >> 5, px = tid & 31;
-        const int gy = ty0 + py, gx = tx0 + px;
-        const bool inside = gy < H && gx < W;
-        for (int cl = 0; cl < NTB * 16; ++cl) {
-            const int co = co_base + cl;
-            if (co >= Cout) break;
-            float ps = 0.f, pt = 0.f;
-            if (inside) {
-                const size_t o = (((size_t)b * Cout + co) * H + gy) * (size_t)W + gx;
-                const float v = s_out[cl * CS + py * TW + px];
-                const float sc = 1.0f + d.scale[b * Cout + co];
-                if constexpr (EP == BNERV_EP_DGELU) {
-                    const float pre = d.aux0[o];
-                    d.out[o] = v * sc * gelu_grad_f(pre);
-                    ps = v * gelu_f(pre);
-                } else {
-                    const float y0 = d.aux0[o];
-                    d.out[o] = (d.aux1[o] + v * sc) * (d.aux2 ? d.aux2[o] : 1.0f);
-                    ps = v * y0;
+            if (co_base + n * 16 < d.Cout) {
+                if (n > 0) __syncthreads();
+                if (li < ncs) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int py = 2 * wave + (m >> 1), px = (m & 1) * 16 + 4 * kq;
+                        *reinterpret_cast<f32x4*>(&s_out[li * CS + py * TW + px]) = acc[m][n];
+                    }
                 }
-                pt = v;
-            }
-            ps = wave_sum(ps);
-            pt = wave_sum(pt);
-            if (lane == 0) {
-                s_red[(wave * NTB * 16 + cl) * 2 + 0] = ps;
-                s_red[(wave * NTB * 16 + cl) * 2 + 1] = pt;
+                __syncthreads();                           // s_out complete; every wave is done reading s_in
+                if (n == 0 && has_next) commit(nxt);
+                copy_out_tile<EP>(ka, s_out, it, co_base + n * 16);
             }
         }
         __syncthreads();
-        const int ncl = min(NTB * 16, Cout - co_base);
-        for (int idx = tid; idx < ncl * 2; idx += 256) {
-            const int cl = idx >> 1, which = idx & 1;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) v += s_red[(w * NTB * 16 + cl) * 2 + which];
-            const size_t row = (size_t)tile * gridDim.z + b;      // [tiles][B][2][Cout]: one reduce_slabs over tiles
-            d.partial[(row * 2 + which) * Cout + co_base + cl] = v;
-        }
-    } else if (s <= 2 && (NTB * 16) % s2 == 0) {
-        // fast path: walk final rows; consecutive threads -> consecutive output columns
-        const int sh = s - 1;                     // s in {1,2}
-        const int OW = TW << sh, OH = TH << sh;
-        const int ncf = (NTB * 16) >> (2 * sh);
-        const int Cf = Cout >> (2 * sh);
-        const int HF = H << sh, WF = W << sh;
-        for (int cfl = 0; cfl < ncf; ++cfl) {
-            const int cf = (co_base >> (2 * sh)) + cfl;
-            if (cf >= Cf) break;
-            for (int e = tid; e < OH * OW; e += 256) {
-                const int orow = e / OW, ocol = e - orow * OW;
-                const int py = orow >> sh, i = orow & sh, px = ocol >> sh, j = ocol & sh;
-                const int gy = (ty0 << sh) + orow, gx = (tx0 << sh) + ocol;
-                if (gy >= HF || gx >= WF) continue;
-                const int cl = (cfl << (2 * sh)) + i * s + j;
-                float v = s_out[cl * CS + py * TW + px];
-                const size_t o = (((size_t)b * Cf + cf) * HF + gy) * (size_t)WF + gx;
-                if constexpr (EP != BNERV_EP_PLAIN) { if (d.bias) v += d.bias[co_base + cl]; }
-                if constexpr (EP == BNERV_EP_BIAS || EP == BNERV_EP_PLAIN) d.out[o] = v;
-                if constexpr (EP == BNERV_EP_BIAS_SIN) { float sv, cv; sincosf(v, &sv, &cv); d.out[o] = sv; if (d.out2) d.out2[o] = cv; }
-                if constexpr (EP == BNERV_EP_BIAS_RES) d.out[o] = v + d.aux0[o];
-                if constexpr (EP == BNERV_EP_BIAS_TANH) d.out[o] = tanhf(v) * 0.5f + 0.5f;
-            }
-        }
-    } else {
-        // generic pixel-shuffle scatter (s = 3, 5: low-resolution stages only)
-        const int Cf = Cout / s2, HF = H * s, WF = W * s;
-        for (int e = tid; e < NTB * 16 * TH * TW; e += 256) {
-            const int cl = e >> 8, p = e & 255, py = p >> 5, px = p & 31;
-            const int co = co_base + cl;
-            if (co >= Cout) break;
-            if (ty0 + py >= H || tx0 + px >= W) continue;
-            const int c = co / s2, rem = co - c * s2, i = rem / s, j = rem - i * s;
-            const size_t o = (((size_t)b * Cf + c) * HF + (size_t)((ty0 + py) * s + i)) * (size_t)WF + (size_t)((tx0 + px) * s + j);
-            float v = s_out[cl * CS + py * TW + px];
-            if constexpr (EP != BNERV_EP_PLAIN) { if (d.bias) v += d.bias[co]; }
-            if constexpr (EP == BNERV_EP_BIAS || EP == BNERV_EP_PLAIN) d.out[o] = v;
-            if constexpr (EP == BNERV_EP_BIAS_SIN) { float sv, cv; sincosf(v, &sv, &cv); d.out[o] = sv; if (d.out2) d.out2[o] = cv; }
-            if constexpr (EP == BNERV_EP_BIAS_RES) d.out[o] = v + d.aux0[o];
-            if constexpr (EP == BNERV_EP_BIAS_TANH) d.out[o] = tanhf(v) * 0.5f + 0.5f;
-        }
     }
 }
 
-template <int KS, int NTB>
-constexpr size_t conv_lds_bytes(bool reduce_ep) {
+template <int KS, int IN, int EP, int NTB, int NQ1>
+int launch_fast(hipStream_t st, KArgs& ka) {
     using G = Geo<KS>;
-    size_t a = (size_t)CC * G::PLANE + (size_t)G::T * NQ * NTB * 64;
-    size_t o = (size_t)NTB * 16 * CS + (reduce_ep ? (size_t)4 * NTB * 16 * 2 : 0);
-    return (a > o ? a : o) * sizeof(float);
+    const bnerv_conv_desc& d = ka.d;
+    ka.ngroups = cdiv(cdiv(d.Cout, 16), NTB);
+    ka.total_items = ka.ngroups * d.B * ka.tiles_x * ka.tiles_y;
+    ka.nq_total = NQ1;
+    ka.w_resident = 1;
+    const int s2 = d.out_s * d.out_s;
+    int ncs = d.Cout >= 16 ? 16 : ((d.Cout + 3) / 4) * 4;          // multiple of 4: float4 / PixelShuffle(2) groups stay whole
+    if (s2 > 4) ncs = 16;
+    const size_t lds = ((size_t)NQ1 * 4 * G::PLANE + (size_t)ncs * CS + (size_t)G::T * NQ1 * NTB * 64) * sizeof(float);
+    static size_t attr_lds = 0;
+    static int blocks_per_cu = 0;
+    if (lds > attr_lds || blocks_per_cu == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fast_kernel<KS, IN, EP, NTB, NQ1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_fast_kernel<KS, IN, EP, NTB, NQ1>), 256, lds) != hipSuccess || nb < 1) nb = 1;
+        blocks_per_cu = nb > 4 ? 4 : nb;
+    }
+    int grid = 256 * blocks_per_cu;                       // everything resident: the static item partition is then balanced
+    if (grid > ka.total_items) grid = ka.total_items;
+    hipLaunchKernelGGL((conv_fast_kernel<KS, IN, EP, NTB, NQ1>), dim3(grid), dim3(256), lds, st, ka, ncs);
+    BNERV_LAUNCH_CHECK("conv_fast");
+    return BNERV_OK;
 }
 
 template <int KS, int IN, int EP, int NTB>
-int launch_one(hipStream_t st, const KArgs& ka, int ngroups) {
-    constexpr bool red = (EP == BNERV_EP_DGELU || EP == BNERV_EP_DSIN);
-    constexpr size_t lds = conv_lds_bytes<KS, NTB>(red);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, IN, EP, NTB>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+int launch_one(hipStream_t st, KArgs& ka) {
+    // fast path: instantiated for the shapes the decoders actually have at high resolution (Cin 9..16; Cout <= 16 or 33..48)
+    if constexpr (IN != BNERV_IN_UNSHUFFLE && (NTB == 1 || NTB == 3)) {
+        if (ka.vec && ka.d.Cin <= CC && ka.d.Cin > 8) {
+            if (ka.d.Cin <= 12) return launch_fast<KS, IN, EP, NTB, 3>(st, ka);
+            return launch_fast<KS, IN, EP, NTB, 4>(st, ka);
+        }
     }
-    dim3 grid(ka.tiles_x * ka.tiles_y, ngroups, ka.d.B);
-    hipLaunchKernelGGL((conv_igemm_kernel<KS, IN, EP, NTB>), grid, dim3(256), lds, st, ka);
+    using G = Geo<KS>;
+    const bnerv_conv_desc& d = ka.d;
+    const int nt = cdiv(d.Cout, 16);
+    ka.ngroups = cdiv(nt, NTB);
+    ka.total_items = ka.ngroups * d.B * ka.tiles_x * ka.tiles_y * ka.ksplit;
+    ka.nq_total = cdiv(d.Cin, 4);
+    const size_t wres = (size_t)G::T * ka.nq_total * NTB * 64;
+    ka.w_resident = wres <= (size_t)W_RESIDENT_MAX ? 1 : 0;
+    const size_t wfl = ka.w_resident ? wres : (size_t)G::T * NQ * NTB * 64;
+    const size_t lds = ((size_t)CC * G::PLANE + (size_t)16 * CS + wfl) * sizeof(float);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, IN, EP, NTB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    const int per_cu = (int)((size_t)160 * 1024 / lds);
+    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    if (grid > ka.total_items) grid = ka.total_items;
+    hipLaunchKernelGGL((conv_igemm_kernel<KS, IN, EP, NTB>), dim3(grid), dim3(256), lds, st, ka);
     BNERV_LAUNCH_CHECK("conv_igemm");
     return BNERV_OK;
 }
 
 template <int KS, int IN, int EP>
-int launch_ntb(hipStream_t st, const KArgs& ka) {
+int launch_ntb(hipStream_t st, KArgs& ka) {
     const int nt = cdiv(ka.d.Cout, 16);
-    if (nt == 1) return launch_one<KS, IN, EP, 1>(st, ka, 1);
-    if (nt == 2) return launch_one<KS, IN, EP, 2>(st, ka, 1);
-    if (nt == 3) return launch_one<KS, IN, EP, 3>(st, ka, 1);
-    return launch_one<KS, IN, EP, 4>(st, ka, cdiv(nt, 4));
+    if (nt == 1) return launch_one<KS, IN, EP, 1>(st, ka);
+    if (nt == 2) return launch_one<KS, IN, EP, 2>(st, ka);
+    if (nt == 3) return launch_one<KS, IN, EP, 3>(st, ka);
+    return launch_one<KS, IN, EP, 4>(st, ka);
 }
 
 template <int KS>
-int launch_mode(hipStream_t st, const KArgs& ka) {
+int launch_mode(hipStream_t st, KArgs& ka) {
     const int in = ka.d.in_mode, ep = ka.d.ep_mode;
 #define BNERV_CASE(I, E) if (in == I && ep == E) return launch_ntb<KS, I, E>(st, ka);
     BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS)
@@ -287,18 +688,42 @@ int launch_mode(hipStream_t st, const KArgs& ka) {
     return bnerv_set_error(BNERV_E_ARG, "conv_igemm: unsupported (k=%d, in_mode=%d, ep_mode=%d)", KS, in, ep);
 }
 
+// Split-K policy: layers with a long K loop and almost no spatial parallelism (the low-resolution data gradients:
+// Cin = 750 or 1975 at 9x16 = 2 tiles) spread the input-channel chunks over work items.  Only for EP_PLAIN, out_s == 1.
+struct SplitPlan { int ksplit, chunks_per_split; };
+SplitPlan plan_split(const bnerv_conv_desc& d) {
+    SplitPlan p{1, 0};
+    if (d.ep_mode != BNERV_EP_PLAIN || d.out_s != 1) return p;
+    const int nchunks = cdiv(d.Cin, CC);
+    const int nt = cdiv(d.Cout, 16);
+    const int ngroups = cdiv(nt, nt >= 4 ? 4 : nt);
+    const int items = ngroups * d.B * cdiv(d.H, TH) * cdiv(d.W, TW);
+    if (nchunks < 8 || items >= 128) return p;
+    int ks = 512 / items;
+    if (ks > nchunks) ks = nchunks;
+    if (ks < 2) return p;
+    p.chunks_per_split = cdiv(nchunks, ks);
+    p.ksplit = cdiv(nchunks, p.chunks_per_split);
+    return p;
+}
+
 }  // namespace
 
 extern "C" int bnerv_conv_tiles(int H, int W) { return cdiv(H, TH) * cdiv(W, TW); }
+
+extern "C" size_t bnerv_conv_splitk_ws_bytes(const bnerv_conv_desc* dp) {
+    if (!dp || dp->B <= 0 || dp->Cin <= 0 || dp->Cout <= 0 || dp->H <= 0 || dp->W <= 0) return 0;
+    const SplitPlan p = plan_split(*dp);
+    return p.ksplit > 1 ? (size_t)p.ksplit * dp->B * dp->Cout * dp->H * dp->W * sizeof(float) : 0;
+}
 
 extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
     BNERV_REQUIRE(dp != nullptr, "conv_igemm: null descriptor");
     KArgs ka;
     ka.d = *dp;
-    const bnerv_conv_desc& d = ka.d;
+    bnerv_conv_desc& d = ka.d;
     BNERV_REQUIRE(d.k == 1 || d.k == 3, "conv_igemm: k must be 1 or 3 (got %d)", d.k);
     BNERV_REQUIRE(d.B > 0 && d.Cin > 0 && d.Cout > 0 && d.H > 0 && d.W > 0, "conv_igemm: bad dims");
-    BNERV_REQUIRE(d.B <= 65535, "conv_igemm: batch too large");
     BNERV_REQUIRE(d.x && d.w && d.out, "conv_igemm: null tensor");
     BNERV_REQUIRE(d.in_s >= 1 && d.out_s >= 1, "conv_igemm: shuffle factors must be >= 1");
     BNERV_REQUIRE(d.Cout % (d.out_s * d.out_s) == 0, "conv_igemm: Cout %d not divisible by out_s^2", d.Cout);
@@ -310,8 +735,21 @@ extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
     if (d.ep_mode == BNERV_EP_BIAS_RES) BNERV_REQUIRE(d.aux0, "conv_igemm: residual epilogue needs aux0");
     if (d.ep_mode == BNERV_EP_DGELU) BNERV_REQUIRE(d.aux0 && d.scale && d.partial && d.out_s == 1, "conv_igemm: DGELU epilogue args");
     if (d.ep_mode == BNERV_EP_DSIN) BNERV_REQUIRE(d.aux0 && d.aux1 && d.scale && d.partial && d.out_s == 1, "conv_igemm: DSIN epilogue args");
+    if (d.in_mode == BNERV_IN_UNSHUFFLE && d.in_s == 1) d.in_mode = BNERV_IN_PLAIN;       // same gather, faster staging
     ka.tiles_x = cdiv(d.W, TW);
     ka.tiles_y = cdiv(d.H, TH);
+    // float4 paths need 16-B aligned rows: W % 4 == 0 and 16-B aligned base pointers (NULL counts as aligned)
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    ka.vec = ((d.W % 4 == 0) && al(d.x) && al(d.out) && al(d.out2) && al(d.aux0) && al(d.aux1) && al(d.aux2)) ? 1 : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);
+    ka.ksplit = 1;
+    ka.chunks_per_split = 0;
+    if (d.ep_mode == BNERV_EP_PLAIN && d.partial != nullptr) {            // caller supplied a split-K workspace
+        const SplitPlan p = plan_split(d);
+        ka.ksplit = p.ksplit;
+        ka.chunks_per_split = p.chunks_per_split;
+    }
+    const int rc = d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);
+    if (rc != BNERV_OK || ka.ksplit == 1) return rc;
+    return bnerv_reduce_slabs(stream, d.partial, ka.ksplit, d.B * d.Cout * d.H * d.W, d.out);
 }

@@ -1,49 +1,63 @@
 // wgrad.hip -- weight + bias gradient of the decoder convolutions as an MFMA 16x16x4 GEMM with K = pixels.
 //
 //   dw[co][n] = sum_{b, p} g[b][co][p] * a[b][ci(n)][p + tap(n) - pad],   n = ci*T + tap   (the OIHW flattening)
-//   db[co]    = the extra column n = Cin*T whose B operand is the constant 1
+//   db[co]    = the extra column n = Cin*T, whose B operand reads a plane of ones
 // (autograd's backward of F.conv2d wrt weight/bias at lib/quant_ops.py:39-41; call sites as in conv.hip.)
 //
 // GEMM view: M = cout (MTW tiles of 16), N = (ci,tap)+bias column (NTW tiles of 16), K = pixels of an 8x32 spatial tile
-// (4 per MFMA: lane k-slot kq <-> pixel 4*step + kq).  A block walks spatial tiles in a grid-stride loop with the
-// accumulators in registers; its 4 waves split each tile's 64 K-steps; every wave writes ONE slab at the end and
-// reduce_slabs finishes the sum deterministically (no atomics, no memset).
-//   LDS: s_g  [MTW*16][256 + 2]   gradient tile, cout-major, stride == 2 (mod 32): conflict-free A reads
-//        s_in [<=16 planes][halo tile] exactly as in conv.hip (same prologues: plain / affine / gelu-affine)
+// (4 per MFMA: lane k-slot kq <-> pixel 4*step + kq).  PERSISTENT blocks walk spatial tiles with the accumulators in
+// registers; the 4 waves of a block split each tile's 64 K-steps; at the end the waves are summed through LDS and the block
+// writes ONE slab; wgrad_finish sums the slabs in a fixed order (deterministic, no atomics, no memset).
+//   LDS  s_g  [MTW*16][256 + 2]    gradient tile, cout-major; stride == 2 (mod 32) -> conflict-free A reads
+//        s_in [planes][ROWS][RS]   halo tile of a = prologue(x), RS = 40 (aligned float4 segments, as conv.hip); plane stride
+//                                  == 4 (mod 32) so the 16 (ci,tap) columns x 2 k-lanes of a B read fall on distinct banks;
+//                                  + a plane of ones (bias column) + a plane of zeros (columns beyond the weight matrix)
+// The K loop is fully unrolled: every ds_read has an immediate offset, the body is (MTW + NTW) ds_read_b32 + MTW*NTW MFMA.
+// Staging is float4 from global; for the single-cout-tile shapes (all the 12-channel layers) the loads of tile t+1 are issued
+// before the MFMA phase of tile t and committed to LDS after it.
 #include "common.h"
 
 namespace {
 
 constexpr int TH = 8, TW = 32;
-constexpr int MAXPL = 16;
 constexpr int CSG = TH * TW + 2;
 
 template <int KS> struct Geo {
     static constexpr int PAD = (KS - 1) / 2;
     static constexpr int ROWS = TH + 2 * PAD;
-    static constexpr int RS = TW + 2 * PAD;
-    static constexpr int PLANE_RAW = ROWS * RS;
-    static constexpr int PLANE = ((PLANE_RAW - 16 + 31) / 32) * 32 + 16;
+    static constexpr int XOFF = (KS == 3) ? 4 : 0;
+    static constexpr int RS = TW + 2 * XOFF;                   // 40 / 32
+    static constexpr int SEGS = RS / 4;
+    static constexpr int PLANE_RAW = ROWS * RS;                // 400 / 256
+    // 3x3: == 4 (mod 32): columns (ci, ky, kx)+kq map to banks 4*ci' + 8*ky + kx + kq
+    // 1x1: == 2 (mod 32): 16 consecutive channels x 2 k-lanes -> 32 distinct banks
+    static constexpr int PLANE = (KS == 3) ? 420 : 258;
     static constexpr int T = KS * KS;
+    static constexpr int COL0 = XOFF - PAD;
+    static constexpr int NPL = (KS == 3) ? 14 : 16;            // data planes per block; + 1 plane of ones + 1 of zeros
 };
 
 struct WArgs {
     bnerv_wgrad_desc d;
     float* slab;
     int tiles_x, tiles_y, n_mgroups, n_ngroups, ncols;   // ncols = Cin*T + 1
+    int vec;
 };
 
+__device__ __forceinline__ void lds_barrier() {
+    // LDS-only hazard: do NOT drain the global loads that are prefetching the next tile
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int IN>
-__device__ __forceinline__ float load_x(const bnerv_wgrad_desc& d, int b, int ci, int gy, int gx) {
-    const size_t idx = (((size_t)b * d.Cin + ci) * d.H + gy) * (size_t)d.W + gx;
-    const float v = d.x[idx];
-    if constexpr (IN == BNERV_IN_AFFINE) return v * (1.0f + d.scale[b * d.Cin + ci]) + d.shift[b * d.Cin + ci];
-    if constexpr (IN == BNERV_IN_GELU_AFFINE) return gelu_f(v) * (1.0f + d.scale[b * d.Cin + ci]) + d.shift[b * d.Cin + ci];
+__device__ __forceinline__ float xf_in(float v, float sc, float sh) {
+    if constexpr (IN == BNERV_IN_AFFINE) return v * sc + sh;
+    if constexpr (IN == BNERV_IN_GELU_AFFINE) return gelu_f(v) * sc + sh;
     return v;
 }
 
 template <int GM>
-__device__ __forceinline__ float load_g(const bnerv_wgrad_desc& d, int b, int co, int gy, int gx) {
+__device__ __forceinline__ float load_g_scalar(const bnerv_wgrad_desc& d, int b, int co, int gy, int gx) {
     if constexpr (GM == BNERV_IN_TANHGRAD) {
         const size_t idx = (((size_t)b * d.Cout + co) * d.H + gy) * (size_t)d.W + gx;
         const float t = 2.0f * d.gaux[idx] - 1.0f;
@@ -57,12 +71,14 @@ __device__ __forceinline__ float load_g(const bnerv_wgrad_desc& d, int b, int co
 }
 
 template <int KS, int IN, int GM, int MTW, int NTW>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WArgs wa) {
+__global__ __launch_bounds__(256, (MTW * NTW <= 7 ? 3 : 2)) void conv_wgrad_kernel(const WArgs wa) {
     using G = Geo<KS>;
+    constexpr bool PIPE = (MTW == 1);                          // register-prefetch the next tile under the MFMA phase
+    constexpr bool GTWO = true;                                // GM is UNSHUFFLE or TANHGRAD: both may need a second float4
     const bnerv_wgrad_desc& d = wa.d;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_g = smem;                          // MTW*16*CSG
-    float* s_in = smem + MTW * 16 * CSG;        // MAXPL*PLANE
+    float* s_g = smem;                                  // MTW*16*CSG
+    float* s_in = smem + MTW * 16 * CSG;                // (NPL + 2) * PLANE
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -70,26 +86,165 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WArgs wa) {
     const int co_base = mg * MTW * 16;
     const int n_base = ngp * NTW * 16;
     const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
-    const int nW = Cin * G::T;                  // weight columns; column nW is the bias column
+    const int nW = Cin * G::T;                          // weight columns; column nW is the bias column
     const int ci_lo = min(n_base, nW - 1) / G::T;
     const int ci_hi = min(n_base + NTW * 16 - 1, nW - 1) / G::T;
-    const int npl = ci_hi - ci_lo + 1;          // <= MAXPL by construction of NTW
+    const int npl = ci_hi - ci_lo + 1;                  // <= NPL by construction of NTW
+    const bool vec_x = wa.vec != 0;
+    const bool vec_g = wa.vec != 0 && (GM == BNERV_IN_TANHGRAD || d.g_s <= 2);
+    const bool pair = (GM == BNERV_IN_UNSHUFFLE) && d.g_s == 2;
+    const int ng_slots = (pair ? MTW * 8 : MTW * 16) * TH * (TW / 4);
+    const int nx_slots = npl * G::ROWS * G::SEGS;
 
-    // per-lane B-fragment descriptors for this block's N tiles
-    int boff[NTW];
-    float bconst[NTW];   // value used when the column is not an LDS read: 1 for the bias column, 0 beyond it
-    bool bread[NTW];
+    // constant planes: ones (bias column) and zeros (columns beyond the matrix)
+    for (int i = tid; i < 2 * G::PLANE; i += 256) s_in[G::NPL * G::PLANE + i] = i < G::PLANE ? 1.0f : 0.0f;
+
+    // per-lane fragment bases.  pixel of (wave, step, kq): p = wave*64 + step*4 + kq
+    int bbase[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int n = n_base + nt * 16 + li;
+        int off;
         if (n < nW) {
             const int ci = n / G::T, tap = n - ci * G::T;
-            boff[nt] = (ci - ci_lo) * G::PLANE + (tap / KS) * G::RS + (tap % KS);
-            bread[nt] = true; bconst[nt] = 0.f;
+            off = (ci - ci_lo) * G::PLANE + (tap / KS) * G::RS + (tap % KS) + G::COL0;
         } else {
-            boff[nt] = 0; bread[nt] = false; bconst[nt] = (n == nW) ? 1.0f : 0.0f;
+            off = (n == nW ? G::NPL : G::NPL + 1) * G::PLANE;
         }
+        bbase[nt] = off + (2 * wave) * G::RS + kq;
     }
+    int abase[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) abase[m] = (m * 16 + li) * CSG + wave * 64 + kq;
+
+    // ---- slot-level staging primitives (float4) ----
+    // g: slot = (cout, row, 4-px segment)   [pair: slot = (cout PAIR (c,i; j=0,1), row, segment): two float4 of the shuffled row]
+    auto g_load = [&](int sidx, int b, int ty0, int tx0, f32x4& va, f32x4& vb) {
+        va = f32x4{0.f, 0.f, 0.f, 0.f}; vb = va;
+        if (sidx >= ng_slots) return;
+        const int c = sidx >> 6, rem = sidx & 63, r = rem >> 3, sg = rem & 7;
+        const int gy = ty0 + r, gx = tx0 + 4 * sg;
+        if (gy >= H || gx >= W) return;
+        if (pair) {
+            const int co = co_base + 2 * c;
+            if (co < Cout) {
+                const int cf = co >> 2, i = (co >> 1) & 1;
+                const float* src = d.g + (((size_t)b * (Cout >> 2) + cf) * (size_t)(2 * H) + (size_t)(2 * gy + i)) * (size_t)(2 * W) + (size_t)(2 * gx);
+                va = *reinterpret_cast<const f32x4*>(src);
+                vb = *reinterpret_cast<const f32x4*>(src + 4);
+            }
+        } else {
+            const int co = co_base + c;
+            if (co < Cout) {
+                const size_t idx = (((size_t)b * Cout + co) * H + gy) * (size_t)W + gx;
+                va = *reinterpret_cast<const f32x4*>(d.g + idx);
+                if constexpr (GM == BNERV_IN_TANHGRAD) vb = *reinterpret_cast<const f32x4*>(d.gaux + idx);
+            }
+        }
+    };
+    auto g_store = [&](int sidx, f32x4 a, f32x4 bq) {
+        if (sidx >= ng_slots) return;
+        const int c = sidx >> 6, rem = sidx & 63, r = rem >> 3, sg = rem & 7;
+        if (pair) {
+            float* dst = s_g + (2 * c) * CSG + r * TW + 4 * sg;                 // 8-B aligned (CSG*4 = 1032)
+            *reinterpret_cast<float2*>(dst) = float2{a[0], a[2]};
+            *reinterpret_cast<float2*>(dst + 2) = float2{bq[0], bq[2]};
+            *reinterpret_cast<float2*>(dst + CSG) = float2{a[1], a[3]};
+            *reinterpret_cast<float2*>(dst + CSG + 2) = float2{bq[1], bq[3]};
+        } else {
+            if constexpr (GM == BNERV_IN_TANHGRAD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = 2.0f * bq[e] - 1.0f; a[e] = a[e] * 0.5f * (1.0f - t * t); }
+            }
+            float* dst = s_g + c * CSG + r * TW + 4 * sg;
+            *reinterpret_cast<float2*>(dst) = float2{a[0], a[1]};
+            *reinterpret_cast<float2*>(dst + 2) = float2{a[2], a[3]};
+        }
+    };
+    auto x_load = [&](int sidx, int b, int ty0, int tx0, f32x4& v) {
+        v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (sidx >= nx_slots) return;
+        const int c = sidx / (G::ROWS * G::SEGS);
+        const int rem = sidx - c * (G::ROWS * G::SEGS);
+        const int r = rem / G::SEGS, sg = rem - r * G::SEGS;
+        const int gy = ty0 + r - G::PAD, gx = tx0 - G::XOFF + 4 * sg;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = *reinterpret_cast<const f32x4*>(d.x + (((size_t)b * Cin + ci_lo + c) * H + gy) * (size_t)W + gx);
+    };
+    auto x_store = [&](int sidx, int b, int ty0, int tx0, f32x4 v) {
+        if (sidx >= nx_slots) return;
+        const int c = sidx / (G::ROWS * G::SEGS);
+        const int rem = sidx - c * (G::ROWS * G::SEGS);
+        const int r = rem / G::SEGS, sg = rem - r * G::SEGS;
+        if constexpr (IN != BNERV_IN_PLAIN) {
+            const int gy = ty0 + r - G::PAD, gx = tx0 - G::XOFF + 4 * sg;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {                      // padding AFTER the prologue
+                const float sc = 1.0f + d.scale[b * Cin + ci_lo + c], sh = d.shift[b * Cin + ci_lo + c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = xf_in<IN>(v[e], sc, sh);
+            }
+        }
+        float* dst = s_in + c * G::PLANE + r * G::RS + 4 * sg;                  // PLANE*4 = 1680 / 1032 bytes: 8-B aligned
+        *reinterpret_cast<float2*>(dst) = float2{v[0], v[1]};
+        *reinterpret_cast<float2*>(dst + 2) = float2{v[2], v[3]};
+    };
+    // scalar fallbacks (W % 4 != 0, or pixel-unshuffle factors 3 / 5): low-resolution layers only
+    auto g_stage_scalar = [&](int b, int ty0, int tx0) {
+        for (int idx = tid; idx < MTW * 16 * TH * TW; idx += 256) {
+            const int cl = idx >> 8, p = idx & 255;
+            const int co = co_base + cl, gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
+            float v = 0.f;
+            if (co < Cout && gy < H && gx < W) v = load_g_scalar<GM>(d, b, co, gy, gx);
+            s_g[cl * CSG + p] = v;
+        }
+    };
+    auto x_stage_scalar = [&](int b, int ty0, int tx0) {
+        for (int idx = tid; idx < npl * G::PLANE_RAW; idx += 256) {
+            const int c = idx / G::PLANE_RAW;
+            const int rem = idx - c * G::PLANE_RAW;
+            const int r = rem / G::RS, col = rem - r * G::RS;
+            const int gy = ty0 + r - G::PAD, gx = tx0 + col - G::XOFF;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                v = d.x[(((size_t)b * Cin + ci_lo + c) * H + gy) * (size_t)W + gx];
+                if constexpr (IN != BNERV_IN_PLAIN) v = xf_in<IN>(v, 1.0f + d.scale[b * Cin + ci_lo + c], d.shift[b * Cin + ci_lo + c]);
+            }
+            s_in[c * G::PLANE + r * G::RS + col] = v;
+        }
+    };
+
+    constexpr int NGS = MTW * 16 * TH * (TW / 4) / 256;           // g slots per thread (pair path uses half of them)
+    constexpr int NXS = (G::NPL * G::ROWS * G::SEGS + 255) / 256;
+    f32x4 ga[PIPE ? NGS : 1], gb[PIPE && GTWO ? NGS : 1], xa[PIPE ? NXS : 1];
+
+    auto issue = [&](int b, int ty0, int tx0) {                  // PIPE only
+        if (vec_g) {
+#pragma unroll
+            for (int k = 0; k < NGS; ++k) g_load(tid + k * 256, b, ty0, tx0, ga[PIPE ? k : 0], gb[PIPE ? k : 0]);
+        }
+        if (vec_x) {
+#pragma unroll
+            for (int k = 0; k < NXS; ++k) x_load(tid + k * 256, b, ty0, tx0, xa[PIPE ? k : 0]);
+        }
+    };
+    auto commit = [&](int b, int ty0, int tx0) {                 // PIPE only
+        if (vec_g) {
+#pragma unroll
+            for (int k = 0; k < NGS; ++k) g_store(tid + k * 256, ga[PIPE ? k : 0], gb[PIPE ? k : 0]);
+        } else g_stage_scalar(b, ty0, tx0);
+        if (vec_x) {
+#pragma unroll
+            for (int k = 0; k < NXS; ++k) x_store(tid + k * 256, b, ty0, tx0, xa[PIPE ? k : 0]);
+        } else x_stage_scalar(b, ty0, tx0);
+    };
+    auto stage_direct = [&](int b, int ty0, int tx0) {           // !PIPE: load + store slot by slot (registers reused)
+        if (vec_g) {
+            for (int sidx = tid; sidx < ng_slots; sidx += 256) { f32x4 a, bq; g_load(sidx, b, ty0, tx0, a, bq); g_store(sidx, a, bq); }
+        } else g_stage_scalar(b, ty0, tx0);
+        if (vec_x) {
+            for (int sidx = tid; sidx < nx_slots; sidx += 256) { f32x4 v; x_load(sidx, b, ty0, tx0, v); x_store(sidx, b, ty0, tx0, v); }
+        } else x_stage_scalar(b, ty0, tx0);
+    };
 
     f32x4 acc[MTW][NTW];
 #pragma unroll
@@ -99,50 +254,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WArgs wa) {
 
     const int tiles = wa.tiles_x * wa.tiles_y;
     const int total = d.B * tiles;
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    int t = blockIdx.x;
+    if (PIPE && t < total) {
         const int b = t / tiles, tile = t - b * tiles;
-        const int ty0 = (tile / wa.tiles_x) * TH, tx0 = (tile % wa.tiles_x) * TW;
-        __syncthreads();
-        for (int idx = tid; idx < MTW * 16 * TH * TW; idx += 256) {
-            const int cl = idx >> 8, p = idx & 255;
-            const int co = co_base + cl, gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
-            float v = 0.f;
-            if (co < Cout && gy < H && gx < W) v = load_g<GM>(d, b, co, gy, gx);
-            s_g[cl * CSG + p] = v;
+        issue(b, (tile / wa.tiles_x) * TH, (tile % wa.tiles_x) * TW);
+        commit(b, (tile / wa.tiles_x) * TH, (tile % wa.tiles_x) * TW);
+    }
+    for (; t < total; t += gridDim.x) {
+        const int tn = t + gridDim.x;
+        const bool has_next = tn < total;
+        const int bn = has_next ? tn / tiles : 0, tilen = has_next ? tn - bn * tiles : 0;
+        const int ty0n = (tilen / wa.tiles_x) * TH, tx0n = (tilen % wa.tiles_x) * TW;
+        if (!PIPE) {
+            const int b = t / tiles, tile = t - b * tiles;
+            lds_barrier();                                 // previous tile fully consumed
+            stage_direct(b, (tile / wa.tiles_x) * TH, (tile % wa.tiles_x) * TW);
         }
-        for (int idx = tid; idx < npl * G::PLANE_RAW; idx += 256) {
-            const int c = idx / G::PLANE_RAW;
-            const int rem = idx - c * G::PLANE_RAW;
-            const int r = rem / G::RS, col = rem - r * G::RS;
-            const int gy = ty0 + r - G::PAD, gx = tx0 + col - G::PAD;
-            float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = load_x<IN>(d, b, ci_lo + c, gy, gx);
-            s_in[c * G::PLANE + r * G::RS + col] = v;
-        }
-        __syncthreads();
-#pragma unroll 4
+        lds_barrier();                                     // tile t staged by everyone
+        if (PIPE && has_next) issue(bn, ty0n, tx0n);       // flies under the MFMA phase
+#pragma unroll
         for (int st = 0; st < 16; ++st) {
-            const int p = (wave * 16 + st) * 4 + kq;
-            const int poff = (p >> 5) * G::RS + (p & 31);
             float af[MTW], bf[NTW];
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) af[m] = s_g[(m * 16 + li) * CSG + p];
+            for (int m = 0; m < MTW; ++m) af[m] = s_g[abase[m] + st * 4];
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) {
-                const float v = s_in[boff[n] + poff];
-                bf[n] = bread[n] ? v : bconst[n];
-            }
+            for (int n = 0; n < NTW; ++n) bf[n] = s_in[bbase[n] + ((st >> 3) * G::RS + (st & 7) * 4)];
 #pragma unroll
             for (int m = 0; m < MTW; ++m)
 #pragma unroll
                 for (int n = 0; n < NTW; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[n], acc[m][n], 0, 0, 0);
         }
+        if (PIPE) {
+            lds_barrier();                                 // everyone done reading tile t
+            if (has_next) commit(bn, ty0n, tx0n);
+        }
     }
+
     // cross-wave reduction through LDS (fixed order => deterministic), then ONE slab per block:
     // slab[block][co][n]; D layout: lane holds rows (cout) 4*kq..4*kq+3 of column (n) li
     __syncthreads();
-    float* s_red = smem;                                      // [4 waves][MTW*16][NTW*16]  (fits: <= 4*64*64 floats only for (4,4); checked on host)
+    float* s_red = smem;
     constexpr int RW = NTW * 16, RSZ = MTW * 16 * RW;
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
@@ -196,22 +348,27 @@ Plan make_plan(int B, int Cin, int Cout, int H, int W, int k) {
     p.n_ngroups = cdiv(nt, p.ntw);
     const int total_tiles = B * cdiv(H, TH) * cdiv(W, TW);
     const int groups = p.n_mgroups * p.n_ngroups;
-    int target = 512 / groups;                   // ~2 blocks per CU in flight over all groups
+    // everything resident at once (balanced static partition): ~3 blocks per CU for the small-register shapes, 2 otherwise
+    const int per_cu = (p.mtw * p.ntw <= 7) ? 3 : 2;
+    int target = (256 * per_cu) / groups;
     if (target < 1) target = 1;
-    p.nsplit = total_tiles < target ? total_tiles : target;
+    // at least ~4 tiles per block: per-block fixed cost (constant planes, wave reduction, one slab) must stay amortised
+    int want = (total_tiles + 3) / 4;
+    if (want < 1) want = 1;
+    p.nsplit = want < target ? want : target;
     return p;
 }
 
 template <int KS, int IN, int GM, int MTW, int NTW>
 int launch_w(hipStream_t st, const WArgs& wa, const Plan& p) {
     using G = Geo<KS>;
-    constexpr size_t lds_main = (size_t)MTW * 16 * CSG + (size_t)MAXPL * G::PLANE;
+    constexpr size_t lds_main = (size_t)MTW * 16 * CSG + (size_t)(G::NPL + 2) * G::PLANE;
     constexpr size_t lds_red = (size_t)4 * MTW * 16 * NTW * 16;
     constexpr size_t lds = (lds_main > lds_red ? lds_main : lds_red) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<KS, IN, GM, MTW, NTW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid(p.nsplit, p.n_mgroups * p.n_ngroups);
@@ -273,6 +430,8 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
     wa.n_mgroups = p.n_mgroups;
     wa.n_ngroups = p.n_ngroups;
     wa.ncols = d.Cin * d.k * d.k + 1;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    wa.vec = ((d.W % 4 == 0) && al(d.x) && al(d.g) && al(d.gaux)) ? 1 : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc = d.k == 1 ? launch_modes<1>(st, wa, p) : launch_modes<3>(st, wa, p);
     if (rc != BNERV_OK) return rc;

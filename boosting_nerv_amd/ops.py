@@ -31,7 +31,14 @@ def _conv(x, w, bias, out, *, B, Cin, Cout, H, W, k, in_mode, ep_mode, in_s=1, o
     d = L.ConvDesc(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(out), L.ptr(out2), L.ptr(aux0), L.ptr(aux1), L.ptr(aux2),
                    L.ptr(scale), L.ptr(shift), L.ptr(partial), B, Cin, Cout, H, W, k, in_mode, ep_mode, in_s, out_s,
                    transposed, w.shape[0], w.shape[1])
-    L.check(L.load().bnerv_conv_igemm(L.stream(), C.byref(d)), "bnerv_conv_igemm")
+    lib = L.load()
+    ws = None
+    if ep_mode == L.EP_PLAIN and partial is None:
+        nbytes = lib.bnerv_conv_splitk_ws_bytes(C.byref(d))      # low-resolution, long-K layers want a split-K workspace
+        if nbytes:
+            ws = _ws(nbytes, x.device)
+            d.partial = ws.data_ptr()
+    L.check(lib.bnerv_conv_igemm(L.stream(), C.byref(d)), "bnerv_conv_igemm")
 
 
 def _wgrad(x, g, dw, db, *, B, Cin, Cout, H, W, k, in_mode, g_mode, g_s=1, gaux=None, scale=None, shift=None):

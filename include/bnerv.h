@@ -146,6 +146,11 @@ typedef struct {
 
 /* number of spatial tiles per sample (rows of `partial`) for an H x W conv-space image */
 int bnerv_conv_tiles(int H, int W);
+/* EP_PLAIN only: bytes of split-K workspace this layer wants (0 = none).  Layers with a long K loop and almost no
+ * spatial parallelism (the low-resolution data gradients, e.g. Cin = 750 at 9x16) split their input-channel range over
+ * work items; pass a buffer of this size in `partial` and bnerv_conv_igemm finishes with a deterministic slab reduction.
+ * With partial == NULL the layer runs unsplit. */
+size_t bnerv_conv_splitk_ws_bytes(const bnerv_conv_desc* d);
 int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* d);
 
 /* Weight + bias gradient (autograd's backward of F.conv2d wrt weight/bias at the same call sites):
