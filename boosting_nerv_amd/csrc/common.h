@@ -42,6 +42,13 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// Workgroup barrier for LDS hazards only: waits for this wave's LDS traffic (lgkmcnt) and NOT for global loads / stores
+// in flight.  __syncthreads() carries a global-memory fence (s_waitcnt vmcnt(0)) which would drain a register prefetch of
+// the next tile and expose the latency of the epilogue stores at every barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // XCD-aware remap of a 1-D block index: blocks that the dispatcher places on the same XCD (b % 8) get a contiguous
 // range of logical indices, so neighbouring tiles (which share halo rows) share one L2.  Bijective for any n.
 __device__ __forceinline__ int xcd_remap(int orig, int n) {

@@ -538,15 +538,17 @@ __global__ __launch_bounds__(256, (NTB == 1 ? (NQ1 <= 3 ? 4 : 3) : 2)) void conv
         }
     };
 
+    // Barriers here guard LDS hazards only, so they wait for LDS traffic (lgkmcnt) and NOT for the global stores of the
+    // previous copy-out or the prefetch loads in flight (a __syncthreads() would drain both: vmcnt(0)).
+    // Per tile (NTB = 1): (A) s_in(t) + weights visible, s_out free   (B) s_out(t) complete, s_in free.
     int cur_g = -1;
     int itx = r0 + lb;
+    Item it = decode_item(ka, itx < r1 ? itx : 0);
     if (itx < r1) {
-        const Item it = decode_item(ka, itx);
         issue(it);
         commit(it);
     }
     for (; itx < r1; itx += nlb) {
-        const Item it = decode_item(ka, itx);
         const int co_base = it.g * NTB * 16;
         f32x4 acc[4][NTB];
 #pragma unroll
@@ -554,14 +556,14 @@ __global__ __launch_bounds__(256, (NTB == 1 ? (NQ1 <= 3 ? 4 : 3) : 2)) void conv
 #pragma unroll
             for (int n = 0; n < NTB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (cur_g != it.g) {
-            __syncthreads();
+            lds_barrier();
             stage_weights<KS, NTB>(d, s_w, co_base, 0, NQ1, NQ1);
             cur_g = it.g;
         }
         const bool has_next = itx + nlb < r1;
         Item nxt = it;
         if (has_next) nxt = decode_item(ka, itx + nlb);
-        __syncthreads();                                   // s_in(it) committed by every thread, weights staged
+        lds_barrier();                                     // (A)
         if (has_next) issue(nxt);                          // flies under the MFMA phase
 #pragma unroll
         for (int tap = 0; tap < G::T; ++tap) {
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(256, (NTB == 1 ? (NQ1 <= 3 ? 4 : 3) : 2)) void conv
 #pragma unroll
         for (int n = 0; n < NTB; ++n) {
             if (co_base + n * 16 < d.Cout) {
-                if (n > 0) __syncthreads();
+                if (n > 0) lds_barrier();
                 if (li < ncs) {
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
@@ -590,12 +592,12 @@ __global__ __launch_bounds__(256, (NTB == 1 ? (NQ1 <= 3 ? 4 : 3) : 2)) void conv
                         *reinterpret_cast<f32x4*>(&s_out[li * CS + py * TW + px]) = acc[m][n];
                     }
                 }
-                __syncthreads();                           // s_out complete; every wave is done reading s_in
+                lds_barrier();                             // (B)
                 if (n == 0 && has_next) commit(nxt);
                 copy_out_tile<EP>(ka, s_out, it, co_base + n * 16);
             }
         }
-        __syncthreads();
+        it = nxt;                                          // barrier (A) of the next iteration also frees s_out
     }
 }
 

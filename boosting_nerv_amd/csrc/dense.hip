@@ -139,21 +139,34 @@ __global__ __launch_bounds__(256) void sft_affine_bwd_kernel(const float* __rest
 }
 
 // out[i] = sum_k slabs[k*count + i]: EPB consecutive elements x (256/EPB) slab lanes per block, fixed combination order
+// (1024 threads: these reductions are latency-bound -- a few MB at most -- so the lever is loads in flight, not bytes)
 template <int EPB>
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int count, float* __restrict__ out) {
-    constexpr int LANES = 256 / EPB;
-    __shared__ float red[LANES][EPB];
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int count, float* __restrict__ out) {
+    constexpr int LANES = 1024 / EPB;
+    __shared__ float red[LANES][EPB + 1];
     const int e = threadIdx.x % EPB, lane = threadIdx.x / EPB;
     const int i = blockIdx.x * EPB + e;
-    float s = 0.f;
-    if (i < count)
-        for (int k = lane; k < n_slabs; k += LANES) s += slabs[(size_t)k * count + i];
-    red[lane][e] = s;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < count) {
+        int k = lane;
+        for (; k + LANES < n_slabs; k += 2 * LANES) { s0 += slabs[(size_t)k * count + i]; s1 += slabs[(size_t)(k + LANES) * count + i]; }
+        if (k < n_slabs) s0 += slabs[(size_t)k * count + i];
+    }
+    red[lane][e] = s0 + s1;
+    __syncthreads();
+    // fixed-order tree over the lanes (deterministic): 16 partial sums per element, then one thread adds those
+    constexpr int G16 = LANES / 16;
+    if (lane < 16 && i < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < G16; ++k) t += red[lane * G16 + k][e];
+        red[lane * G16][e] = t;
+    }
     __syncthreads();
     if (lane == 0 && i < count) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < LANES; ++k) t += red[k][e];
+        for (int k = 0; k < 16; ++k) t += red[k * G16][e];
         out[i] = t;
     }
 }
@@ -236,9 +249,9 @@ extern "C" int bnerv_sft_affine_bwd(void* stream, const float* x, const float* s
 extern "C" int bnerv_reduce_slabs(void* stream, const float* slabs, int n_slabs, int count, float* out) {
     BNERV_REQUIRE(slabs && out && n_slabs > 0 && count > 0, "reduce_slabs: bad args");
     if (count >= 2048 || n_slabs <= 16)
-        hipLaunchKernelGGL(reduce_slabs_kernel<32>, dim3(cdiv(count, 32)), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs, count, out);
+        hipLaunchKernelGGL(reduce_slabs_kernel<32>, dim3(cdiv(count, 32)), dim3(1024), 0, (hipStream_t)stream, slabs, n_slabs, count, out);
     else
-        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(cdiv(count, 4)), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs, count, out);
+        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(cdiv(count, 4)), dim3(1024), 0, (hipStream_t)stream, slabs, n_slabs, count, out);
     BNERV_LAUNCH_CHECK("reduce_slabs");
     return BNERV_OK;
 }

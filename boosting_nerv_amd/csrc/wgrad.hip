@@ -44,11 +44,6 @@ struct WArgs {
     int vec;
 };
 
-__device__ __forceinline__ void lds_barrier() {
-    // LDS-only hazard: do NOT drain the global loads that are prefetching the next tile
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 template <int IN>
 __device__ __forceinline__ float xf_in(float v, float sc, float sh) {
     if constexpr (IN == BNERV_IN_AFFINE) return v * sc + sh;
@@ -314,20 +309,23 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 7 ? 3 : 2)) void conv_wgrad_kern
 
 // finish: dw[co][n] = sum_slabs, db[co] = column nW.  32 consecutive elements x 8 slab lanes per block: coalesced 128-B rows,
 // 8-way parallel over slabs, fixed combination order (deterministic).
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ slab, int n_slabs, int Cout, int ncols, float* __restrict__ dw, float* __restrict__ db) {
-    __shared__ float red[8][32];
-    const int e = threadIdx.x & 31, lane = threadIdx.x >> 5;
+__global__ __launch_bounds__(1024) void wgrad_finish_kernel(const float* __restrict__ slab, int n_slabs, int Cout, int ncols, float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float red[32][33];
+    const int e = threadIdx.x & 31, lane = threadIdx.x >> 5;        // 32 elements x 32 slab lanes: latency-bound, so go wide
     const int i = blockIdx.x * 32 + e;
     const int count = Cout * ncols;
-    float s = 0.f;
-    if (i < count)
-        for (int k = lane; k < n_slabs; k += 8) s += slab[(size_t)k * count + i];
-    red[lane][e] = s;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < count) {
+        int k = lane;
+        for (; k + 32 < n_slabs; k += 64) { s0 += slab[(size_t)k * count + i]; s1 += slab[(size_t)(k + 32) * count + i]; }
+        if (k < n_slabs) s0 += slab[(size_t)k * count + i];
+    }
+    red[lane][e] = s0 + s1;
     __syncthreads();
     if (lane == 0 && i < count) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][e];
+        for (int k = 0; k < 32; ++k) t += red[k][e];
         const int co = i / ncols, n = i - co * ncols;
         if (n < ncols - 1) dw[(size_t)co * (ncols - 1) + n] = t;
         else if (db) db[co] = t;
@@ -436,7 +434,7 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
     int rc = d.k == 1 ? launch_modes<1>(st, wa, p) : launch_modes<3>(st, wa, p);
     if (rc != BNERV_OK) return rc;
     const int count = d.Cout * wa.ncols;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(cdiv(count, 32)), dim3(256), 0, st, wa.slab, p.nsplit, d.Cout, wa.ncols, d.dw, d.db);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(cdiv(count, 32)), dim3(1024), 0, st, wa.slab, p.nsplit, d.Cout, wa.ncols, d.dw, d.db);
     BNERV_LAUNCH_CHECK("wgrad_finish");
     return BNERV_OK;
 }

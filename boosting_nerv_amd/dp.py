@@ -15,10 +15,11 @@ from . import _lib as L
 
 
 class GradBucket:
-    def __init__(self, params, process_group=None):
+    def __init__(self, params, process_group=None, force=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force = force          # run the exchange even on a 1-rank group (tests of the multi-GPU path)
         self.offsets, off = [], 0
         for p in self.params:
             self.offsets.append(off)
@@ -49,7 +50,7 @@ class GradBucket:
     @torch.no_grad()
     def allreduce_mean(self):
         """grad <- mean over ranks of grad (DDP semantics).  No-op for world size 1."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         for p in self.params:
             if p.grad is None:

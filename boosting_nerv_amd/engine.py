@@ -15,7 +15,7 @@ from .dp import GradBucket
 
 class TrainStep:
     def __init__(self, model, optimizer, loss_type, takes_image, batch_shape, device, use_graph=True, warmup_eager=3,
-                 process_group=None, world_size=1, clip_max_norm=0.0):
+                 process_group=None, world_size=1, clip_max_norm=0.0, force_bucket=False):
         self.model, self.opt, self.loss_type = model, optimizer, loss_type
         self.takes_image = takes_image                       # HNeRV_Boost consumes the frame; NeRV/ENeRV the frame index
         self.dev = device
@@ -29,7 +29,9 @@ class TrainStep:
         self.graph_a = self.graph_b = None
         self.loss_out = self.psnr_out = None
         self.world = world_size
-        self.bucket = GradBucket(model.parameters(), process_group) if world_size > 1 else None
+        # force_bucket: run the multi-GPU code path (bucket gather -> RCCL all-reduce -> scatter, two graphs) on a 1-rank
+        # group, so the path the scaling runs take can be tested on a single-GPU box
+        self.bucket = GradBucket(model.parameters(), process_group, force=force_bucket) if (world_size > 1 or force_bucket) else None
         self.params = [p for p in model.parameters() if p.requires_grad]
 
     # ---- pieces -------------------------------------------------------------------------------------------------------

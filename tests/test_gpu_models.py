@@ -190,3 +190,43 @@ def test_train_trajectory_matches_oracle(use_graph):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_dp_step_path_on_one_rank_group():
+    """The multi-GPU step (graph A [fwd,loss,bwd,bucket gather] -> RCCL all-reduce -> graph B [scatter, Adan]) executed on a
+    1-rank NCCL(=RCCL) group: must reproduce the single-GPU trajectory exactly (mean over 1 rank is the identity)."""
+    import os
+    import torch.distributed as dist
+    from boosting_nerv_amd.engine import TrainStep
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    from boosting_nerv_amd.optimizer import Adan
+    from boosting_nerv_amd.synth import SyntheticVideo
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        vid = SyntheticVideo(3, 180, 320)
+        frames = torch.stack([vid.frame(i) for i in range(3)]).to(DEV)
+        norm = torch.tensor([(i + 1) / 3 for i in range(3)], dtype=torch.float64, device=DEV)
+        results = []
+        for force in (False, True):
+            torch.manual_seed(1)
+            model = NeRV_Boost(1, args=configs.tiny_nerv()).to(DEV)
+            opt = Adan(model.parameters(), lr=0.003)
+            step = TrainStep(model, opt, "Fusion10_freq", False, (1, 3, 180, 320), torch.device(DEV), use_graph=True, warmup_eager=2, force_bucket=force)
+            losses = []
+            for s in range(7):
+                loss, _ = step(frames[s % 3:s % 3 + 1], norm[s % 3:s % 3 + 1])
+                losses.append(loss.item())
+            if force:
+                assert step.graph_b is not None
+            results.append((losses, [p.detach().clone() for p in model.parameters()]))
+        assert results[0][0] == results[1][0], (results[0][0], results[1][0])
+        for a, b in zip(results[0][1], results[1][1]):
+            assert torch.equal(a, b)
+    finally:
+        if created:
+            dist.destroy_process_group()
