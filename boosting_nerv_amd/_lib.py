@@ -84,6 +84,7 @@ SYMBOLS = {
     "bnerv_conv_tiles": (_I, [_I, _I]),
     "bnerv_conv_igemm": (_I, [_V, C.POINTER(ConvDesc)]),
     "bnerv_conv_splitk_ws_bytes": (_Z, [C.POINTER(ConvDesc)]),
+    "bnerv_conv_partial_rows": (_I, [C.POINTER(ConvDesc)]),
     "bnerv_conv_wgrad_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bnerv_conv_wgrad": (_I, [_V, C.POINTER(WgradDesc)]),
     "bnerv_loss_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),

@@ -713,6 +713,18 @@ SplitPlan plan_split(const bnerv_conv_desc& d) {
 
 extern "C" int bnerv_conv_tiles(int H, int W) { return cdiv(H, TH) * cdiv(W, TW); }
 
+static int conv_vec_ok(const bnerv_conv_desc& d) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return ((d.W % 4 == 0) && al(d.x) && al(d.out) && al(d.out2) && al(d.aux0) && al(d.aux1) && al(d.aux2)) ? 1 : 0;
+}
+
+extern "C" int bnerv_conv_partial_rows(const bnerv_conv_desc* dp) {
+    if (!dp || dp->H <= 0 || dp->W <= 0) return 0;
+    bnerv_conv_desc d = *dp;
+    if (d.in_mode == BNERV_IN_UNSHUFFLE && d.in_s == 1) d.in_mode = BNERV_IN_PLAIN;
+    return cdiv(d.H, TH) * cdiv(d.W, TW);     // every kernel of this build uses 8x32 tiles; callers must still ask (it may change)
+}
+
 extern "C" size_t bnerv_conv_splitk_ws_bytes(const bnerv_conv_desc* dp) {
     if (!dp || dp->B <= 0 || dp->Cin <= 0 || dp->Cout <= 0 || dp->H <= 0 || dp->W <= 0) return 0;
     const SplitPlan p = plan_split(*dp);
@@ -741,8 +753,7 @@ extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
     ka.tiles_x = cdiv(d.W, TW);
     ka.tiles_y = cdiv(d.H, TH);
     // float4 paths need 16-B aligned rows: W % 4 == 0 and 16-B aligned base pointers (NULL counts as aligned)
-    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    ka.vec = ((d.W % 4 == 0) && al(d.x) && al(d.out) && al(d.out2) && al(d.aux0) && al(d.aux1) && al(d.aux2)) ? 1 : 0;
+    ka.vec = conv_vec_ok(d);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     ka.ksplit = 1;
     ka.chunks_per_split = 0;

@@ -33,6 +33,15 @@ def _conv(x, w, bias, out, *, B, Cin, Cout, H, W, k, in_mode, ep_mode, in_s=1, o
                    transposed, w.shape[0], w.shape[1])
     lib = L.load()
     ws = None
+    if ep_mode in (L.EP_DGELU, L.EP_DSIN):
+        # per-tile (ds, dt) partial sums: the kernel (hence its tile height) is chosen from shape + alignment -> ask, allocate, reduce
+        rows = lib.bnerv_conv_partial_rows(C.byref(d))
+        part = torch.empty(rows, B, 2, Cout, dtype=torch.float32, device=x.device)
+        d.partial = part.data_ptr()
+        L.check(lib.bnerv_conv_igemm(L.stream(), C.byref(d)), "bnerv_conv_igemm")
+        st = torch.empty(B, 2, Cout, dtype=torch.float32, device=x.device)
+        _reduce_slabs(part, rows, B * 2 * Cout, st)
+        return st
     if ep_mode == L.EP_PLAIN and partial is None:
         nbytes = lib.bnerv_conv_splitk_ws_bytes(C.byref(d))      # low-resolution, long-K layers want a split-K workspace
         if nbytes:
@@ -243,23 +252,16 @@ def _tat_backward(dout, y0, c0, v, s0, t0, s1, t1, w0, w1):
     d/d(pre-sin) = (dout + dA0*(1+s0)) * c0, otherwise d/dy0."""
     B, Cc, H, W = y0.shape
     dev = y0.device
-    tiles = _tiles(H, W)
     dw1 = torch.empty_like(w1); db1 = torch.empty(Cc, dtype=torch.float32, device=dev)
     _wgrad(v, dout, dw1, db1, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_GELU_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s1, shift=t1)
     dv = torch.empty_like(y0)
-    part = torch.empty(tiles, B, 2, Cc, dtype=torch.float32, device=dev)
-    _conv(dout, w1, None, dv, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU, transposed=1,
-          aux0=v, scale=s1, partial=part)
-    st1 = torch.empty(B, 2, Cc, dtype=torch.float32, device=dev)
-    _reduce_slabs(part, tiles, B * 2 * Cc, st1)
+    st1 = _conv(dout, w1, None, dv, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU, transposed=1,
+                aux0=v, scale=s1)
     dw0 = torch.empty_like(w0); db0 = torch.empty(Cc, dtype=torch.float32, device=dev)
     _wgrad(y0, dv, dw0, db0, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s0, shift=t0)
     du = torch.empty_like(y0)
-    part0 = torch.empty(tiles, B, 2, Cc, dtype=torch.float32, device=dev)
-    _conv(dv, w0, None, du, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN, transposed=1,
-          aux0=y0, aux1=dout, aux2=c0, scale=s0, partial=part0)
-    st0 = torch.empty(B, 2, Cc, dtype=torch.float32, device=dev)
-    _reduce_slabs(part0, tiles, B * 2 * Cc, st0)
+    st0 = _conv(dv, w0, None, du, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN, transposed=1,
+                aux0=y0, aux1=dout, aux2=c0, scale=s0)
     return du, st0[:, 0], st0[:, 1], st1[:, 0], st1[:, 1], dw0, db0, dw1, db1
 
 

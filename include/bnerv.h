@@ -133,8 +133,9 @@ typedef struct {
     const float* aux2;
     const float* scale;   /* [B, Cin] for IN_AFFINE / IN_GELU_AFFINE;  [B, Cout] for EP_DGELU / EP_DSIN */
     const float* shift;   /* [B, Cin] for IN_AFFINE / IN_GELU_AFFINE */
-    float* partial;       /* EP_DGELU / EP_DSIN: [tiles][B][2][Cout] per-tile partial sums (written); finish with
-                             bnerv_reduce_slabs(partial, tiles, B*2*Cout, out) -> out[b][0][c] = ds, out[b][1][c] = dt */
+    float* partial;       /* EP_DGELU / EP_DSIN: [R][B][2][Cout] per-tile partial sums (written), R = bnerv_conv_partial_rows(d);
+                             finish with bnerv_reduce_slabs(partial, R, B*2*Cout, out) -> out[b][0][c] = ds, out[b][1][c] = dt.
+                             EP_PLAIN: optional split-K workspace (see bnerv_conv_splitk_ws_bytes) */
     int B, Cin, Cout, H, W;
     int k;                /* 1 or 3 */
     int in_mode, ep_mode;
@@ -144,8 +145,11 @@ typedef struct {
     int wCo, wCi;
 } bnerv_conv_desc;
 
-/* number of spatial tiles per sample (rows of `partial`) for an H x W conv-space image */
+/* number of 8x32 spatial tiles per sample of an H x W conv-space image */
 int bnerv_conv_tiles(int H, int W);
+/* EP_DGELU / EP_DSIN: number of per-sample rows R this descriptor's kernel writes into `partial` ([R][B][2][Cout]); the
+ * kernel is chosen from the shape and pointer alignment, so fill in every field except `partial` before asking. */
+int bnerv_conv_partial_rows(const bnerv_conv_desc* d);
 /* EP_PLAIN only: bytes of split-K workspace this layer wants (0 = none).  Layers with a long K loop and almost no
  * spatial parallelism (the low-resolution data gradients, e.g. Cin = 750 at 9x16) split their input-channel range over
  * work items; pass a buffer of this size in `partial` and bnerv_conv_igemm finishes with a deterministic slab reduction.
