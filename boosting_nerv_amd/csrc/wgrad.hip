@@ -332,6 +332,336 @@ __global__ __launch_bounds__(1024) void wgrad_finish_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- lean kernel
+// Same GEMM, for the shapes with ONE cout tile (every 12-channel layer and the 1x1 head), rebuilt around the measured cost
+// model of gfx950 (see conv.hip, "lean kernel"): VALU/SALU work is not hidden by the MFMAs of the other waves, so staging is
+// raw buffer loads with per-block slot offsets + a per-tile SGPR base, out-of-image slots are switched off through the
+// offset (no branches), interior tiles take a path without any per-slot arithmetic, tiles are walked incrementally, and each
+// XCD works on a contiguous slice of tiles (halo rows meet in one L2).  LDS is trimmed so that 4 blocks fit a CU.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned shift_bytes, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(p) - shift_bytes), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+struct LTile { int b, ty, tx; };
+
+// GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient (two float4 per channel PAIR), 2 = tanh-grad (g, gaux)
+template <int KS, int IN, int GM2>
+__global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(const WArgs wa, const int n_grows /* s_g rows kept */) {
+    using G = Geo<KS>;
+    constexpr int NTW = (KS == 3) ? 7 : 1;
+    constexpr int NPLL = (KS == 3) ? 12 : 15;                                // data planes (input channels) of this kernel
+    constexpr int NXSLOT = NPLL * G::ROWS * G::SEGS;
+    constexpr int NXS = (NXSLOT + 255) / 256;
+    constexpr int NGS = (GM2 == 1) ? 2 : 4;                                  // g slots per thread (16 couts, or 8 cout pairs)
+    constexpr bool GTWO = (GM2 != 0);
+    constexpr bool AFF = (IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE);
+    constexpr bool B128 = (G::PLANE % 4 == 0);                               // plane stride 16-B aligned -> ds_write_b128
+    const bnerv_wgrad_desc& d = wa.d;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_g = smem;                                                       // n_grows rows of CSG.  Rows beyond Cout are never written: the
+                                                                             // A reads of rows 12..15 then see s_in data, which only
+                                                                             // reaches output rows that are dropped.
+    float* s_in = smem + n_grows * CSG;                                      // (NPLL + 2) planes + dump area for idle slots (16-B aligned)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
+    const int nW = Cin * G::T;
+    const int tiles_x = wa.tiles_x, tiles_y = wa.tiles_y;
+
+    // XCD x owns a contiguous slice of the tile list; its blocks take it round-robin
+    const int total = d.B * tiles_x * tiles_y;
+    const int nx = min(8, (int)gridDim.x);                                   // (a grid of fewer than 8 blocks has fewer slices)
+    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx;
+    const int nlb = (gridDim.x - xcd + nx - 1) / nx;
+    const int per = total / nx, extra = total % nx;
+    const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
+    int itx = r0 + lb;
+    const bool has_work = itx < r1;                                          // (a block without tiles still writes its zero slab)
+    const int step_q = nlb / tiles_x, step_r = nlb - step_q * tiles_x;
+    LTile it{0, 0, 0};
+    if (has_work) {
+        const int tiles = tiles_x * tiles_y;
+        it.b = itx / tiles;
+        const int t = itx - it.b * tiles;
+        it.ty = t / tiles_x;
+        it.tx = t - it.ty * tiles_x;
+    }
+    auto advance = [&](LTile a) {
+        a.tx += step_r;
+        a.ty += step_q;
+        if (a.tx >= tiles_x) { a.tx -= tiles_x; ++a.ty; }
+        while (a.ty >= tiles_y) { a.ty -= tiles_y; ++a.b; }
+        return a;
+    };
+
+    // constant planes: ones (bias column) and zeros (columns beyond the weight matrix)
+    for (int i = tid; i < 2 * G::PLANE; i += 256) s_in[NPLL * G::PLANE + i] = i < G::PLANE ? 1.0f : 0.0f;
+
+    // ---- per-slot constants
+    auto xslot = [&](int k, int& c, int& r, int& sg) {
+        const int sidx = tid + k * 256;
+        c = sidx / (G::ROWS * G::SEGS);
+        const int rem = sidx - c * (G::ROWS * G::SEGS);
+        r = rem / G::SEGS;
+        sg = rem - r * G::SEGS;
+    };
+    auto x_inside = [&](int k, int ty0, int tx0) {
+        int c, r, sg;
+        xslot(k, c, r, sg);
+        const int gy = ty0 + r - G::PAD, gx = tx0 + 4 * sg - G::XOFF;
+        return (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    };
+    unsigned voffx[NXS], voffg[NGS];
+    int loffx[NXS], loffg[NGS];
+#pragma unroll
+    for (int k = 0; k < NXS; ++k) {
+        int c, r, sg;
+        xslot(k, c, r, sg);
+        const bool real = tid + k * 256 < NXSLOT;
+        voffx[k] = (real && c < Cin) ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB;
+        loffx[k] = real ? (c * G::PLANE + r * G::RS + 4 * sg) * 4 : ((NPLL + 2) * G::PLANE + (tid + k * 256 - NXSLOT) * 4) * 4;
+    }
+#pragma unroll
+    for (int k = 0; k < NGS; ++k) {
+        const int sidx = tid + k * 256;
+        const int c = sidx >> 6, r = (sidx >> 3) & 7, sg = sidx & 7;
+        if constexpr (GM2 == 1) {                                            // c = cout pair: couts 2c (j = 0) and 2c + 1 (j = 1)
+            const int co = 2 * c, cf = co >> 2, i = (co >> 1) & 1;
+            voffg[k] = co < Cout ? (unsigned)((((cf * 2 * H) + 2 * r + i) * (2 * W) + 8 * sg) * 4) : OOB;
+            loffg[k] = (2 * c * CSG + r * TW + 4 * sg) * 4;
+        } else {
+            voffg[k] = c < Cout ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB;
+            loffg[k] = (c * CSG + r * TW + 4 * sg) * 4;
+        }
+    }
+    const unsigned shift = (unsigned)((G::PAD * W + G::XOFF) * 4);
+    const unsigned x_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
+    const unsigned g_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, x_bytes);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(d.g, 0, g_bytes);
+    const __amdgpu_buffer_rsrc_t rg2 = make_rsrc(GM2 == 2 ? d.gaux : d.g, 0, g_bytes);
+
+    float sc[NXS], sh[NXS];
+    auto load_affine = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < NXS; ++k) {
+            int c, r, sg;
+            xslot(k, c, r, sg);
+            const bool ok = voffx[k] != OOB;
+            sc[k] = ok ? 1.0f + d.scale[b * Cin + c] : 0.f;
+            sh[k] = ok ? d.shift[b * Cin + c] : 0.f;
+        }
+    };
+
+    f32x4 xa[NXS], ga[NGS], gb[GTWO ? NGS : 1];
+    auto issue = [&](const LTile& a) {
+        const int ty0 = a.ty * TH, tx0 = a.tx * TW;
+        const unsigned sbx = (unsigned)((((a.b * Cin) * H + ty0) * W + tx0) * 4);
+        const unsigned sbg = GM2 == 1 ? (unsigned)(((((a.b * (Cout >> 2)) * 2 * H) + 2 * ty0) * (2 * W) + 2 * tx0) * 4)
+                                      : (unsigned)((((a.b * Cout) * H + ty0) * W + tx0) * 4);
+        const bool interior = ty0 >= G::PAD && ty0 + TH + G::PAD <= H && tx0 >= G::XOFF && tx0 + TW + G::XOFF <= W;
+        const bool gfull = ty0 + TH <= H && tx0 + TW <= W;
+        if (gfull) {
+#pragma unroll
+            for (int k = 0; k < NGS; ++k) {
+                ga[k] = bload(rg, voffg[k], sbg);
+                if constexpr (GM2 == 1) gb[k] = bload(rg, voffg[k] + 16u, sbg);
+                if constexpr (GM2 == 2) gb[k] = bload(rg2, voffg[k], sbg);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NGS; ++k) {
+                const int sidx = tid + k * 256;
+                const int r = (sidx >> 3) & 7, sg = sidx & 7;
+                const unsigned vo = (ty0 + r < H && tx0 + 4 * sg < W) ? voffg[k] : OOB;
+                ga[k] = bload(rg, vo, sbg);
+                if constexpr (GM2 == 1) gb[k] = bload(rg, vo == OOB ? OOB : vo + 16u, sbg);
+                if constexpr (GM2 == 2) gb[k] = bload(rg2, vo, sbg);
+            }
+        }
+        if (interior) {
+#pragma unroll
+            for (int k = 0; k < NXS; ++k) xa[k] = bload(rx, voffx[k], sbx);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NXS; ++k) xa[k] = bload(rx, x_inside(k, ty0, tx0) ? voffx[k] : OOB, sbx);
+        }
+    };
+    auto commit = [&](const LTile& a) {
+        const int ty0 = a.ty * TH, tx0 = a.tx * TW;
+        const bool interior = ty0 >= G::PAD && ty0 + TH + G::PAD <= H && tx0 >= G::XOFF && tx0 + TW + G::XOFF <= W;
+#pragma unroll
+        for (int k = 0; k < NGS; ++k) {
+            char* dst = reinterpret_cast<char*>(s_g) + loffg[k];
+            if constexpr (GM2 == 1) {
+                const f32x4 a0 = ga[k], a1 = gb[k];
+                if (voffg[k] != OOB) {                                       // rows beyond Cout are not kept in LDS
+                    *reinterpret_cast<float2*>(dst) = float2{a0[0], a0[2]};
+                    *reinterpret_cast<float2*>(dst + 8) = float2{a1[0], a1[2]};
+                    *reinterpret_cast<float2*>(dst + CSG * 4) = float2{a0[1], a0[3]};
+                    *reinterpret_cast<float2*>(dst + CSG * 4 + 8) = float2{a1[1], a1[3]};
+                }
+            } else {
+                f32x4 v = ga[k];
+                if constexpr (GM2 == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float t = 2.0f * gb[k][e] - 1.0f; v[e] = v[e] * 0.5f * (1.0f - t * t); }
+                }
+                if (voffg[k] != OOB) {                                       // rows beyond Cout are not kept in LDS
+                    *reinterpret_cast<float2*>(dst) = float2{v[0], v[1]};
+                    *reinterpret_cast<float2*>(dst + 8) = float2{v[2], v[3]};
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NXS; ++k) {
+            f32x4 v = xa[k];
+            if constexpr (IN != BNERV_IN_PLAIN) {
+                float s = AFF ? sc[k] : 0.f, h = AFF ? sh[k] : 0.f;
+                if (!interior) {                                             // zero padding is applied AFTER the prologue
+                    const bool ok = x_inside(k, ty0, tx0);
+                    s = ok ? s : 0.f;
+                    h = ok ? h : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = xf_in<IN>(v[e], s, h);
+            }
+            char* dst = reinterpret_cast<char*>(s_in) + loffx[k];
+            if constexpr (B128) {
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+                *reinterpret_cast<float2*>(dst) = float2{v[0], v[1]};
+                *reinterpret_cast<float2*>(dst + 8) = float2{v[2], v[3]};
+            }
+        }
+    };
+
+    // per-lane fragment bases.  pixel of (wave, step, kq): p = wave*64 + step*4 + kq
+    int bbase[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int n = nt * 16 + li;
+        int off;
+        if (n < nW) {
+            const int ci = n / G::T, tap = n - ci * G::T;
+            off = ci * G::PLANE + (tap / KS) * G::RS + (tap % KS) + G::COL0;
+        } else {
+            off = (n == nW ? NPLL : NPLL + 1) * G::PLANE;
+        }
+        bbase[nt] = off + (2 * wave) * G::RS + kq;
+    }
+    const int abase = li * CSG + wave * 64 + kq;
+
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int aff_b = -1;
+    if (has_work) {
+        issue(it);
+        if constexpr (AFF) { load_affine(it.b); aff_b = it.b; }
+        commit(it);
+    }
+    for (; itx < r1; itx += nlb) {
+        const bool has_next = itx + nlb < r1;
+        LTile nxt = it;
+        if (has_next) nxt = advance(it);
+        lds_barrier();                                     // tile t staged by everyone
+        if (has_next) issue(nxt);                          // flies under the MFMA phase
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            float bf[NTW];
+            const float af = s_g[abase + st * 4];
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) bf[n] = s_in[bbase[n] + ((st >> 3) * G::RS + (st & 7) * 4)];
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[n], acc[n], 0, 0, 0);
+        }
+        lds_barrier();                                     // everyone done reading tile t
+        if (has_next) {
+            if constexpr (AFF) { if (nxt.b != aff_b) { load_affine(nxt.b); aff_b = nxt.b; } }
+            commit(nxt);
+        }
+        it = nxt;
+    }
+
+    // cross-wave reduction through LDS (fixed order => deterministic), then ONE slab per block
+    __syncthreads();
+    float* s_red = smem;
+    constexpr int RW = NTW * 16, RSZ = 16 * RW;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_red[wave * RSZ + (4 * kq + r) * RW + n * 16 + li] = acc[n][r];
+    __syncthreads();
+    float* slab = wa.slab + (size_t)blockIdx.x * Cout * wa.ncols;
+    for (int idx = tid; idx < RSZ; idx += 256) {
+        const int row = idx / RW, col = idx - row * RW;
+        if (row < Cout && col < wa.ncols)
+            slab[(size_t)row * wa.ncols + col] = (s_red[idx] + s_red[RSZ + idx]) + (s_red[2 * RSZ + idx] + s_red[3 * RSZ + idx]);
+    }
+    (void)n_grows;
+}
+
+constexpr size_t WLEAN_MAX_BYTES = 0x7ff00000;
+
+static bool wlean_ok(const WArgs& wa) {
+    const bnerv_wgrad_desc& d = wa.d;
+    if (!wa.vec || d.Cout > 16) return false;
+    if (d.k == 3 && d.Cin > 12) return false;
+    if (d.k == 1 && d.Cin > 15) return false;
+    if (d.g_mode == BNERV_IN_UNSHUFFLE && d.g_s > 2) return false;
+    if (d.g_mode == BNERV_IN_UNSHUFFLE && d.g_s == 2 && (d.Cout % 4 != 0)) return false;
+    const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
+    return (size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 < WLEAN_MAX_BYTES;
+}
+
+static int wlean_blocks(const bnerv_wgrad_desc& d) {
+    const int total_tiles = d.B * cdiv(d.H, TH) * cdiv(d.W, TW);
+    int want = (total_tiles + 3) / 4;                     // >= ~4 tiles per block keeps the per-block fixed cost amortised
+    if (want < 1) want = 1;
+    const int target = 256 * (d.k == 3 ? 3 : 4);
+    return want < target ? want : target;
+}
+
+template <int KS, int IN, int GM2>
+int launch_wlean(hipStream_t st, const WArgs& wa) {
+    using G = Geo<KS>;
+    constexpr int NTW = (KS == 3) ? 7 : 1;
+    constexpr int NPLL = (KS == 3) ? 12 : 15;
+    constexpr int NXSLOT = NPLL * G::ROWS * G::SEGS;
+    constexpr int NXS = (NXSLOT + 255) / 256;
+    const int n_grows = wa.d.Cout <= 12 ? 12 : 16;
+    const size_t lds_main = (size_t)(NPLL + 2) * G::PLANE + (size_t)(NXS * 256 - NXSLOT) * 4 + (size_t)n_grows * CSG + 64;
+    const size_t lds_red = (size_t)4 * 16 * NTW * 16;
+    const size_t lds = (lds_main > lds_red ? lds_main : lds_red) * sizeof(float);
+    hipLaunchKernelGGL((wgrad_lean_kernel<KS, IN, GM2>), dim3(wlean_blocks(wa.d)), dim3(256), lds, st, wa, n_grows);
+    BNERV_LAUNCH_CHECK("wgrad_lean");
+    return BNERV_OK;
+}
+
+template <int KS>
+int launch_wlean_modes(hipStream_t st, const WArgs& wa) {
+    const int in = wa.d.in_mode, gm = wa.d.g_mode;
+    if (gm == BNERV_IN_TANHGRAD && in == BNERV_IN_PLAIN) return launch_wlean<KS, BNERV_IN_PLAIN, 2>(st, wa);
+    if (gm == BNERV_IN_PLAIN || gm == BNERV_IN_UNSHUFFLE) {
+        const bool pair = gm == BNERV_IN_UNSHUFFLE && wa.d.g_s == 2;
+        if (in == BNERV_IN_PLAIN) return pair ? launch_wlean<KS, BNERV_IN_PLAIN, 1>(st, wa) : launch_wlean<KS, BNERV_IN_PLAIN, 0>(st, wa);
+        if constexpr (KS == 3) {
+            if (!pair && in == BNERV_IN_AFFINE) return launch_wlean<KS, BNERV_IN_AFFINE, 0>(st, wa);
+            if (!pair && in == BNERV_IN_GELU_AFFINE) return launch_wlean<KS, BNERV_IN_GELU_AFFINE, 0>(st, wa);
+        }
+    }
+    return -1;                                            // not covered: the caller falls back to the general kernel
+}
+
 struct Plan { int mtw, ntw, n_mgroups, n_ngroups, nsplit; };
 
 Plan make_plan(int B, int Cin, int Cout, int H, int W, int k) {
@@ -405,7 +735,10 @@ int launch_modes(hipStream_t st, const WArgs& wa, const Plan& p) {
 extern "C" size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int k) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (k != 1 && k != 3)) return 0;
     const Plan p = make_plan(B, Cin, Cout, H, W, k);
-    return (size_t)p.nsplit * Cout * (Cin * k * k + 1) * sizeof(float);
+    bnerv_wgrad_desc t{};
+    t.B = B; t.H = H; t.W = W; t.k = k;
+    const int nb = wlean_blocks(t) > p.nsplit ? wlean_blocks(t) : p.nsplit;     // covers whichever kernel the launcher picks
+    return (size_t)nb * Cout * (Cin * k * k + 1) * sizeof(float);
 }
 
 extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
@@ -431,10 +764,15 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     wa.vec = ((d.W % 4 == 0) && al(d.x) && al(d.g) && al(d.gaux)) ? 1 : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int rc = d.k == 1 ? launch_modes<1>(st, wa, p) : launch_modes<3>(st, wa, p);
+    int rc = -1, n_slabs = p.nsplit;
+    if (wlean_ok(wa)) {
+        rc = d.k == 1 ? launch_wlean_modes<1>(st, wa) : launch_wlean_modes<3>(st, wa);
+        if (rc == BNERV_OK) n_slabs = wlean_blocks(d);
+    }
+    if (rc == -1) rc = d.k == 1 ? launch_modes<1>(st, wa, p) : launch_modes<3>(st, wa, p);
     if (rc != BNERV_OK) return rc;
     const int count = d.Cout * wa.ncols;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(cdiv(count, 32)), dim3(1024), 0, st, wa.slab, p.nsplit, d.Cout, wa.ncols, d.dw, d.db);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(cdiv(count, 32)), dim3(1024), 0, st, wa.slab, n_slabs, d.Cout, wa.ncols, d.dw, d.db);
     BNERV_LAUNCH_CHECK("wgrad_finish");
     return BNERV_OK;
 }
