@@ -102,14 +102,28 @@ __device__ __forceinline__ float load_in_scalar(const bnerv_conv_desc& d, int b,
 template <int KS, int IN>
 __device__ __forceinline__ void stage_scalar(const bnerv_conv_desc& d, float* s_in, int b, int c0, int nch, int ty0, int tx0) {
     using G = Geo<KS>;
-    for (int idx = threadIdx.x; idx < nch * G::PLANE_RAW; idx += 256) {
-        const int c = idx / G::PLANE_RAW;
-        const int rem = idx - c * G::PLANE_RAW;
-        const int r = rem / G::RS, col = rem - r * G::RS;
-        const int gy = ty0 + r - G::PAD, gx = tx0 + col - G::XOFF, ci = c0 + c;
-        float v = 0.f;
-        if (ci < d.Cin && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W) v = load_in_scalar<IN>(d, b, ci, gy, gx);
-        s_in[c * G::PLANE + r * G::RS + col] = v;
+    // loads are issued in batches of 8 before the LDS stores, otherwise every element costs a full memory latency
+    const int n_el = nch * G::PLANE_RAW;
+    for (int i0 = threadIdx.x; i0 < n_el; i0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = i0 + u * 256;
+            const int c = idx / G::PLANE_RAW;
+            const int rem = idx - c * G::PLANE_RAW;
+            const int r = rem / G::RS, col = rem - r * G::RS;
+            const int gy = ty0 + r - G::PAD, gx = tx0 + col - G::XOFF, ci = c0 + c;
+            v[u] = 0.f;
+            if (idx < n_el && ci < d.Cin && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W) v[u] = load_in_scalar<IN>(d, b, ci, gy, gx);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = i0 + u * 256;
+            const int c = idx / G::PLANE_RAW;
+            const int rem = idx - c * G::PLANE_RAW;
+            const int r = rem / G::RS, col = rem - r * G::RS;
+            if (idx < n_el) s_in[c * G::PLANE + r * G::RS + col] = v[u];
+        }
     }
 }
 
@@ -198,19 +212,29 @@ struct VecStage {
 template <int KS, int NTB>
 __device__ __forceinline__ void stage_weights(const bnerv_conv_desc& d, float* s_w, int co_base, int q0, int nq, int qstride) {
     using G = Geo<KS>;
-    for (int idx = threadIdx.x; idx < G::T * nq * NTB * 64; idx += 256) {
-        const int l = idx & 63;
-        int rest = idx >> 6;
-        const int n = rest % NTB; rest /= NTB;
-        const int q = rest % nq;
-        const int tap = rest / nq;
-        const int co = co_base + n * 16 + (l & 15), ci = (q0 + q) * 4 + (l >> 4);
-        float v = 0.f;
-        if (co < d.Cout && ci < d.Cin) {
-            v = d.transposed ? d.w[((size_t)ci * d.wCi + co) * G::T + (G::T - 1 - tap)]
-                             : d.w[((size_t)co * d.wCi + ci) * G::T + tap];
+    const int n_el = G::T * nq * NTB * 64;
+    for (int i0 = threadIdx.x; i0 < n_el; i0 += 256 * 8) {   // 8 gathers in flight per thread, then the LDS stores
+        float v[8];
+        int dst[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = i0 + u * 256;
+            const int l = idx & 63;
+            int rest = idx >> 6;
+            const int n = rest % NTB; rest /= NTB;
+            const int q = rest % nq;
+            const int tap = rest / nq;
+            const int co = co_base + n * 16 + (l & 15), ci = (q0 + q) * 4 + (l >> 4);
+            v[u] = 0.f;
+            if (idx < n_el && co < d.Cout && ci < d.Cin) {
+                v[u] = d.transposed ? d.w[((size_t)ci * d.wCi + co) * G::T + (G::T - 1 - tap)]
+                                    : d.w[((size_t)co * d.wCi + ci) * G::T + tap];
+            }
+            dst[u] = ((tap * qstride + q) * NTB + n) * 64 + l;
         }
-        s_w[((tap * qstride + q) * NTB + n) * 64 + l] = v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 256 < n_el) s_w[dst[u]] = v[u];
     }
 }
 
@@ -1071,9 +1095,14 @@ int launch_one(hipStream_t st, KArgs& ka) {
 template <int KS, int IN, int EP>
 int launch_ntb(hipStream_t st, KArgs& ka) {
     const int nt = cdiv(ka.d.Cout, 16);
-    if (nt == 1) return launch_one<KS, IN, EP, 1>(st, ka);
-    if (nt == 2) return launch_one<KS, IN, EP, 2>(st, ka);
-    if (nt == 3) return launch_one<KS, IN, EP, 3>(st, ka);
+    // cout tiles per block: as many as fit (<= 4, the input tile is staged once for all of them) -- unless that leaves most of
+    // the 256 CUs idle (the low-resolution stages: a handful of spatial tiles), where more, smaller blocks cut the latency.
+    int ntb = nt < 4 ? nt : 4;
+    const int spatial = ka.d.B * ka.tiles_x * ka.tiles_y * ka.ksplit;
+    while (ntb > 1 && cdiv(nt, ntb) * spatial < 256) --ntb;
+    if (ntb == 1) return launch_one<KS, IN, EP, 1>(st, ka);
+    if (ntb == 2) return launch_one<KS, IN, EP, 2>(st, ka);
+    if (ntb == 3) return launch_one<KS, IN, EP, 3>(st, ka);
     return launch_one<KS, IN, EP, 4>(st, ka);
 }
 

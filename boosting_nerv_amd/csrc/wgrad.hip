@@ -184,27 +184,50 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 7 ? 3 : 2)) void conv_wgrad_kern
         *reinterpret_cast<float2*>(dst + 2) = float2{v[2], v[3]};
     };
     // scalar fallbacks (W % 4 != 0, or pixel-unshuffle factors 3 / 5): low-resolution layers only
+    // (scalar paths: loads are issued in batches of 8 before the LDS stores, otherwise every element costs a full memory latency)
     auto g_stage_scalar = [&](int b, int ty0, int tx0) {
-        for (int idx = tid; idx < MTW * 16 * TH * TW; idx += 256) {
-            const int cl = idx >> 8, p = idx & 255;
-            const int co = co_base + cl, gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
-            float v = 0.f;
-            if (co < Cout && gy < H && gx < W) v = load_g_scalar<GM>(d, b, co, gy, gx);
-            s_g[cl * CSG + p] = v;
+        for (int i0 = tid; i0 < MTW * 16 * TH * TW; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i0 + u * 256;
+                const int cl = idx >> 8, p = idx & 255;
+                const int co = co_base + cl, gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
+                v[u] = 0.f;
+                if (idx < MTW * 16 * TH * TW && co < Cout && gy < H && gx < W) v[u] = load_g_scalar<GM>(d, b, co, gy, gx);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i0 + u * 256;
+                if (idx < MTW * 16 * TH * TW) s_g[(idx >> 8) * CSG + (idx & 255)] = v[u];
+            }
         }
     };
     auto x_stage_scalar = [&](int b, int ty0, int tx0) {
-        for (int idx = tid; idx < npl * G::PLANE_RAW; idx += 256) {
-            const int c = idx / G::PLANE_RAW;
-            const int rem = idx - c * G::PLANE_RAW;
-            const int r = rem / G::RS, col = rem - r * G::RS;
-            const int gy = ty0 + r - G::PAD, gx = tx0 + col - G::XOFF;
-            float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                v = d.x[(((size_t)b * Cin + ci_lo + c) * H + gy) * (size_t)W + gx];
-                if constexpr (IN != BNERV_IN_PLAIN) v = xf_in<IN>(v, 1.0f + d.scale[b * Cin + ci_lo + c], d.shift[b * Cin + ci_lo + c]);
+        const int n_el = npl * G::PLANE_RAW;
+        for (int i0 = tid; i0 < n_el; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i0 + u * 256;
+                const int c = idx / G::PLANE_RAW;
+                const int rem = idx - c * G::PLANE_RAW;
+                const int r = rem / G::RS, col = rem - r * G::RS;
+                const int gy = ty0 + r - G::PAD, gx = tx0 + col - G::XOFF;
+                v[u] = 0.f;
+                if (idx < n_el && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    v[u] = d.x[(((size_t)b * Cin + ci_lo + c) * H + gy) * (size_t)W + gx];
+                    if constexpr (IN != BNERV_IN_PLAIN) v[u] = xf_in<IN>(v[u], 1.0f + d.scale[b * Cin + ci_lo + c], d.shift[b * Cin + ci_lo + c]);
+                }
             }
-            s_in[c * G::PLANE + r * G::RS + col] = v;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i0 + u * 256;
+                const int c = idx / G::PLANE_RAW;
+                const int rem = idx - c * G::PLANE_RAW;
+                const int r = rem / G::RS, col = rem - r * G::RS;
+                if (idx < n_el) s_in[c * G::PLANE + r * G::RS + col] = v[u];
+            }
         }
     };
 
@@ -233,11 +256,23 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 7 ? 3 : 2)) void conv_wgrad_kern
         } else x_stage_scalar(b, ty0, tx0);
     };
     auto stage_direct = [&](int b, int ty0, int tx0) {           // !PIPE: load + store slot by slot (registers reused)
-        if (vec_g) {
-            for (int sidx = tid; sidx < ng_slots; sidx += 256) { f32x4 a, bq; g_load(sidx, b, ty0, tx0, a, bq); g_store(sidx, a, bq); }
+        if (vec_g) {                                           // batches of 4 slots: loads first, then the LDS stores
+            for (int s0 = tid; s0 < ng_slots; s0 += 256 * 4) {
+                f32x4 a[4], bq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g_load(s0 + u * 256, b, ty0, tx0, a[u], bq[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g_store(s0 + u * 256, a[u], bq[u]);
+            }
         } else g_stage_scalar(b, ty0, tx0);
         if (vec_x) {
-            for (int sidx = tid; sidx < nx_slots; sidx += 256) { f32x4 v; x_load(sidx, b, ty0, tx0, v); x_store(sidx, b, ty0, tx0, v); }
+            for (int s0 = tid; s0 < nx_slots; s0 += 256 * 4) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x_load(s0 + u * 256, b, ty0, tx0, v[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x_store(s0 + u * 256, b, ty0, tx0, v[u]);
+            }
         } else x_stage_scalar(b, ty0, tx0);
     };
 
@@ -625,8 +660,7 @@ static bool wlean_ok(const WArgs& wa) {
 
 static int wlean_blocks(const bnerv_wgrad_desc& d) {
     const int total_tiles = d.B * cdiv(d.H, TH) * cdiv(d.W, TW);
-    int want = (total_tiles + 3) / 4;                     // >= ~4 tiles per block keeps the per-block fixed cost amortised
-    if (want < 1) want = 1;
+    const int want = total_tiles < 1 ? 1 : total_tiles;   // fill the machine first: small layers are latency-bound
     const int target = 256 * (d.k == 3 ? 3 : 4);
     return want < target ? want : target;
 }
@@ -680,8 +714,10 @@ Plan make_plan(int B, int Cin, int Cout, int H, int W, int k) {
     const int per_cu = (p.mtw * p.ntw <= 7) ? 3 : 2;
     int target = (256 * per_cu) / groups;
     if (target < 1) target = 1;
-    // at least ~4 tiles per block: per-block fixed cost (constant planes, wave reduction, one slab) must stay amortised
-    int want = (total_tiles + 3) / 4;
+    // fill the machine first (one tile per block until every slot is taken): the small layers are latency-bound, and the
+    // per-block fixed cost (constant planes, wave reduction, one slab) is only a few microseconds
+    // (beyond that, ~4 tiles per block amortise the fixed cost better than more, shorter blocks)
+    int want = total_tiles <= target ? total_tiles : (total_tiles + 3) / 4;
     if (want < 1) want = 1;
     p.nsplit = want < target ? want : target;
     return p;

@@ -77,6 +77,34 @@ du = rnd(B, 30, 45, 80)
 dx = torch.empty(B, Ci, H, W, device=dev)
 t = timeit(lambda: ops._conv(du, w, None, dx, B=B, Cin=Co, Cout=Ci, H=H, W=W, k=3, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=5, transposed=1))
 rows.append(("dgrad stage0 750->30 (unshuffle5) @9x16", t, 2.0 * Ci * Co * 9 * H * W / t / 1e6))
+# low-resolution stages of C1: latency-bound (tiny grids)
+for (B, Ci, Co, H, W, s_) in ((1, 30, 750, 9, 16, 5), (1, 30, 60, 45, 80, 2), (1, 15, 48, 90, 160, 2)):
+    x = rnd(B, Ci, H, W); w = rnd(Co, Ci, 3, 3) / 10; b = rnd(Co)
+    Cf = Co // (s_ * s_)
+    out, out2 = torch.empty(B, Cf, s_ * H, s_ * W, device=dev), torch.empty(B, Cf, s_ * H, s_ * W, device=dev)
+    du = rnd(B, Cf, s_ * H, s_ * W); dx = torch.empty_like(x); dw, db = torch.empty_like(w), torch.empty_like(b)
+    fl = 2.0 * Ci * Co * 9 * H * W
+    for name, fn in {
+        f"fwd upconv {Ci}->{Co} +PS{s_}+sin": lambda: ops._conv(x, w, b, out, B=B, Cin=Ci, Cout=Co, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_SIN, out_s=s_, out2=out2),
+        f"dgrad upconv {Co}->{Ci} (unshuffle{s_})": lambda: ops._conv(du, w, None, dx, B=B, Cin=Co, Cout=Ci, H=H, W=W, k=3, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s_, transposed=1),
+        f"wgrad upconv {Ci}->{Co} (unshuffle{s_})": lambda: ops._wgrad(x, du, dw, db, B=B, Cin=Ci, Cout=Co, H=H, W=W, k=3, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s_),
+    }.items():
+        t = timeit(fn)
+        rows.append((f"{name} @{H}x{W}", t, fl / t / 1e6))
+for (C, H, W) in ((30, 45, 80), (15, 90, 160)):
+    B = 1
+    x, y0, v, g = rnd(B, C, H, W), rnd(B, C, H, W), rnd(B, C, H, W), rnd(B, C, H, W)
+    w = rnd(C, C, 3, 3) / 10; b = rnd(C); sc, sh = rnd(B, C) * 0.1, rnd(B, C) * 0.1
+    out = torch.empty_like(x); dw, db = torch.empty_like(w), torch.empty_like(b)
+    part = torch.empty(L.load().bnerv_conv_tiles(H, W), B, 2, C, device=dev)
+    fl = 2.0 * C * C * 9 * H * W
+    for name, fn in {
+        "fwd affine->bias": lambda: ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS, scale=sc, shift=sh),
+        "dgrad ->dgelu": lambda: ops._conv(g, w, None, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU, transposed=1, aux0=v, scale=sc, partial=part),
+        "wgrad gelu-affine": lambda: ops._wgrad(x, g, dw, db, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_GELU_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=sc, shift=sh),
+    }.items():
+        t = timeit(fn)
+        rows.append((f"{name} {C}->{C} @{H}x{W}", t, fl / t / 1e6))
 print(f"{'kernel':58s} {'us':>9s} {'TFLOP/s':>9s}")
 for n, t, tf in rows:
     print(f"{n:58s} {t:9.1f} {tf:9.2f}")
