@@ -89,8 +89,18 @@ def dominant_kernel_roofline(dev, reps=30):
     flops = 2.0 * Cc * Cc * 9 * H * W
     nbytes = (2 * Cc * H * W + Cc * Cc * 9) * 4.0
     ach = flops / t / 1e12
-    return {"kernel": "conv_igemm_kernel<3,IN_AFFINE,EP_BIAS,1> 12->12 3x3 @720x1280", "bound": "mfma", "achieved": round(ach, 2),
-            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+    # HBM bytes per launch: PMC figure of the same kernel and shape, collected with rocprofv3 --pmc in separate passes and
+    # committed with its summary (bench.py cannot run under the counter collector itself); None if the file is absent.
+    traffic, traffic_src = None, None
+    try:
+        import json as _json
+        tj = _json.load(open(os.path.join(ROOT, "profiles", "r01_c_traffic.json")))
+        traffic, traffic_src = float(tj["hbm_bytes_per_launch"]), tj["source"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"kernel": "conv_lean_kernel<3,IN_AFFINE,EP_BIAS,NQ=3> 12->12 3x3 @720x1280", "bound": "mfma", "achieved": round(ach, 2),
+            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
             "avg_launch_us": round(t * 1e6, 2), "algorithmic_GB_per_s": round(nbytes / t / 1e9, 1), "flops_per_launch": flops,
             "bytes_per_launch": nbytes}
 
