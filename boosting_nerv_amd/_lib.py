@@ -42,7 +42,7 @@ class WgradDesc(C.Structure):
     _fields_ = [("x", _fp), ("g", _fp), ("gaux", _fp), ("scale", _fp), ("shift", _fp), ("dw", _fp), ("db", _fp),
                 ("ws", _fp), ("ws_bytes", C.c_size_t),
                 ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("H", C.c_int), ("W", C.c_int), ("k", C.c_int),
-                ("in_mode", C.c_int), ("g_mode", C.c_int), ("g_s", C.c_int)]
+                ("in_mode", C.c_int), ("g_mode", C.c_int), ("g_s", C.c_int), ("defer_finish", C.c_int)]
 
 
 class LossDesc(C.Structure):
@@ -81,6 +81,9 @@ SYMBOLS = {
     "bnerv_sft_affine_fwd": (_I, [_V, _V, _V, _V, _V, _I, _I, _I]),
     "bnerv_sft_affine_bwd": (_I, [_V, _V, _V, _V, _V, _V, _I, _I, _I]),
     "bnerv_reduce_slabs": (_I, [_V, _V, _I, _I, _V]),
+    "bnerv_reduce_slabs_deferred": (_I, [_V, _I, _I, _V]),
+    "bnerv_flush_deferred": (_I, [_V]),
+    "bnerv_deferred_pending": (_I, []),
     "bnerv_conv_tiles": (_I, [_I, _I]),
     "bnerv_conv_igemm": (_I, [_V, C.POINTER(ConvDesc)]),
     "bnerv_conv_splitk_ws_bytes": (_Z, [C.POINTER(ConvDesc)]),

@@ -19,6 +19,7 @@
 // of tile t and written to LDS after it, so HBM/L2 latency hides under the matrix pipe.
 // Each wave owns 2 rows x 32 px = 4 M-tiles; acc[4][NTB] (f32x4) stays in registers for the whole K loop.
 #include "common.h"
+#include "sidejob.h"
 
 namespace {
 
@@ -705,7 +706,7 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 struct LItem { int b, ty, tx; };
 
 template <int KS, int IN, int EP, int NQ1>
-__global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(const KArgs ka) {
+__global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(const KArgs ka, const SidePack side) {
     using G = Geo<KS>;
     constexpr int NCH = NQ1 * 4;
     constexpr int NSLOT = NCH * G::ROWS * G::SEGS;
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
     const int per = ka.total_items >> 3, extra = ka.total_items & 7;
     const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
     int itx = r0 + lb;
-    if (itx >= r1) return;
+    if (itx >= r1) { side_run_hosted(side, smem); return; }
     const int step_q = nlb / tiles_x, step_r = nlb - step_q * tiles_x;
     LItem it;
     {
@@ -1018,6 +1019,7 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
         lds_barrier();
         flush_partials(prev);
     }
+    side_run_hosted(side, smem);                           // queued slab reductions, least-loaded blocks first (sidejob.h)
 }
 
 constexpr size_t LEAN_MAX_BYTES = 0x7ff00000;            // every tensor view must stay below the OOB marker offset
@@ -1042,7 +1044,9 @@ int launch_lean(hipStream_t st, KArgs& ka) {
     }
     int grid = 256 * blocks_per_cu;                       // everything resident: the static item partition is then balanced
     if (grid > ka.total_items) grid = ka.total_items;
-    hipLaunchKernelGGL((conv_lean_kernel<KS, IN, EP, NQ1>), dim3(grid), dim3(256), lds, st, ka);
+    SidePack side;
+    bnerv_side_take(&side);
+    hipLaunchKernelGGL((conv_lean_kernel<KS, IN, EP, NQ1>), dim3(grid), dim3(256), lds, st, ka, side);
     BNERV_LAUNCH_CHECK("conv_lean");
     return BNERV_OK;
 }

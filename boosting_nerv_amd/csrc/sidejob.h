@@ -1,0 +1,86 @@
+// sidejob.h -- deferred slab reductions ("side jobs").
+//
+// Measured on MI355X (tools/kconc.py): a tiny dependent kernel between two big ones costs ~10 us of pipeline (drain, launch,
+// ramp), far more than its own work, and parallel graph branches do not overlap here.  The ~45 slab reductions of a train
+// step (weight-gradient slabs -> dw/db; per-tile epilogue sums -> [B][2][C]) are therefore not launched: they are QUEUED, and
+// the next lean conv / weight-gradient launch executes them as slices at the END of its blocks, least-loaded blocks first
+// (with a static tile partition about half of the blocks own one tile less and would idle at the tail).  bnerv_flush_deferred
+// runs whatever is still queued in one standalone launch; every consumer-side entry point of the library flushes first.
+//
+// One job:  out[i] = sum_{k < n_slabs} src[k * count + i]   (fixed order: `lanes` interleaved partial sums, then a sequential
+// combine -- deterministic and independent of who executes the slice).  ncols > 0 selects the weight-gradient output split:
+// element i = co * ncols + n goes to out[co * (ncols - 1) + n] for n < ncols - 1 and to out2[co] for the bias column.
+#pragma once
+#include "common.h"
+
+constexpr int SIDE_MAX_JOBS = 4;
+
+struct SideJob {
+    const float* src;
+    float* out;
+    float* out2;
+    int n_slabs, count, ncols;
+    int epb;        // consecutive elements per slice (power of two <= 256); lanes = 256 / epb
+    int slices;     // ceil(count / epb)
+};
+
+struct SidePack {
+    SideJob j[SIDE_MAX_JOBS];
+    int n_jobs, n_slices;
+};
+
+// host side (abi.hip)
+void bnerv_side_push(const void* src, int n_slabs, int count, int ncols, float* out, float* out2);
+void bnerv_side_take(SidePack* sp);                      // moves up to SIDE_MAX_JOBS queued jobs into *sp (n_jobs = 0 if none)
+int bnerv_side_flush(hipStream_t st);                    // standalone launch(es) for everything still queued
+int bnerv_side_pending();
+
+// one slice (256 threads, `red` = 256 floats of LDS the caller no longer needs; caller guarantees a barrier before)
+__device__ __forceinline__ void side_slice(const SidePack& sp, int s, float* red) {
+    int j = 0;
+    while (j < sp.n_jobs - 1 && s >= sp.j[j].slices) { s -= sp.j[j].slices; ++j; }
+    const SideJob& job = sp.j[j];
+    const int epb = job.epb, lanes = 256 / epb;
+    const int e = threadIdx.x % epb, lane = threadIdx.x / epb;
+    const int i = s * epb + e;
+    // 16 loads in flight per thread (one memory latency per 16 slabs), combined in a fixed tree
+    float acc = 0.f;
+    if (i < job.count) {
+        const float* p = job.src + i;
+        const size_t cnt = (size_t)job.count;
+        for (int k0 = lane; k0 < job.n_slabs; k0 += 16 * lanes) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + u * lanes;
+                v[u] = k < job.n_slabs ? p[(size_t)k * cnt] : 0.f;
+            }
+#pragma unroll
+            for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+                for (int u = 0; u < w; ++u) v[u] += v[u + w];
+            acc += v[0];
+        }
+    }
+    red[lane * epb + e] = acc;
+    __syncthreads();
+    if (lane == 0 && i < job.count) {
+        float t = 0.f;
+        for (int l = 0; l < lanes; ++l) t += red[l * epb + e];
+        if (job.ncols > 0) {
+            const int co = i / job.ncols, n = i - co * job.ncols;
+            if (n < job.ncols - 1) job.out[(size_t)co * (job.ncols - 1) + n] = t;
+            else if (job.out2) job.out2[co] = t;
+        } else {
+            job.out[i] = t;
+        }
+    }
+    __syncthreads();
+}
+
+// the slices a hosting block executes: blocks are ranked from the END of the grid (they own the fewest tiles)
+__device__ __forceinline__ void side_run_hosted(const SidePack& sp, float* red) {
+    if (sp.n_slices == 0) return;
+    __syncthreads();
+    for (int s = (int)(gridDim.x - 1 - blockIdx.x); s < sp.n_slices; s += (int)gridDim.x) side_slice(sp, s, red);
+}

@@ -16,6 +16,7 @@
 // Staging is float4 from global; for the single-cout-tile shapes (all the 12-channel layers) the loads of tile t+1 are issued
 // before the MFMA phase of tile t and committed to LDS after it.
 #include "common.h"
+#include "sidejob.h"
 
 namespace {
 
@@ -387,7 +388,7 @@ struct LTile { int b, ty, tx; };
 
 // GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient (two float4 per channel PAIR), 2 = tanh-grad (g, gaux)
 template <int KS, int IN, int GM2>
-__global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(const WArgs wa, const int n_grows /* s_g rows kept */) {
+__global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(const WArgs wa, const int n_grows /* s_g rows kept */, const SidePack side) {
     using G = Geo<KS>;
     constexpr int NTW = (KS == 3) ? 7 : 1;
     constexpr int NPLL = (KS == 3) ? 12 : 15;                                // data planes (input channels) of this kernel
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(cons
         if (row < Cout && col < wa.ncols)
             slab[(size_t)row * wa.ncols + col] = (s_red[idx] + s_red[RSZ + idx]) + (s_red[2 * RSZ + idx] + s_red[3 * RSZ + idx]);
     }
-    (void)n_grows;
+    side_run_hosted(side, smem);                           // queued slab reductions of EARLIER launches (sidejob.h)
 }
 
 constexpr size_t WLEAN_MAX_BYTES = 0x7ff00000;
@@ -676,7 +677,9 @@ int launch_wlean(hipStream_t st, const WArgs& wa) {
     const size_t lds_main = (size_t)(NPLL + 2) * G::PLANE + (size_t)(NXS * 256 - NXSLOT) * 4 + (size_t)n_grows * CSG + 64;
     const size_t lds_red = (size_t)4 * 16 * NTW * 16;
     const size_t lds = (lds_main > lds_red ? lds_main : lds_red) * sizeof(float);
-    hipLaunchKernelGGL((wgrad_lean_kernel<KS, IN, GM2>), dim3(wlean_blocks(wa.d)), dim3(256), lds, st, wa, n_grows);
+    SidePack side;
+    bnerv_side_take(&side);
+    hipLaunchKernelGGL((wgrad_lean_kernel<KS, IN, GM2>), dim3(wlean_blocks(wa.d)), dim3(256), lds, st, wa, n_grows, side);
     BNERV_LAUNCH_CHECK("wgrad_lean");
     return BNERV_OK;
 }
@@ -808,6 +811,10 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
     if (rc == -1) rc = d.k == 1 ? launch_modes<1>(st, wa, p) : launch_modes<3>(st, wa, p);
     if (rc != BNERV_OK) return rc;
     const int count = d.Cout * wa.ncols;
+    if (d.defer_finish) {                                  // (queued AFTER the launch: this launch may host older jobs, never its own)
+        bnerv_side_push(wa.slab, n_slabs, count, wa.ncols, d.dw, d.db);
+        return BNERV_OK;
+    }
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3(cdiv(count, 32)), dim3(1024), 0, st, wa.slab, n_slabs, d.Cout, wa.ncols, d.dw, d.db);
     BNERV_LAUNCH_CHECK("wgrad_finish");
     return BNERV_OK;

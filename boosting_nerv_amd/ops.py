@@ -27,7 +27,7 @@ def _ws(nbytes, device):
 # raw kernel wrappers
 # ----------------------------------------------------------------------------------------------------------------------
 def _conv(x, w, bias, out, *, B, Cin, Cout, H, W, k, in_mode, ep_mode, in_s=1, out_s=1, transposed=0, out2=None,
-          aux0=None, aux1=None, aux2=None, scale=None, shift=None, partial=None):
+          aux0=None, aux1=None, aux2=None, scale=None, shift=None, partial=None, defer=False):
     d = L.ConvDesc(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(out), L.ptr(out2), L.ptr(aux0), L.ptr(aux1), L.ptr(aux2),
                    L.ptr(scale), L.ptr(shift), L.ptr(partial), B, Cin, Cout, H, W, k, in_mode, ep_mode, in_s, out_s,
                    transposed, w.shape[0], w.shape[1])
@@ -40,7 +40,7 @@ def _conv(x, w, bias, out, *, B, Cin, Cout, H, W, k, in_mode, ep_mode, in_s=1, o
         d.partial = part.data_ptr()
         L.check(lib.bnerv_conv_igemm(L.stream(), C.byref(d)), "bnerv_conv_igemm")
         st = torch.empty(B, 2, Cout, dtype=torch.float32, device=x.device)
-        _reduce_slabs(part, rows, B * 2 * Cout, st)
+        _reduce_slabs(part, rows, B * 2 * Cout, st, defer=defer)
         return st
     if ep_mode == L.EP_PLAIN and partial is None:
         nbytes = lib.bnerv_conv_splitk_ws_bytes(C.byref(d))      # low-resolution, long-K layers want a split-K workspace
@@ -50,17 +50,34 @@ def _conv(x, w, bias, out, *, B, Cin, Cout, H, W, k, in_mode, ep_mode, in_s=1, o
     L.check(lib.bnerv_conv_igemm(L.stream(), C.byref(d)), "bnerv_conv_igemm")
 
 
-def _wgrad(x, g, dw, db, *, B, Cin, Cout, H, W, k, in_mode, g_mode, g_s=1, gaux=None, scale=None, shift=None):
+def _wgrad(x, g, dw, db, *, B, Cin, Cout, H, W, k, in_mode, g_mode, g_s=1, gaux=None, scale=None, shift=None, defer=False):
     lib = L.load()
     nbytes = lib.bnerv_conv_wgrad_ws_bytes(B, Cin, Cout, H, W, k)
     ws = _ws(nbytes, x.device)
     d = L.WgradDesc(L.ptr(x), L.ptr(g), L.ptr(gaux), L.ptr(scale), L.ptr(shift), L.ptr(dw), L.ptr(db), L.ptr(ws), nbytes,
-                    B, Cin, Cout, H, W, k, in_mode, g_mode, g_s)
+                    B, Cin, Cout, H, W, k, in_mode, g_mode, g_s, 1 if defer else 0)
     L.check(lib.bnerv_conv_wgrad(L.stream(), C.byref(d)), "bnerv_conv_wgrad")
+    if defer:
+        _deferred_keep.append(ws)
 
 
-def _reduce_slabs(slabs, n_slabs, count, out):
+# Deferred slab reductions (include/bnerv.h, bnerv_reduce_slabs_deferred): inside one backward the reductions are queued and
+# ride on the next lean conv / weight-gradient launch; _flush_deferred() at the end of the backward launches the leftovers, so
+# every tensor a backward returns is complete on the stream.  The workspaces of queued jobs are kept alive until then.
+_deferred_keep = []
+
+
+def _reduce_slabs(slabs, n_slabs, count, out, defer=False):
+    if defer:
+        L.check(L.load().bnerv_reduce_slabs_deferred(L.ptr(slabs), n_slabs, count, L.ptr(out)), "bnerv_reduce_slabs_deferred")
+        _deferred_keep.append(slabs)
+        return
     L.check(L.load().bnerv_reduce_slabs(L.stream(), L.ptr(slabs), n_slabs, count, L.ptr(out)), "bnerv_reduce_slabs")
+
+
+def _flush_deferred():
+    L.check(L.load().bnerv_flush_deferred(L.stream()), "bnerv_flush_deferred")
+    _deferred_keep.clear()
 
 
 def _tiles(H, W):
@@ -222,11 +239,12 @@ class _Conv2dPS(torch.autograd.Function):
         Cout, k = w.shape[0], w.shape[-1]
         dw = torch.empty_like(w)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_b else None
-        _wgrad(x, g, dw, db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s)
+        _wgrad(x, g, dw, db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s, defer=True)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _conv(g, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1)
+        _flush_deferred()
         return dx, dw, db, None
 
 
@@ -253,15 +271,18 @@ def _tat_backward(dout, y0, c0, v, s0, t0, s1, t1, w0, w1):
     B, Cc, H, W = y0.shape
     dev = y0.device
     dw1 = torch.empty_like(w1); db1 = torch.empty(Cc, dtype=torch.float32, device=dev)
-    _wgrad(v, dout, dw1, db1, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_GELU_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s1, shift=t1)
+    # every slab reduction below is deferred: it rides on the next launch of this chain; the CALLER flushes the leftovers
+    _wgrad(v, dout, dw1, db1, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_GELU_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s1, shift=t1,
+           defer=True)
     dv = torch.empty_like(y0)
     st1 = _conv(dout, w1, None, dv, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU, transposed=1,
-                aux0=v, scale=s1)
+                aux0=v, scale=s1, defer=True)
     dw0 = torch.empty_like(w0); db0 = torch.empty(Cc, dtype=torch.float32, device=dev)
-    _wgrad(y0, dv, dw0, db0, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s0, shift=t0)
+    _wgrad(y0, dv, dw0, db0, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s0, shift=t0,
+           defer=True)
     du = torch.empty_like(y0)
     st0 = _conv(dv, w0, None, du, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN, transposed=1,
-                aux0=y0, aux1=dout, aux2=c0, scale=s0)
+                aux0=y0, aux1=dout, aux2=c0, scale=s0, defer=True)
     return du, st0[:, 0], st0[:, 1], st1[:, 0], st1[:, 1], dw0, db0, dw1, db1
 
 
@@ -281,6 +302,7 @@ class _TATBlock(torch.autograd.Function):
     def backward(ctx, dout):
         x0, v, s0, t0, s1, t1, w0, w1 = ctx.saved_tensors
         dx0, ds0, dt0, ds1, dt1, dw0, db0, dw1, db1 = _tat_backward(L.f32c(dout), x0, None, v, s0, t0, s1, t1, w0, w1)
+        _flush_deferred()
         m = ctx.mshape
         return dx0, ds0.reshape(m), dt0.reshape(m), ds1.reshape(m), dt1.reshape(m), dw0, db0, dw1, db1
 
@@ -318,11 +340,12 @@ class _SNeRVBlock(torch.autograd.Function):
         Ct, k = wu.shape[0], wu.shape[-1]
         dwu = torch.empty_like(wu)
         dbu = torch.empty(Ct, dtype=torch.float32, device=x.device) if ctx.has_bu else None
-        _wgrad(x, du, dwu, dbu, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s)
+        _wgrad(x, du, dwu, dbu, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s, defer=True)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _conv(du, wu, None, dx, B=B, Cin=Ct, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1)
+        _flush_deferred()
         m = ctx.mshape
         return dx, dwu, dbu, ds0.reshape(m), dt0.reshape(m), ds1.reshape(m), dt1.reshape(m), dw0, db0, dw1, db1, None
 
@@ -389,11 +412,12 @@ class _HeadTanh(torch.autograd.Function):
         Cout, k = w.shape[0], w.shape[-1]
         dw = torch.empty_like(w)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_b else None
-        _wgrad(x, g, dw, db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_TANHGRAD, gaux=img)
+        _wgrad(x, g, dw, db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_TANHGRAD, gaux=img, defer=True)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _conv(g, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_TANHGRAD, ep_mode=L.EP_PLAIN, transposed=1, aux0=img)
+        _flush_deferred()
         return dx, dw, db
 
 

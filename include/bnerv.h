@@ -97,6 +97,16 @@ int bnerv_sft_affine_bwd(void* stream, const float* x, const float* scale, const
 /* out[i] = sum_{s<n_slabs} slabs[s*count + i]   (deterministic finish of every split reduction in this library) */
 int bnerv_reduce_slabs(void* stream, const float* slabs, int n_slabs, int count, float* out);
 
+/* Deferred form of the same reduction.  On MI355X a tiny dependent kernel between two big ones costs ~10 us of pipeline,
+ * so the ~45 slab reductions of a train step are queued instead of launched: the next bnerv_conv_igemm / bnerv_conv_wgrad
+ * launch whose kernel can host them executes the queued reductions at the end of its least-loaded blocks (same fixed
+ * summation order whoever executes them).  `slabs` and `out` must stay valid, and `out` must not be read, until a hosting
+ * launch or bnerv_flush_deferred() has been issued on the stream; bnerv_flush_deferred launches whatever is still queued
+ * (a no-op when the queue is empty).  One queue per process, used from the thread that launches the kernels. */
+int bnerv_reduce_slabs_deferred(const float* slabs, int n_slabs, int count, float* out);
+int bnerv_flush_deferred(void* stream);
+int bnerv_deferred_pending(void);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution (fp32 MFMA 16x16x4), stride 1, square kernel k in {1,3}, zero padding (k-1)/2, with fused
  * input prologue and output epilogue.  One kernel family serves the forward conv and the data gradient.
@@ -175,6 +185,7 @@ typedef struct {
     int in_mode;          /* prologue on x */
     int g_mode;           /* BNERV_IN_PLAIN / BNERV_IN_UNSHUFFLE / BNERV_IN_TANHGRAD */
     int g_s;
+    int defer_finish;     /* 1: queue the slab reduction into dw/db (see bnerv_reduce_slabs_deferred) instead of launching it */
 } bnerv_wgrad_desc;
 
 size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int k);
