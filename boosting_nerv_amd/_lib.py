@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libbnerv_hip.so")
 MAX_DENSE_GROUPS = 40
 ADAN_MAX_TENSORS = 48
 SFT_CHUNKS = 32
+LOSS_STATS = 5
 DENSE_DX_CHUNK = 64
 
 ACT_NONE, ACT_RELU, ACT_SIN = 0, 1, 2

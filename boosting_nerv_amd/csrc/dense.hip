@@ -103,11 +103,15 @@ __global__ __launch_bounds__(256) void dense_bwd_x_kernel(const BwdArgs a) {
     const int o1 = min(o0 + BNERV_DENSE_DX_CHUNK, g.O);
     const int b = blockIdx.y;
     __shared__ float s_dp[BNERV_DENSE_DX_CHUNK];
-    if ((int)threadIdx.x < o1 - o0) s_dp[threadIdx.x] = g.dpre[(size_t)b * g.O + o0 + threadIdx.x];
+    if ((int)threadIdx.x < BNERV_DENSE_DX_CHUNK) s_dp[threadIdx.x] = (int)threadIdx.x < o1 - o0 ? g.dpre[(size_t)b * g.O + o0 + threadIdx.x] : 0.f;
     __syncthreads();
     for (int i = threadIdx.x; i < g.I; i += 256) {
+        float wv[BNERV_DENSE_DX_CHUNK];                    // all rows of the chunk in flight, then the (fixed-order) dot product
+#pragma unroll
+        for (int r = 0; r < BNERV_DENSE_DX_CHUNK; ++r) wv[r] = o0 + r < o1 ? g.w[(size_t)(o0 + r) * g.I + i] : 0.f;
         float s = 0.f;
-        for (int o = o0; o < o1; ++o) s = fmaf(s_dp[o - o0], g.w[(size_t)o * g.I + i], s);
+#pragma unroll
+        for (int r = 0; r < BNERV_DENSE_DX_CHUNK; ++r) s = fmaf(s_dp[r], wv[r], s);
         g.dx_part[((size_t)chunk * ap->B + b) * g.I + i] = s;
     }
 }

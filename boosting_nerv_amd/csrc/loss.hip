@@ -572,7 +572,11 @@ __global__ __launch_bounds__(64) void loss_final_kernel(const FinalArgs a) {
             l += (double)a.c_fft * f / (2.0 * (double)a.n_per_sample);
         }
         if (lane == 0) {
-            a.stats_out[b * 4 + 0] = (float)l; a.stats_out[b * 4 + 1] = (float)s1; a.stats_out[b * 4 + 2] = (float)s2; a.stats_out[b * 4 + 3] = (float)ms;
+            float* so = a.stats_out + b * BNERV_LOSS_STATS;
+            so[0] = (float)l; so[1] = (float)s1; so[2] = (float)s2; so[3] = (float)ms;
+            // psnr_fn_single (hnerv_utils.py:400-403) on the same sums, exactly as psnr_final_kernel computes it
+            const float mse = (float)(s2 / (double)a.n_per_sample);
+            so[4] = -10.0f * log10f(mse + 1e-9f);
         }
         total += l;
     }

@@ -9,7 +9,8 @@ Everything that changes per step and is not data (lr, Adan bias corrections) liv
 Adan.prepare_step(), so the captured kernels never see a stale scalar."""
 import torch
 
-from . import hnerv_utils as hu
+from . import hnerv_utils as hu  # noqa: F401
+from . import ops
 from .dp import GradBucket
 
 
@@ -39,10 +40,12 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         inp = self.static_img if self.takes_image else self.static_idx
         img_out, _, _ = self.model(inp, norm_idx=self.static_idx)
-        loss = hu.loss_fn(img_out, self.static_img, self.loss_type)
-        loss.backward()
-        self.loss_out = loss.detach()
-        self.psnr_out = hu.psnr_fn_device(img_out.detach(), self.static_img)
+        # loss_fn(...).backward() + psnr_fn_single(...) of train_nerv_all.py:337-347 as ONE fused launch sequence: the loss
+        # gradient seeds backward directly and the per-sample PSNR comes from the same L2 sums (stats[:, 4])
+        loss, stats, grad = ops.loss_value_grad_stats(img_out, self.static_img, self.loss_type)
+        img_out.backward(grad)
+        self.loss_out = loss
+        self.psnr_out = stats[:, 4]
 
     def _eager(self):
         self._fwd_bwd()

@@ -449,23 +449,37 @@ def prepare_loss(H, W):
         _fft_ready.add((H, W))
 
 
+def _loss_launch(pred, target, coeffs, need_grad):
+    """One fused call: loss value, per-sample stats and (optionally) d loss / d pred."""
+    pred = L.f32c(L.require_device(pred, "pred")); target = L.f32c(target.detach())
+    B, Cc, H, W = pred.shape
+    c1, c2, cm, cf = coeffs
+    lib = L.load()
+    if cf:
+        prepare_loss(H, W)
+    nbytes = lib.bnerv_loss_ws_bytes(B, Cc, H, W, int(cm != 0), int(cf != 0))
+    ws = _ws(nbytes, pred.device)
+    grad = torch.empty_like(pred) if need_grad else None
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    stats = torch.empty(B, L.LOSS_STATS, dtype=torch.float32, device=pred.device)
+    d = L.LossDesc(L.ptr(pred), L.ptr(target), L.ptr(grad), L.ptr(loss), L.ptr(stats), L.ptr(ws), nbytes, B, Cc, H, W, c1, c2, cm, cf)
+    L.check(lib.bnerv_loss_fwd_bwd(L.stream(), C.byref(d)), "bnerv_loss_fwd_bwd")
+    return loss, stats, grad
+
+
+def loss_value_grad_stats(pred, target, loss_type="Fusion10_freq"):
+    """(loss [scalar], stats [B,5], d loss/d pred) without an autograd node: the train step seeds pred.backward(grad) with
+    the gradient directly (no ones-fill, no grad * 1 pass over the frame) and reads the per-sample PSNR from stats[:, 4]."""
+    if loss_type not in LOSS_COEFFS:
+        raise NotImplementedError(f"loss type {loss_type!r} is not on the HIP path; supported: {sorted(LOSS_COEFFS)}")
+    loss, stats, grad = _loss_launch(pred.detach(), target, LOSS_COEFFS[loss_type], True)
+    return loss.reshape(()), stats, grad
+
+
 class _Loss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, coeffs):
-        pred = L.f32c(L.require_device(pred, "pred")); target = L.f32c(target.detach())
-        B, Cc, H, W = pred.shape
-        c1, c2, cm, cf = coeffs
-        lib = L.load()
-        if cf:
-            prepare_loss(H, W)
-        need_grad = ctx.needs_input_grad[0]
-        nbytes = lib.bnerv_loss_ws_bytes(B, Cc, H, W, int(cm != 0), int(cf != 0))
-        ws = _ws(nbytes, pred.device)
-        grad = torch.empty_like(pred) if need_grad else None
-        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
-        stats = torch.empty(B, 4, dtype=torch.float32, device=pred.device)
-        d = L.LossDesc(L.ptr(pred), L.ptr(target), L.ptr(grad), L.ptr(loss), L.ptr(stats), L.ptr(ws), nbytes, B, Cc, H, W, c1, c2, cm, cf)
-        L.check(lib.bnerv_loss_fwd_bwd(L.stream(), C.byref(d)), "bnerv_loss_fwd_bwd")
+        loss, stats, grad = _loss_launch(pred, target, coeffs, ctx.needs_input_grad[0])
         ctx.grad = grad
         ctx.mark_non_differentiable(stats)
         return loss.reshape(()), stats
@@ -478,7 +492,7 @@ class _Loss(torch.autograd.Function):
 
 
 def loss_with_stats(pred, target, loss_type="Fusion10_freq"):
-    """Returns (batch-mean loss [scalar tensor], stats [B,4] = {loss_b, sum|d|, sum d^2, ms_ssim_b})."""
+    """Returns (batch-mean loss [scalar tensor], stats [B,5] = {loss_b, sum|d|, sum d^2, ms_ssim_b, psnr_b})."""
     if loss_type not in LOSS_COEFFS:
         raise NotImplementedError(f"loss type {loss_type!r} is not on the HIP path; supported: {sorted(LOSS_COEFFS)}")
     return _Loss.apply(pred, target, LOSS_COEFFS[loss_type])

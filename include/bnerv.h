@@ -191,6 +191,7 @@ typedef struct {
 size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int k);
 int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* d);
 
+#define BNERV_LOSS_STATS 5
 /* ------------------------------------------------------------------------------------------------------------------
  * Loss and metrics.  Replaces loss_fn (hnerv_utils.py:335-397; variants L1, L2, L1_freq, Fusion10, Fusion10_freq)
  * including its autograd backward, and psnr_fn_single (hnerv_utils.py:400-403).
@@ -199,7 +200,7 @@ int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* d);
  *   L1: c_l1=1   L2: c_l2=1   L1_freq: c_l1=60,c_fft=1   Fusion10: c_l1=.7,c_ms=.3   Fusion10_freq: c_l1=42,c_ms=18,c_fft=1
  * MS-SSIM follows pytorch_msssim 0.2.1 (win 11, sigma 1.5, 5 levels) -- third-party, PARITY UNPINNED.
  * The 2-D DFT is a mixed-radix LDS FFT; H and W may have any prime factors <= BNERV_FFT_MAX_RADIX.
- * stats_out: [B, 4] = {loss_b, sum|d|, sum d^2, ms_ssim_b};  loss_out: [1].
+ * stats_out: [B, BNERV_LOSS_STATS] = {loss_b, sum|d|, sum d^2, ms_ssim_b, psnr_b (hnerv_utils.py:400-403)};  loss_out: [1].
  * ------------------------------------------------------------------------------------------------------------------ */
 #define BNERV_FFT_MAX_RADIX 31
 #define BNERV_MSSSIM_LEVELS 5
@@ -209,7 +210,7 @@ typedef struct {
     const float* target;  /* [B, C, H, W] */
     float* grad;          /* [B, C, H, W] written (may be NULL: value only) */
     float* loss_out;      /* [1] */
-    float* stats_out;     /* [B, 4] */
+    float* stats_out;     /* [B, BNERV_LOSS_STATS] */
     void* ws;
     size_t ws_bytes;
     int B, C, H, W;

@@ -246,6 +246,9 @@ def test_loss_against_goldens_and_oracle(ops, lt, tag):
     ggrad, = torch.autograd.grad(loss, [pg])
     close(ggrad, rgrad, rtol=2e-3, atol=2e-3 * float(rgrad.abs().max()), msg=f"{lt} grad")
     close(ops.psnr(pg, tgt.to(DEV)), cpu_ref.psnr_fn_single(pred, tgt), rtol=1e-5, atol=1e-3, msg="psnr")
+    # the train step's fused form: same value, same gradient, PSNR from the same L2 sums
+    l2, st2, g2 = ops.loss_value_grad_stats(pg, tgt.to(DEV), lt)
+    assert l2.item() == loss.item() and torch.equal(g2, ggrad) and torch.equal(st2[:, 4], ops.psnr(pg, tgt.to(DEV)))
     if "Fusion" in lt:
         close(ops.msssim(pg, tgt.to(DEV)), msssim_ref.ms_ssim(pred.detach(), tgt, data_range=1, size_average=False), rtol=1e-4, atol=1e-5, msg="msssim")
 
