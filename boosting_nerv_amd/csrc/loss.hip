@@ -138,6 +138,9 @@ struct SsimArgs {
     const float* coef;         // bwd: [BC] for this level (already includes 1/Nvalid and the loss chain)
     const float* dcoarse;      // bwd: [BC][Hc][Wc] gradient wrt the next (coarser) level's pooled image, or NULL
     float* dX;                 // bwd: [BC][H][W] written
+    float* G;                  // fwd writes / bwd reads: [3][BC][H][W] UNSCALED statistic gradients (d mu1-ish, d E[xx], d E[xy]) at
+                               // the valid window positions; NULL = value only.  The chain coefficient (known only after every
+                               // level's forward) multiplies the backward linearly, so it is applied after the adjoint filter.
     int H, W, Hc, Wc, ph, pw;  // ph/pw: padding used when pooling THIS level into the coarser one
     int tiles_x, tiles_y;
     float C1, C2;
@@ -190,9 +193,22 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const SsimArgs a) {
         if (oy0 + r < Hv && ox0 + c < Wv) {
             const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
             const float s1 = exx - m11, s2 = eyy - m22, s12 = exy - m12;
-            const float cs = (2.f * s12 + a.C2) / (s1 + s2 + a.C2);
-            if (LAST) acc += ((2.f * m12 + a.C1) / (m11 + m22 + a.C1)) * cs;
+            const float B2 = s1 + s2 + a.C2;
+            const float cs = (2.f * s12 + a.C2) / B2;
+            float lum = 1.f;
+            if (LAST) { lum = (2.f * m12 + a.C1) / (m11 + m22 + a.C1); acc += lum * cs; }
             else acc += cs;
+            if (a.G) {
+                float dm = (2.f / B2) * (m1 * cs - m2), dxx = -cs / B2, dxy = 2.f / B2;
+                if (LAST) {
+                    const float B1 = m11 + m22 + a.C1;
+                    dm = (2.f / B1) * (m2 - m1 * lum) * cs + lum * dm;
+                    dxx *= lum; dxy *= lum;
+                }
+                const size_t plane = (size_t)a.H * a.W, o = (size_t)bc * plane + (size_t)(oy0 + r) * a.W + (ox0 + c);
+                const size_t mstride = (size_t)gridDim.z * plane;
+                a.G[o] = dm; a.G[mstride + o] = dxx; a.G[2 * mstride + o] = dxy;
+            }
         }
     }
     acc = wave_sum(acc);
@@ -229,85 +245,47 @@ __global__ __launch_bounds__(320) void ms_coef_kernel(const CoefArgs a) {
     }
 }
 
-// ---- backward for one level ----
-template <bool LAST, bool LEVEL0>
-__global__ __launch_bounds__(256) void ssim_bwd_kernel(const SsimArgs a) {
+// ---- backward from the stored statistic gradients: adjoint of the separable "valid" filter over the 3 maps, then
+//      dX = coef * (A0 + 2 x A1 + y A2) [+ 0.25 * d(coarser level)] [+ L1/L2 terms at level 0].  ~6x less arithmetic than
+//      recomputing the statistics on a 36x52 window per tile.
+template <bool LEVEL0>
+__global__ __launch_bounds__(256) void ssim_bwd_from_g_kernel(const SsimArgs a) {
     constexpr int GH = STH + HW_, GW = STW + HW_;        // 26 x 42 statistic-gradient region
-    constexpr int WH = GH + HW_, WW = GW + HW_;          // 36 x 52 input window
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float (*sX)[WW] = reinterpret_cast<float (*)[WW]>(sm);
-    float (*sY)[WW] = reinterpret_cast<float (*)[WW]>(sm + WH * WW);
-    float* sVb = sm + 2 * WH * WW;                       // [5][GH][WW], later reused as sA [3][STH][GW]
-    float* sGb = sVb + 5 * GH * WW;                      // [3][GH][GW]
+    __shared__ float sG[3][GH][GW];
+    __shared__ float sA[3][STH][GW];
     const int tid = threadIdx.x, bc = blockIdx.z;
     const int py0 = blockIdx.y * STH, px0 = blockIdx.x * STW;
     const int wy0 = py0 - HW_, wx0 = px0 - HW_;
-    const float* X = a.X + (size_t)bc * a.H * a.W;
-    const float* Y = a.Y + (size_t)bc * a.H * a.W;
-    for (int i = tid; i < WH * WW; i += 256) {
-        const int r = i / WW, c = i - r * WW;
-        const int y = wy0 + r, x = wx0 + c;
-        const bool in = y >= 0 && y < a.H && x >= 0 && x < a.W;
-        sX[r][c] = in ? X[(size_t)y * a.W + x] : 0.f;
-        sY[r][c] = in ? Y[(size_t)y * a.W + x] : 0.f;
-    }
-    __syncthreads();
-    for (int i = tid; i < GH * WW; i += 256) {
-        const int r = i / WW, c = i - r * WW;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
-#pragma unroll
-        for (int k = 0; k < WS_; ++k) {
-            const float g = a.win.g[k], x = sX[r + k][c], y = sY[r + k][c];
-            v0 = fmaf(g, x, v0); v1 = fmaf(g, y, v1); v2 = fmaf(g, x * x, v2); v3 = fmaf(g, y * y, v3); v4 = fmaf(g, x * y, v4);
-        }
-        sVb[(0 * GH + r) * WW + c] = v0; sVb[(1 * GH + r) * WW + c] = v1; sVb[(2 * GH + r) * WW + c] = v2;
-        sVb[(3 * GH + r) * WW + c] = v3; sVb[(4 * GH + r) * WW + c] = v4;
-    }
-    __syncthreads();
     const int Hv = a.H - HW_, Wv = a.W - HW_;
-    const float coef = a.coef[bc];
+    const size_t plane = (size_t)a.H * a.W, mstride = (size_t)gridDim.z * plane;
+    const float* Gp = a.G + (size_t)bc * plane;
     for (int i = tid; i < GH * GW; i += 256) {
         const int r = i / GW, c = i - r * GW;
         const int oy = wy0 + r, ox = wx0 + c;
-        float gm = 0.f, gxx = 0.f, gxy = 0.f;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
         if (oy >= 0 && oy < Hv && ox >= 0 && ox < Wv) {
-            float m1 = 0.f, m2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
-#pragma unroll
-            for (int k = 0; k < WS_; ++k) {
-                const float g = a.win.g[k];
-                m1 = fmaf(g, sVb[(0 * GH + r) * WW + c + k], m1); m2 = fmaf(g, sVb[(1 * GH + r) * WW + c + k], m2);
-                exx = fmaf(g, sVb[(2 * GH + r) * WW + c + k], exx); eyy = fmaf(g, sVb[(3 * GH + r) * WW + c + k], eyy);
-                exy = fmaf(g, sVb[(4 * GH + r) * WW + c + k], exy);
-            }
-            const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
-            const float B2 = (exx - m11) + (eyy - m22) + a.C2;
-            const float cs = (2.f * (exy - m12) + a.C2) / B2;
-            float dm = (2.f / B2) * (m1 * cs - m2), dxx = -cs / B2, dxy = 2.f / B2;
-            if (LAST) {
-                const float B1 = m11 + m22 + a.C1;
-                const float lum = (2.f * m12 + a.C1) / B1;
-                dm = (2.f / B1) * (m2 - m1 * lum) * cs + lum * dm;
-                dxx *= lum; dxy *= lum;
-            }
-            gm = coef * dm; gxx = coef * dxx; gxy = coef * dxy;
+            const size_t o = (size_t)oy * a.W + ox;
+            g0 = Gp[o]; g1 = Gp[mstride + o]; g2 = Gp[2 * mstride + o];
         }
-        sGb[(0 * GH + r) * GW + c] = gm; sGb[(1 * GH + r) * GW + c] = gxx; sGb[(2 * GH + r) * GW + c] = gxy;
+        sG[0][r][c] = g0; sG[1][r][c] = g1; sG[2][r][c] = g2;
     }
     __syncthreads();
-    float* sA = sVb;   // [3][STH][GW]
     for (int i = tid; i < STH * GW; i += 256) {
         const int r = i / GW, c = i - r * GW;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int k = 0; k < WS_; ++k) {
             const float g = a.win.g[k];
-            a0 = fmaf(g, sGb[(0 * GH + r + HW_ - k) * GW + c], a0);
-            a1 = fmaf(g, sGb[(1 * GH + r + HW_ - k) * GW + c], a1);
-            a2 = fmaf(g, sGb[(2 * GH + r + HW_ - k) * GW + c], a2);
+            a0 = fmaf(g, sG[0][r + HW_ - k][c], a0);
+            a1 = fmaf(g, sG[1][r + HW_ - k][c], a1);
+            a2 = fmaf(g, sG[2][r + HW_ - k][c], a2);
         }
-        sA[(0 * STH + r) * GW + c] = a0; sA[(1 * STH + r) * GW + c] = a1; sA[(2 * STH + r) * GW + c] = a2;
+        sA[0][r][c] = a0; sA[1][r][c] = a1; sA[2][r][c] = a2;
     }
     __syncthreads();
+    const float coef = a.coef[bc];
+    const float* X = a.X + (size_t)bc * plane;
+    const float* Y = a.Y + (size_t)bc * plane;
     for (int i = tid; i < STH * STW; i += 256) {
         const int r = i / STW, c = i - r * STW;
         const int y = py0 + r, x = px0 + c;
@@ -316,13 +294,13 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const SsimArgs a) {
 #pragma unroll
         for (int k = 0; k < WS_; ++k) {
             const float g = a.win.g[k];
-            a0 = fmaf(g, sA[(0 * STH + r) * GW + c + HW_ - k], a0);
-            a1 = fmaf(g, sA[(1 * STH + r) * GW + c + HW_ - k], a1);
-            a2 = fmaf(g, sA[(2 * STH + r) * GW + c + HW_ - k], a2);
+            a0 = fmaf(g, sA[0][r][c + HW_ - k], a0);
+            a1 = fmaf(g, sA[1][r][c + HW_ - k], a1);
+            a2 = fmaf(g, sA[2][r][c + HW_ - k], a2);
         }
-        const float xv = sX[r + HW_][c + HW_], yv = sY[r + HW_][c + HW_];
-        float d = a0 + 2.f * xv * a1 + yv * a2;
-        if (!LAST && a.dcoarse) d += 0.25f * a.dcoarse[((size_t)bc * a.Hc + (y + a.ph) / 2) * a.Wc + (x + a.pw) / 2];
+        const float xv = X[(size_t)y * a.W + x], yv = Y[(size_t)y * a.W + x];
+        float d = coef * (a0 + 2.f * xv * a1 + yv * a2);
+        if (a.dcoarse) d += 0.25f * a.dcoarse[((size_t)bc * a.Hc + (y + a.ph) / 2) * a.Wc + (x + a.pw) / 2];
         if (LEVEL0) {
             const float df = xv - yv;
             const float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
@@ -331,7 +309,6 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const SsimArgs a) {
         a.dX[((size_t)bc * a.H + y) * a.W + x] = d;
     }
 }
-constexpr size_t SSIM_BWD_LDS = (size_t)(2 * 36 * 52 + 5 * 26 * 52 + 3 * 26 * 42) * sizeof(float);
 
 // =====================================================================================================================
 // mixed-radix FFT in LDS
@@ -383,16 +360,16 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return float2{a.x 
 //  forward (DIF):  y_q = w_Ns^{jq} * sum_m x_m w_R^{mq}             x_m = buf[base+m*M], y_q -> buf[base+q*M]
 //  adjoint      :  x_m = sum_q conj(w_R^{mq}) conj(w_Ns^{jq}) y_q   (exact conjugate transpose of the forward stage)
 template <int R, bool ADJ>
-__device__ __forceinline__ void butterfly(float2* buf, int base, int M, int j, int tstride /* N/Ns */, const FftPlan& pl) {
+__device__ __forceinline__ void butterfly(float2* buf, int base, int M, int j, int tstride /* N/Ns */, const FftPlan& pl, const float2* tw) {
     float2 v[R], o[R], wr[R];
     const int rstep = pl.N / R;
 #pragma unroll
-    for (int k = 0; k < R; ++k) wr[k] = pl.tw[rstep * k];
+    for (int k = 0; k < R; ++k) wr[k] = tw[rstep * k];
 #pragma unroll
     for (int m = 0; m < R; ++m) v[m] = buf[base + m * M];
     if (ADJ) {
 #pragma unroll
-        for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], pl.tw[(int)(((long long)tstride * j * q) % pl.N)]);
+        for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], tw[tstride * j * q]);      // j < Ns/R: tstride * j * q < N, no wrap
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) {
@@ -404,7 +381,7 @@ __device__ __forceinline__ void butterfly(float2* buf, int base, int M, int j, i
     }
     if (!ADJ) {
 #pragma unroll
-        for (int q = 1; q < R; ++q) o[q] = cmul(o[q], pl.tw[(int)(((long long)tstride * j * q) % pl.N)]);
+        for (int q = 1; q < R; ++q) o[q] = cmul(o[q], tw[tstride * j * q]);
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) buf[base + q * M] = o[q];
@@ -412,51 +389,55 @@ __device__ __forceinline__ void butterfly(float2* buf, int base, int M, int j, i
 
 // generic radix (primes 7..31): O(R^2) with the table, operands staged in registers one output at a time
 template <bool ADJ>
-__device__ void butterfly_generic(float2* buf, int base, int M, int j, int tstride, int R, const FftPlan& pl) {
+__device__ void butterfly_generic(float2* buf, int base, int M, int j, int tstride, int R, const FftPlan& pl, const float2* tw) {
     float2 v[BNERV_FFT_MAX_RADIX], o[BNERV_FFT_MAX_RADIX];
     const int rstep = pl.N / R;
     for (int m = 0; m < R; ++m) {
         v[m] = buf[base + m * M];
-        if (ADJ && m) v[m] = cmulc(v[m], pl.tw[(int)(((long long)tstride * j * m) % pl.N)]);
+        if (ADJ && m) v[m] = cmulc(v[m], tw[tstride * j * m]);
     }
     for (int q = 0; q < R; ++q) {
         float2 s = v[0];
         for (int m = 1; m < R; ++m) {
-            const float2 w = pl.tw[rstep * ((m * q) % R)];
+            const float2 w = tw[rstep * ((m * q) % R)];
             const float2 t = ADJ ? cmulc(v[m], w) : cmul(v[m], w);
             s.x += t.x; s.y += t.y;
         }
-        if (!ADJ && q) s = cmul(s, pl.tw[(int)(((long long)tstride * j * q) % pl.N)]);
+        if (!ADJ && q) s = cmul(s, tw[tstride * j * q]);
         o[q] = s;
     }
     for (int q = 0; q < R; ++q) buf[base + q * M] = o[q];
 }
 
 template <bool ADJ>
-__device__ void fft_stage(float2* buf, int nlines, int lstride, int Ns, int R, const FftPlan& pl) {
+__device__ void fft_stage(float2* buf, int nlines, int lstride, int Ns, int R, const FftPlan& pl, const float2* tw) {
     const int N = pl.N, M = Ns / R, per_line = N / R, tstride = N / Ns;
     for (int bf = threadIdx.x; bf < nlines * per_line; bf += blockDim.x) {
         const int line = bf / per_line, rem = bf - line * per_line;
         const int blk = rem / M, j = rem - blk * M;
         const int base = line * lstride + blk * Ns + j;
         switch (R) {
-            case 2: butterfly<2, ADJ>(buf, base, M, j, tstride, pl); break;
-            case 3: butterfly<3, ADJ>(buf, base, M, j, tstride, pl); break;
-            case 4: butterfly<4, ADJ>(buf, base, M, j, tstride, pl); break;
-            case 5: butterfly<5, ADJ>(buf, base, M, j, tstride, pl); break;
-            default: butterfly_generic<ADJ>(buf, base, M, j, tstride, R, pl); break;
+            case 2: butterfly<2, ADJ>(buf, base, M, j, tstride, pl, tw); break;
+            case 3: butterfly<3, ADJ>(buf, base, M, j, tstride, pl, tw); break;
+            case 4: butterfly<4, ADJ>(buf, base, M, j, tstride, pl, tw); break;
+            case 5: butterfly<5, ADJ>(buf, base, M, j, tstride, pl, tw); break;
+            default: butterfly_generic<ADJ>(buf, base, M, j, tstride, R, pl, tw); break;
         }
     }
     __syncthreads();
 }
 
-__device__ void fft_forward(float2* buf, int nlines, int lstride, const FftPlan& pl) {
-    int Ns = pl.N;
-    for (int s = 0; s < pl.nrad; ++s) { fft_stage<false>(buf, nlines, lstride, Ns, pl.rad[s], pl); Ns /= pl.rad[s]; }
+// `tw`: the plan's twiddle table copied to LDS by load_twiddles (every butterfly reads up to 2R-1 entries)
+__device__ void load_twiddles(float2* tw, const FftPlan& pl) {
+    for (int i = threadIdx.x; i < pl.N; i += blockDim.x) tw[i] = pl.tw[i];
 }
-__device__ void fft_adjoint(float2* buf, int nlines, int lstride, const FftPlan& pl) {
+__device__ void fft_forward(float2* buf, int nlines, int lstride, const FftPlan& pl, const float2* tw) {
+    int Ns = pl.N;
+    for (int s = 0; s < pl.nrad; ++s) { fft_stage<false>(buf, nlines, lstride, Ns, pl.rad[s], pl, tw); Ns /= pl.rad[s]; }
+}
+__device__ void fft_adjoint(float2* buf, int nlines, int lstride, const FftPlan& pl, const float2* tw) {
     int Ns = 1;
-    for (int s = pl.nrad - 1; s >= 0; --s) { Ns *= pl.rad[s]; fft_stage<true>(buf, nlines, lstride, Ns, pl.rad[s], pl); }
+    for (int s = pl.nrad - 1; s >= 0; --s) { Ns *= pl.rad[s]; fft_stage<true>(buf, nlines, lstride, Ns, pl.rad[s], pl, tw); }
 }
 
 constexpr int ROWS_PER_BLOCK = 2;
@@ -480,12 +461,25 @@ __global__ __launch_bounds__(256) void fft_rows_fwd_kernel(const FftArgs a) {
     const size_t row0 = (size_t)blockIdx.x * ROWS_PER_BLOCK;            // global row index over BC*H
     const size_t nrows = (size_t)a.BC * a.H;
     const int nl = (int)min((size_t)ROWS_PER_BLOCK, nrows - row0);
-    for (int i = threadIdx.x; i < nl * W; i += blockDim.x) {
-        const size_t g = row0 * W + i;
-        buf[i] = float2{a.pred[g] - a.target[g], 0.f};
+    float2* tw = buf + ROWS_PER_BLOCK * W;
+    load_twiddles(tw, a.prow);
+    for (int i0 = threadIdx.x; i0 < nl * W; i0 += blockDim.x * 8) {       // 16 loads in flight per thread, then the LDS stores
+        float pv[8], tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            const bool ok = i < nl * W;
+            pv[u] = ok ? a.pred[row0 * W + i] : 0.f;
+            tv[u] = ok ? a.target[row0 * W + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < nl * W) buf[i] = float2{pv[u] - tv[u], 0.f};
+        }
     }
     __syncthreads();
-    fft_forward(buf, nl, W, a.prow);
+    fft_forward(buf, nl, W, a.prow, tw);
     for (int i = threadIdx.x; i < nl * W; i += blockDim.x) a.T[row0 * W + i] = buf[i];
 }
 
@@ -497,12 +491,25 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const FftArgs a) {
     const int v0 = blockIdx.x * COLS_PER_BLOCK;
     const int nc = min(COLS_PER_BLOCK, W - v0);
     float2* T = a.T + (size_t)bc * H * W;
-    for (int i = threadIdx.x; i < H * nc; i += blockDim.x) {
-        const int y = i / nc, c = i - y * nc;
-        buf[c * H + y] = T[(size_t)y * W + v0 + c];
+    float2* tw = buf + COLS_PER_BLOCK * H;
+    load_twiddles(tw, a.pcol);
+    for (int i0 = threadIdx.x; i0 < H * nc; i0 += blockDim.x * 8) {       // column gather: 8 loads in flight per thread
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            const int y = i / nc, c = i - y * nc;
+            v[u] = i < H * nc ? T[(size_t)y * W + v0 + c] : float2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            const int y = i / nc, c = i - y * nc;
+            if (i < H * nc) buf[c * H + y] = v[u];
+        }
     }
     __syncthreads();
-    fft_forward(buf, nc, H, a.pcol);
+    fft_forward(buf, nc, H, a.pcol, tw);
     float acc = 0.f;
     for (int i = threadIdx.x; i < H * nc; i += blockDim.x) {
         const float2 f = buf[i];           // lines are contiguous: nc*H elements
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const FftArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) a.partial[(size_t)bc * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
     if (a.grad == nullptr) return;
-    fft_adjoint(buf, nc, H, a.pcol);
+    fft_adjoint(buf, nc, H, a.pcol, tw);
     for (int i = threadIdx.x; i < H * nc; i += blockDim.x) {
         const int y = i / nc, c = i - y * nc;
         T[(size_t)y * W + v0 + c] = buf[c * H + y];
@@ -528,13 +535,35 @@ __global__ __launch_bounds__(256) void fft_rows_adj_kernel(const FftArgs a) {
     const size_t row0 = (size_t)blockIdx.x * ROWS_PER_BLOCK;
     const size_t nrows = (size_t)a.BC * a.H;
     const int nl = (int)min((size_t)ROWS_PER_BLOCK, nrows - row0);
-    for (int i = threadIdx.x; i < nl * W; i += blockDim.x) buf[i] = a.T[row0 * W + i];
+    float2* tw = buf + ROWS_PER_BLOCK * W;
+    load_twiddles(tw, a.prow);
+    for (int i0 = threadIdx.x; i0 < nl * W; i0 += blockDim.x * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            v[u] = i < nl * W ? a.T[row0 * W + i] : float2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < nl * W) buf[i] = v[u];
+        }
+    }
     __syncthreads();
-    fft_adjoint(buf, nl, W, a.prow);
-    for (int i = threadIdx.x; i < nl * W; i += blockDim.x) {
-        const size_t g = row0 * W + i;
-        const float v = a.gscale * buf[i].x;
-        a.grad[g] = a.accumulate ? a.grad[g] + v : v;
+    fft_adjoint(buf, nl, W, a.prow, tw);
+    for (int i0 = threadIdx.x; i0 < nl * W; i0 += blockDim.x * 8) {
+        float gv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            gv[u] = (a.accumulate && i < nl * W) ? a.grad[row0 * W + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < nl * W) a.grad[row0 * W + i] = gv[u] + a.gscale * buf[i].x;
+        }
     }
 }
 
@@ -594,7 +623,7 @@ __global__ void msssim_final_kernel(const float* __restrict__ msval, float* __re
 // workspace layout
 // =====================================================================================================================
 struct WsLayout {
-    size_t stats_part, pyrX[LV], pyrY[LV], dXl[LV], ssim_part[LV], msval, coef, T, fft_part, total;
+    size_t stats_part, pyrX[LV], pyrY[LV], dXl[LV], Gl[LV], ssim_part[LV], msval, coef, T, fft_part, total;
     int tiles[LV];
     Pyr pyr;
     int ncolblk;
@@ -611,6 +640,7 @@ static WsLayout make_layout(int B, int C, int H, int W, bool use_ms, bool use_ff
         for (int l = 0; l < LV; ++l) {
             const size_t n = BC * L.pyr.H[l] * L.pyr.W[l];
             if (l > 0) { L.pyrX[l] = take(n); L.pyrY[l] = take(n); L.dXl[l] = take(n); }
+            L.Gl[l] = take(3 * n);
             L.tiles[l] = cdiv(L.pyr.H[l] - HW_, STH) * cdiv(L.pyr.W[l] - HW_, STW);
             L.ssim_part[l] = take(BC * L.tiles[l]);
         }
@@ -626,7 +656,7 @@ static WsLayout make_layout(int B, int C, int H, int W, bool use_ms, bool use_ff
     return L;
 }
 
-static int run_ms_forward(hipStream_t st, const float* X, const float* Y, float* ws, const WsLayout& L, int B, int C, float chain) {
+static int run_ms_forward(hipStream_t st, const float* X, const float* Y, float* ws, const WsLayout& L, int B, int C, float chain, bool want_g) {
     const int BC = B * C;
     const Win win = make_win();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
@@ -637,7 +667,7 @@ static int run_ms_forward(hipStream_t st, const float* X, const float* Y, float*
         const int Hl = L.pyr.H[l], Wl = L.pyr.W[l];
         if (Hl <= HW_ || Wl <= HW_) return bnerv_set_error(BNERV_E_ARG, "ms_ssim: level %d is %dx%d, needs > %d on both sides", l, Hl, Wl, HW_);
         SsimArgs a{};
-        a.X = Xl; a.Y = Yl; a.partial = ws + L.ssim_part[l]; a.H = Hl; a.W = Wl;
+        a.X = Xl; a.Y = Yl; a.partial = ws + L.ssim_part[l]; a.H = Hl; a.W = Wl; a.G = want_g ? ws + L.Gl[l] : nullptr;
         a.tiles_x = cdiv(Wl - HW_, STW); a.tiles_y = cdiv(Hl - HW_, STH); a.C1 = C1; a.C2 = C2; a.win = win;
         dim3 grid(a.tiles_x, a.tiles_y, BC);
         if (l == LV - 1) hipLaunchKernelGGL(ssim_fwd_kernel<true>, grid, dim3(256), 0, st, a);
@@ -664,13 +694,6 @@ static int run_ms_forward(hipStream_t st, const float* X, const float* Y, float*
 static int run_ms_backward(hipStream_t st, const float* X, const float* Y, float* grad, float* ws, const WsLayout& L, int B, int C, float k_l1, float k_l2) {
     const int BC = B * C;
     const Win win = make_win();
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssim_bwd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SSIM_BWD_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssim_bwd_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SSIM_BWD_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssim_bwd_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SSIM_BWD_LDS);
-        attr_done = true;
-    }
     for (int l = LV - 1; l >= 0; --l) {
         const int Hl = L.pyr.H[l], Wl = L.pyr.W[l];
         SsimArgs a{};
@@ -680,10 +703,10 @@ static int run_ms_backward(hipStream_t st, const float* X, const float* Y, float
         a.H = Hl; a.W = Wl; a.C1 = 0.01f * 0.01f; a.C2 = 0.03f * 0.03f; a.win = win;
         if (l < LV - 1) { a.dcoarse = ws + L.dXl[l + 1]; a.Hc = L.pyr.H[l + 1]; a.Wc = L.pyr.W[l + 1]; a.ph = Hl % 2; a.pw = Wl % 2; }
         a.k_l1 = k_l1; a.k_l2 = k_l2;
+        a.G = ws + L.Gl[l];
         dim3 grid(cdiv(Wl, STW), cdiv(Hl, STH), BC);
-        if (l == LV - 1) hipLaunchKernelGGL((ssim_bwd_kernel<true, false>), grid, dim3(256), SSIM_BWD_LDS, st, a);
-        else if (l == 0) hipLaunchKernelGGL((ssim_bwd_kernel<false, true>), grid, dim3(256), SSIM_BWD_LDS, st, a);
-        else hipLaunchKernelGGL((ssim_bwd_kernel<false, false>), grid, dim3(256), SSIM_BWD_LDS, st, a);
+        if (l == 0) hipLaunchKernelGGL((ssim_bwd_from_g_kernel<true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((ssim_bwd_from_g_kernel<false>), grid, dim3(256), 0, st, a);
         BNERV_LAUNCH_CHECK("ssim_bwd");
     }
     return BNERV_OK;
@@ -719,7 +742,7 @@ extern "C" int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* dp) {
     const float k_l1 = d.c_l1 / ((float)d.B * (float)nps), k_l2 = 2.0f * d.c_l2 / ((float)d.B * (float)nps);
     if (use_ms) {
         if (d.H <= 160 || d.W <= 160) return bnerv_set_error(BNERV_E_ARG, "loss: MS-SSIM needs min(H,W) > 160 (got %dx%d)", d.H, d.W);
-        rc = run_ms_forward(st, d.pred, d.target, ws, L, d.B, d.C, -d.c_ms / (float)BC);
+        rc = run_ms_forward(st, d.pred, d.target, ws, L, d.B, d.C, -d.c_ms / (float)BC, d.grad != nullptr);
         if (rc) return rc;
         if (d.grad) { rc = run_ms_backward(st, d.pred, d.target, d.grad, ws, L, d.B, d.C, k_l1, k_l2); if (rc) return rc; }
     } else if (d.grad) {
@@ -734,7 +757,7 @@ extern "C" int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* dp) {
             return bnerv_set_error(BNERV_E_ARG, "loss: FFT size %dx%d has a prime factor > %d", d.H, d.W, BNERV_FFT_MAX_RADIX);
         a.pred = d.pred; a.target = d.target; a.T = reinterpret_cast<float2*>(ws + L.T); a.partial = ws + L.fft_part; a.grad = d.grad;
         a.BC = BC; a.H = d.H; a.W = d.W; a.gscale = d.c_fft / ((float)d.B * (float)nps * 2.0f); a.accumulate = 1;
-        const size_t lds_row = (size_t)ROWS_PER_BLOCK * d.W * sizeof(float2), lds_col = (size_t)COLS_PER_BLOCK * d.H * sizeof(float2);
+        const size_t lds_row = (size_t)(ROWS_PER_BLOCK + 1) * d.W * sizeof(float2), lds_col = (size_t)(COLS_PER_BLOCK + 1) * d.H * sizeof(float2);   // + twiddle table
         BNERV_REQUIRE(lds_row <= 160 * 1024 && lds_col <= 160 * 1024, "loss: frame %dx%d too large for the LDS FFT", d.H, d.W);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_adj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
@@ -765,7 +788,7 @@ extern "C" int bnerv_msssim(void* stream, const float* x, const float* y, float*
     if (ws_bytes < L.total * sizeof(float)) return bnerv_set_error(BNERV_E_WS, "msssim: workspace %zu < %zu", ws_bytes, L.total * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     float* ws = reinterpret_cast<float*>(wsv);
-    int rc = run_ms_forward(st, x, y, ws, L, B, C, 0.f);
+    int rc = run_ms_forward(st, x, y, ws, L, B, C, 0.f, false);
     if (rc) return rc;
     hipLaunchKernelGGL(msssim_final_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, ws + L.msval, out, B, C);
     BNERV_LAUNCH_CHECK("msssim_final");
