@@ -16,7 +16,7 @@ DENSE_DX_CHUNK = 64
 
 ACT_NONE, ACT_RELU, ACT_SIN = 0, 1, 2
 IN_PLAIN, IN_AFFINE, IN_GELU_AFFINE, IN_UNSHUFFLE, IN_TANHGRAD = 0, 1, 2, 3, 4
-EP_BIAS, EP_BIAS_SIN, EP_BIAS_RES, EP_BIAS_TANH, EP_PLAIN, EP_DGELU, EP_DSIN = 0, 1, 2, 3, 4, 5, 6
+EP_BIAS, EP_BIAS_SIN, EP_BIAS_RES, EP_BIAS_TANH, EP_PLAIN, EP_DGELU, EP_DSIN, EP_BIAS_GELU, EP_DGELU_SAVED = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 _fp = C.c_void_p     # device pointers travel as void* (data_ptr())
 

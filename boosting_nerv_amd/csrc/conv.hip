@@ -244,6 +244,7 @@ template <int EP>
 __device__ __forceinline__ float ep_value(const bnerv_conv_desc& d, float v, float bias, size_t o, float* out2v) {
     if constexpr (EP == BNERV_EP_BIAS) return v + bias;
     if constexpr (EP == BNERV_EP_BIAS_SIN) { float sv, cv; sincosf(v + bias, &sv, &cv); *out2v = cv; return sv; }
+    if constexpr (EP == BNERV_EP_BIAS_GELU) { float h; gelu_pair_f(v + bias, &h, out2v); return h; }
     if constexpr (EP == BNERV_EP_BIAS_RES) return v + bias + d.aux0[o];
     if constexpr (EP == BNERV_EP_BIAS_TANH) return tanhf(v + bias) * 0.5f + 0.5f;
     return v;
@@ -258,7 +259,7 @@ __device__ __forceinline__ void copy_out_tile(const KArgs& ka, const float* s_ou
     const int s = d.out_s;
     float* outp = d.out;                                  // split-K partial results go to this item's slab instead
     if constexpr (EP == BNERV_EP_PLAIN) { if (ka.ksplit > 1) outp = d.partial + (size_t)it.ks * d.B * Cout * H * W; }
-    if constexpr (EP == BNERV_EP_DGELU || EP == BNERV_EP_DSIN) {
+    if constexpr (EP == BNERV_EP_DGELU || EP == BNERV_EP_DSIN || EP == BNERV_EP_DGELU_SAVED) {
         // stride-1 only.  Pass k: wave w handles channel cl = 4k + w: 64 lanes = 8 rows x 8 float4 (vec) or 4 x 64 px (scalar);
         // per-channel (ds, dt) partial sums need only a wave reduction.
         for (int k = 0; k < 4; ++k) {
@@ -277,6 +278,10 @@ __device__ __forceinline__ void copy_out_tile(const KArgs& ka, const float* s_ou
                     if constexpr (EP == BNERV_EP_DGELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { r[e] = v[e] * sc * gelu_grad_f(a0[e]); ps = fmaf(v[e], gelu_f(a0[e]), ps); pt += v[e]; }
+                    } else if constexpr (EP == BNERV_EP_DGELU_SAVED) {
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(d.aux1 + o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { r[e] = v[e] * sc * a0[e]; ps = fmaf(v[e], a1[e], ps); pt += v[e]; }
                     } else {
                         const f32x4 a1 = *reinterpret_cast<const f32x4*>(d.aux1 + o);
                         f32x4 a2 = {1.f, 1.f, 1.f, 1.f};
@@ -296,6 +301,9 @@ __device__ __forceinline__ void copy_out_tile(const KArgs& ka, const float* s_ou
                         const float pre = d.aux0[o];
                         d.out[o] = v * sc * gelu_grad_f(pre);
                         ps = fmaf(v, gelu_f(pre), ps);
+                    } else if constexpr (EP == BNERV_EP_DGELU_SAVED) {
+                        d.out[o] = v * sc * d.aux0[o];
+                        ps = fmaf(v, d.aux1[o], ps);
                     } else {
                         d.out[o] = (d.aux1[o] + v * sc) * (d.aux2 ? d.aux2[o] : 1.0f);
                         ps = fmaf(v, d.aux0[o], ps);
@@ -330,7 +338,7 @@ __device__ __forceinline__ void copy_out_tile(const KArgs& ka, const float* s_ou
                 for (int e = 0; e < 4; ++e) { float c2 = 0.f; r[e] = ep_value<EP>(d, v[e], bias, o + e, &c2); r2[e] = c2; }
             }
             *reinterpret_cast<f32x4*>(outp + o) = r;
-            if constexpr (EP == BNERV_EP_BIAS_SIN) { if (d.out2) *reinterpret_cast<f32x4*>(d.out2 + o) = r2; }
+            if constexpr (EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) { if (d.out2) *reinterpret_cast<f32x4*>(d.out2 + o) = r2; }
         }
     } else if (s == 2 && ka.vec) {
         // PixelShuffle(2): final channel cf = co/4; output float4 = (px, j=0), (px, j=1), (px+1, j=0), (px+1, j=1) of row 2*py+i
@@ -353,7 +361,7 @@ __device__ __forceinline__ void copy_out_tile(const KArgs& ka, const float* s_ou
 #pragma unroll
             for (int e = 0; e < 4; ++e) { float c2 = 0.f; r[e] = ep_value<EP>(d, in4[e], bs4[e], o + e, &c2); r2[e] = c2; }
             *reinterpret_cast<f32x4*>(d.out + o) = r;
-            if constexpr (EP == BNERV_EP_BIAS_SIN) { if (d.out2) *reinterpret_cast<f32x4*>(d.out2 + o) = r2; }
+            if constexpr (EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) { if (d.out2) *reinterpret_cast<f32x4*>(d.out2 + o) = r2; }
         }
     } else {
         // generic pixel-shuffle scatter (s = 3, 5, or unaligned widths): low-resolution stages only
@@ -367,7 +375,7 @@ __device__ __forceinline__ void copy_out_tile(const KArgs& ka, const float* s_ou
             const float bias = (EP != BNERV_EP_PLAIN && d.bias) ? d.bias[co] : 0.f;
             float c2 = 0.f;
             outp[o] = ep_value<EP>(d, s_out[cl * CS + py * TW + px], bias, o, &c2);
-            if constexpr (EP == BNERV_EP_BIAS_SIN) { if (d.out2) d.out2[o] = c2; }
+            if constexpr (EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) { if (d.out2) d.out2[o] = c2; }
         }
     }
 }
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
     constexpr int S_IN = NCH * G::PLANE + (NPRE * 256 - NSLOT) * 4;        // floats; the tail is a dump area for idle slots
     constexpr bool TWO = (IN == BNERV_IN_TANHGRAD);
     constexpr bool AFF = (IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE);
-    constexpr bool RED = (EP == BNERV_EP_DGELU || EP == BNERV_EP_DSIN);
+    constexpr bool RED = (EP == BNERV_EP_DGELU || EP == BNERV_EP_DSIN || EP == BNERV_EP_DGELU_SAVED);
     const bnerv_conv_desc& d = ka.d;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;
@@ -790,7 +798,7 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, in_bytes);
     const __amdgpu_buffer_rsrc_t rx2 = make_rsrc(TWO ? d.aux0 : d.x, shift, in_bytes);
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.out, 0, out_bytes);
-    const __amdgpu_buffer_rsrc_t ro2 = make_rsrc((EP == BNERV_EP_BIAS_SIN && d.out2) ? d.out2 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ro2 = make_rsrc(((EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) && d.out2) ? d.out2 : d.out, 0, out_bytes);
     const __amdgpu_buffer_rsrc_t ra0 = make_rsrc((!TWO && d.aux0) ? d.aux0 : d.out, 0, out_bytes);
     const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(d.aux1 ? d.aux1 : d.out, 0, out_bytes);
     const __amdgpu_buffer_rsrc_t ra2 = make_rsrc(d.aux2 ? d.aux2 : d.out, 0, out_bytes);
@@ -963,6 +971,15 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
                     bstore(ro, vo[m], so[m], sv);
                     if (d.out2) bstore(ro2, vo[m], so[m], cv);
                 }
+            } else if constexpr (EP == BNERV_EP_BIAS_GELU) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x4 hv, gv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float h_, g_; gelu_pair_f(acc[m][e] + bias_l, &h_, &g_); hv[e] = h_; gv[e] = g_; }
+                    bstore(ro, vo[m], so[m], hv);
+                    if (d.out2) bstore(ro2, vo[m], so[m], gv);
+                }
             } else if constexpr (EP == BNERV_EP_BIAS_TANH) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -982,6 +999,7 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     a0[m] = bload(ra0, vo[m], so[m]);
+                    if constexpr (EP == BNERV_EP_DGELU_SAVED) a1[m] = bload(ra1, vo[m], so[m]);
                     if constexpr (EP == BNERV_EP_DSIN) {
                         a1[m] = bload(ra1, vo[m], so[m]);
                         a2[m] = f32x4{1.f, 1.f, 1.f, 1.f};
@@ -996,6 +1014,9 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
                     if constexpr (EP == BNERV_EP_DGELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { r[e] = v[e] * scl * gelu_grad_f(a0[m][e]); ps = fmaf(v[e], gelu_f(a0[m][e]), ps); pt += v[e]; }
+                    } else if constexpr (EP == BNERV_EP_DGELU_SAVED) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { r[e] = v[e] * scl * a0[m][e]; ps = fmaf(v[e], a1[m][e], ps); pt += v[e]; }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { r[e] = (a1[m][e] + v[e] * scl) * a2[m][e]; ps = fmaf(v[e], a0[m][e], ps); pt += v[e]; }
@@ -1125,6 +1146,9 @@ int launch_mode(hipStream_t st, KArgs& ka) {
         BNERV_CASE(BNERV_IN_GELU_AFFINE, BNERV_EP_BIAS_RES)
         BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DGELU)
         BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DSIN)
+        BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_GELU)
+        BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_RES)
+        BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DGELU_SAVED)
     }
 #undef BNERV_CASE
     return bnerv_set_error(BNERV_E_ARG, "conv_igemm: unsupported (k=%d, in_mode=%d, ep_mode=%d)", KS, in, ep);
@@ -1192,6 +1216,8 @@ extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
     if (d.ep_mode == BNERV_EP_BIAS_RES) BNERV_REQUIRE(d.aux0, "conv_igemm: residual epilogue needs aux0");
     if (d.ep_mode == BNERV_EP_DGELU) BNERV_REQUIRE(d.aux0 && d.scale && d.partial && d.out_s == 1, "conv_igemm: DGELU epilogue args");
     if (d.ep_mode == BNERV_EP_DSIN) BNERV_REQUIRE(d.aux0 && d.aux1 && d.scale && d.partial && d.out_s == 1, "conv_igemm: DSIN epilogue args");
+    if (d.ep_mode == BNERV_EP_DGELU_SAVED) BNERV_REQUIRE(d.aux0 && d.aux1 && d.scale && d.partial && d.out_s == 1, "conv_igemm: DGELU_SAVED epilogue args");
+    if (d.ep_mode == BNERV_EP_BIAS_GELU) BNERV_REQUIRE(d.out2 && d.out_s == 1, "conv_igemm: BIAS_GELU epilogue needs out2, stride-1 output");
     if (d.in_mode == BNERV_IN_UNSHUFFLE && d.in_s == 1) d.in_mode = BNERV_IN_PLAIN;       // same gather, faster staging
     ka.tiles_x = cdiv(d.W, TW);
     ka.tiles_y = cdiv(d.H, TH);

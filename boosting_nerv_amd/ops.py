@@ -33,7 +33,7 @@ def _conv(x, w, bias, out, *, B, Cin, Cout, H, W, k, in_mode, ep_mode, in_s=1, o
                    transposed, w.shape[0], w.shape[1])
     lib = L.load()
     ws = None
-    if ep_mode in (L.EP_DGELU, L.EP_DSIN):
+    if ep_mode in (L.EP_DGELU, L.EP_DSIN, L.EP_DGELU_SAVED):
         # per-tile (ds, dt) partial sums: the kernel (hence its tile height) is chosen from shape + alignment -> ask, allocate, reduce
         rows = lib.bnerv_conv_partial_rows(C.byref(d))
         part = torch.empty(rows, B, 2, Cout, dtype=torch.float32, device=x.device)
@@ -258,25 +258,28 @@ def conv2d_ps(x, w, b, shuffle=1):
 # ----------------------------------------------------------------------------------------------------------------------
 def _tat_forward(y0, s0, t0, s1, t1, w0, b0, w1, b1):
     B, Cc, H, W = y0.shape
-    v = torch.empty_like(y0)
-    _conv(y0, w0, b0, v, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS, scale=s0, shift=t0)
+    # conv0's epilogue stores h = gelu(v) and gp = gelu'(v) instead of v: conv1, its weight gradient and the dGELU epilogue of
+    # the backward then run without erf/exp (v itself has no other consumer)
+    h = torch.empty_like(y0)
+    gp = torch.empty_like(y0)
+    _conv(y0, w0, b0, h, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=s0, shift=t0, out2=gp)
     out = torch.empty_like(y0)
-    _conv(v, w1, b1, out, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_GELU_AFFINE, ep_mode=L.EP_BIAS_RES, scale=s1, shift=t1, aux0=y0)
-    return v, out
+    _conv(h, w1, b1, out, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_RES, scale=s1, shift=t1, aux0=y0)
+    return h, gp, out
 
 
-def _tat_backward(dout, y0, c0, v, s0, t0, s1, t1, w0, w1):
+def _tat_backward(dout, y0, c0, h, gp, s0, t0, s1, t1, w0, w1):
     """Returns (dy0_or_du, ds0, dt0, ds1, dt1, dw0, db0, dw1, db1).  With c0 given the first result is
     d/d(pre-sin) = (dout + dA0*(1+s0)) * c0, otherwise d/dy0."""
     B, Cc, H, W = y0.shape
     dev = y0.device
     dw1 = torch.empty_like(w1); db1 = torch.empty(Cc, dtype=torch.float32, device=dev)
     # every slab reduction below is deferred: it rides on the next launch of this chain; the CALLER flushes the leftovers
-    _wgrad(v, dout, dw1, db1, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_GELU_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s1, shift=t1,
+    _wgrad(h, dout, dw1, db1, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s1, shift=t1,
            defer=True)
     dv = torch.empty_like(y0)
-    st1 = _conv(dout, w1, None, dv, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU, transposed=1,
-                aux0=v, scale=s1, defer=True)
+    st1 = _conv(dout, w1, None, dv, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU_SAVED, transposed=1,
+                aux0=gp, aux1=h, scale=s1, defer=True)
     dw0 = torch.empty_like(w0); db0 = torch.empty(Cc, dtype=torch.float32, device=dev)
     _wgrad(y0, dv, dw0, db0, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s0, shift=t0,
            defer=True)
@@ -293,15 +296,15 @@ class _TATBlock(torch.autograd.Function):
         B, Cc = x0.shape[:2]
         s0, t0, s1, t1 = (_bc(t, B, Cc) for t in (s0, t0, s1, t1))
         w0, b0, w1, b1 = (L.f32c(t) for t in (w0, b0, w1, b1))
-        v, out = _tat_forward(x0, s0, t0, s1, t1, w0, b0, w1, b1)
-        ctx.save_for_backward(x0, v, s0, t0, s1, t1, w0, w1)
+        h, gp, out = _tat_forward(x0, s0, t0, s1, t1, w0, b0, w1, b1)
+        ctx.save_for_backward(x0, h, gp, s0, t0, s1, t1, w0, w1)
         ctx.mshape = (B, Cc, 1, 1)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x0, v, s0, t0, s1, t1, w0, w1 = ctx.saved_tensors
-        dx0, ds0, dt0, ds1, dt1, dw0, db0, dw1, db1 = _tat_backward(L.f32c(dout), x0, None, v, s0, t0, s1, t1, w0, w1)
+        x0, h, gp, s0, t0, s1, t1, w0, w1 = ctx.saved_tensors
+        dx0, ds0, dt0, ds1, dt1, dw0, db0, dw1, db1 = _tat_backward(L.f32c(dout), x0, None, h, gp, s0, t0, s1, t1, w0, w1)
         _flush_deferred()
         m = ctx.mshape
         return dx0, ds0.reshape(m), dt0.reshape(m), ds1.reshape(m), dt1.reshape(m), dw0, db0, dw1, db1
@@ -326,16 +329,16 @@ class _SNeRVBlock(torch.autograd.Function):
         y0 = torch.empty(B, Cc, H * s, W * s, dtype=torch.float32, device=x.device)
         c0 = torch.empty_like(y0)
         _conv(x, wu, bu, y0, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_SIN, out_s=s, out2=c0)
-        v, out = _tat_forward(y0, s0, t0, s1, t1, w0, b0, w1, b1)
-        ctx.save_for_backward(x, y0, c0, v, s0, t0, s1, t1, wu, w0, w1)
+        h, gp, out = _tat_forward(y0, s0, t0, s1, t1, w0, b0, w1, b1)
+        ctx.save_for_backward(x, y0, c0, h, gp, s0, t0, s1, t1, wu, w0, w1)
         ctx.s, ctx.has_bu, ctx.mshape = s, bu is not None, (B, Cc, 1, 1)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, y0, c0, v, s0, t0, s1, t1, wu, w0, w1 = ctx.saved_tensors
+        x, y0, c0, h, gp, s0, t0, s1, t1, wu, w0, w1 = ctx.saved_tensors
         s = ctx.s
-        du, ds0, dt0, ds1, dt1, dw0, db0, dw1, db1 = _tat_backward(L.f32c(dout), y0, c0, v, s0, t0, s1, t1, w0, w1)
+        du, ds0, dt0, ds1, dt1, dw0, db0, dw1, db1 = _tat_backward(L.f32c(dout), y0, c0, h, gp, s0, t0, s1, t1, w0, w1)
         B, Cin, H, W = x.shape
         Ct, k = wu.shape[0], wu.shape[-1]
         dwu = torch.empty_like(wu)

@@ -210,6 +210,7 @@ def train(local_rank, args):
     random.seed(args.manualSeed)
     if not torch.cuda.is_available():
         raise RuntimeError("train_nerv_all: no ROCm GPU visible -- the decoder path has no CPU fallback")
+    torch.backends.cudnn.benchmark = True   # train_nerv_all.py:154 (on ROCm: MIOpen solver search for the stock-PyTorch encoder convs)
     world = 1
     if args.distributed and args.ngpus_per_node > 1:
         rank = int(os.environ["RANK"]) if args.init_method == "env://" else local_rank

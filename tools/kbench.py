@@ -44,6 +44,9 @@ for (H, W) in ((720, 1280), (360, 640)):
     cases = {
         "fwd affine->bias (K2)": lambda: ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS, scale=sc, shift=sh),
         "fwd gelu-affine->res (K3)": lambda: ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_GELU_AFFINE, ep_mode=L.EP_BIAS_RES, scale=sc, shift=sh, aux0=y0),
+        "fwd affine->gelu,gelu' (K2s)": lambda: ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=sc, shift=sh, out2=out2),
+        "fwd affine->res (K3s)": lambda: ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_RES, scale=sc, shift=sh, aux0=y0),
+        "dgrad ->dgelu saved (K3s bwd)": lambda: ops._conv(g, w, None, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU_SAVED, transposed=1, aux0=v, aux1=y0, scale=sc, partial=part),
         "fwd plain->sin s1 (K1)": lambda: ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_SIN, out2=out2),
         "dgrad ->dgelu (K3 bwd)": lambda: ops._conv(g, w, None, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU, transposed=1, aux0=v, scale=sc, partial=part),
         "dgrad ->dsin (K2 bwd)": lambda: ops._conv(g, w, None, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN, transposed=1, aux0=y0, aux1=g, aux2=v, scale=sc, partial=part),
