@@ -57,7 +57,11 @@ struct KArgs {
     int vec;              // 1: W % 4 == 0 and aligned pointers -> float4 staging and epilogue
     int ksplit;           // >1: the K (input-channel chunk) range is split over `ksplit` work items; each writes a raw
     int chunks_per_split; //     partial result to its slab in d.partial ([ksplit][B][Cout][H][W]), finished by reduce_slabs
+    unsigned magic_tiles, magic_tiles_x;   // floor(2^32 / n) + 1: a / n == umulhi(a, magic) for a * n < 2^32 (lean kernel's item decode)
 };
+
+static inline unsigned div_magic(int n) { return n <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)n) + 1ull); }   // 0 encodes n == 1
+__device__ __forceinline__ int fast_div(int a, unsigned magic) { return magic ? (int)__umulhi((unsigned)a, magic) : a; }
 
 struct Item { int g, b, ty0, tx0, tile, ks; };
 
@@ -728,6 +732,7 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
     float* s_in = smem;
     float* s_w = smem + S_IN;                              // [T][NQ1][64] B fragments
     float* s_red = s_w + G::T * NQ1 * 64;                  // [4 waves][2][16] per-channel partial sums (DGELU / DSIN)
+    float* s_aff = s_red + 128;                            // [2][16] affine prologue parameters of the current sample
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -743,13 +748,13 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
     const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
     int itx = r0 + lb;
     if (itx >= r1) { side_run_hosted(side, smem); return; }
-    const int step_q = nlb / tiles_x, step_r = nlb - step_q * tiles_x;
+    const int step_q = fast_div(nlb, ka.magic_tiles_x), step_r = nlb - step_q * tiles_x;      // uniform: two SALU per division
     LItem it;
     {
         const int tiles = tiles_x * tiles_y;
-        it.b = itx / tiles;
+        it.b = fast_div(itx, ka.magic_tiles);
         const int t = itx - it.b * tiles;
-        it.ty = t / tiles_x;
+        it.ty = fast_div(t, ka.magic_tiles_x);
         it.tx = t - it.ty * tiles_x;
     }
     auto advance = [&](LItem a) {
@@ -807,16 +812,32 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
     const unsigned ovoff = li < Cout ? (unsigned)(((li * H) * W + 4 * kq) * 4) : OOB;
     const float bias_l = (EP != BNERV_EP_PLAIN && !RED && d.bias && li < Cout) ? d.bias[li] : 0.f;
 
+    // Affine prologue parameters go through LDS: ONE 32-lane load per block (s_aff[c] = 1 + scale[b][c], s_aff[16 + c] =
+    // shift[b][c]), then each thread picks the values of its slots.  (A wave64 global load occupies the address unit for ~16
+    // cycles whatever its width: 2 * NPRE per-lane loads in every wave of every block were ~2.5 k cycles of every launch.)
     float sc[NPRE], sh[NPRE];
-    auto load_affine = [&](int b) {
+    auto fetch_affine = [&](int b) {                       // tid < 32 only: the value this lane contributes
+        const int c = tid & 15;
+        float v = 0.f;
+        if (tid < 32 && c < Cin) v = tid < 16 ? 1.0f + d.scale[b * Cin + c] : d.shift[b * Cin + c];
+        return v;
+    };
+    auto pick_affine = [&]() {                             // after s_aff is visible
 #pragma unroll
         for (int k = 0; k < NPRE; ++k) {
             int c, r, sg;
             slot_geom(k, c, r, sg);
             const bool ok = voff[k] != OOB;
-            sc[k] = ok ? 1.0f + d.scale[b * Cin + c] : 0.f;
-            sh[k] = ok ? d.shift[b * Cin + c] : 0.f;
+            sc[k] = ok ? s_aff[c & 15] : 0.f;
+            sh[k] = ok ? s_aff[16 + (c & 15)] : 0.f;
         }
+    };
+    auto load_affine = [&](int b) {                        // mid-loop reload when the sample changes (B > 1; latency exposed, rare)
+        const float v = fetch_affine(b);
+        lds_barrier();
+        if (tid < 32) s_aff[tid] = v;
+        lds_barrier();
+        pick_affine();
     };
     float scl = 0.f;                                       // 1 + scale[b][co] of the DGELU / DSIN epilogues
 
@@ -872,26 +893,34 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
 
     // prologue: the first tile's loads, then ALL weight loads back to back (one exposed memory latency for the lot)
     int aff_b = -1, ep_b = -1;
+    { const int trace_iter = 5; (void)trace_iter; TRACE(2); }
+    float aff_v = 0.f;
+    if constexpr (AFF) { aff_v = fetch_affine(it.b); aff_b = it.b; }      // oldest load in flight: first to come back
     issue(it);
+    { const int trace_iter = 5; (void)trace_iter; TRACE(3); }
     {
         constexpr int NWV = (G::T * NQ1 * 64 + 255) / 256;
         float wv[NWV];
+        // B fragment (tap, q) lane l <- W(co = l & 15, ci = 4 q + (l >> 4), tap).  (tap, q) is wave-uniform (tq = wave + 4 j): the
+        // per-lane part of the element index is one constant, the rest is scalar arithmetic.
+        const int lane_w = d.transposed ? ((kq * d.wCi + li) * G::T) : ((li * d.wCi + kq) * G::T);
 #pragma unroll
-        for (int j = 0; j < NWV; ++j) {                    // B fragment (tap, q) lane l <- W(co = l & 15, ci = 4 q + (l >> 4), tap)
-            const int idx = tid + j * 256;
-            const int l = idx & 63, tq = idx >> 6;
+        for (int j = 0; j < NWV; ++j) {
+            const int tq = wave + 4 * j;
             const int tap = tq / NQ1, q = tq - tap * NQ1;
-            const int co = l & 15, ci = q * 4 + (l >> 4);
+            const int sc_off = d.transposed ? (4 * q * d.wCi * G::T + (G::T - 1 - tap)) : (4 * q * G::T + tap);
             float v = 0.f;
-            if (tq < G::T * NQ1 && co < Cout && ci < Cin)
-                v = d.transposed ? d.w[((size_t)ci * d.wCi + co) * G::T + (G::T - 1 - tap)] : d.w[((size_t)co * d.wCi + ci) * G::T + tap];
+            if (tq < G::T * NQ1 && li < Cout && q * 4 + kq < Cin) v = d.w[lane_w + sc_off];
             wv[j] = v;
         }
-        if constexpr (AFF) { load_affine(it.b); aff_b = it.b; }
+        { const int trace_iter = 5; (void)trace_iter; TRACE(4); }
+        if constexpr (AFF) { if (tid < 32) s_aff[tid] = aff_v; }
 #pragma unroll
         for (int j = 0; j < NWV; ++j)
             if (tid + j * 256 < G::T * NQ1 * 64) s_w[tid + j * 256] = wv[j];
+        { const int trace_iter = 5; (void)trace_iter; TRACE(5); }
     }
+    if constexpr (AFF) { lds_barrier(); pick_affine(); }
     commit(it);
     { const int trace_iter = 5; (void)trace_iter; TRACE(1); }
     const int abase = kq * G::PLANE + (2 * wave) * G::RS + li + G::COL0;
@@ -1056,7 +1085,9 @@ int launch_lean(hipStream_t st, KArgs& ka) {
     ka.total_items = d.B * ka.tiles_x * ka.tiles_y;
     ka.nq_total = NQ1;
     ka.w_resident = 1;
-    const size_t lds = ((size_t)NCH * G::PLANE + (size_t)(NPRE * 256 - NSLOT) * 4 + (size_t)G::T * NQ1 * 64 + 128) * sizeof(float);
+    ka.magic_tiles = div_magic(ka.tiles_x * ka.tiles_y);
+    ka.magic_tiles_x = div_magic(ka.tiles_x);
+    const size_t lds = ((size_t)NCH * G::PLANE + (size_t)(NPRE * 256 - NSLOT) * 4 + (size_t)G::T * NQ1 * 64 + 128 + 32) * sizeof(float);
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         int nb = 0;
@@ -1226,6 +1257,7 @@ extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     ka.ksplit = 1;
     ka.chunks_per_split = 0;
+    ka.magic_tiles = ka.magic_tiles_x = 0;
     if (d.ep_mode == BNERV_EP_PLAIN && d.partial != nullptr) {            // caller supplied a split-K workspace
         const SplitPlan p = plan_split(d);
         ka.ksplit = p.ksplit;

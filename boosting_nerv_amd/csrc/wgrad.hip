@@ -484,15 +484,27 @@ __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(cons
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(d.g, 0, g_bytes);
     const __amdgpu_buffer_rsrc_t rg2 = make_rsrc(GM2 == 2 ? d.gaux : d.g, 0, g_bytes);
 
+    // affine parameters through LDS: one 32-lane load per block, then every thread picks its slots' values (see conv.hip)
     float sc[NXS], sh[NXS];
+    float* s_aff = s_in + (NPLL + 2) * G::PLANE + (NXS * 256 - NXSLOT) * 4;   // [2][16], behind the dump area
+    auto fetch_affine = [&](int b) {
+        const int c = tid & 15;
+        float v = 0.f;
+        if (tid < 32 && c < Cin) v = tid < 16 ? 1.0f + d.scale[b * Cin + c] : d.shift[b * Cin + c];
+        return v;
+    };
     auto load_affine = [&](int b) {
+        const float v = fetch_affine(b);
+        lds_barrier();
+        if (tid < 32) s_aff[tid] = v;
+        lds_barrier();
 #pragma unroll
         for (int k = 0; k < NXS; ++k) {
             int c, r, sg;
             xslot(k, c, r, sg);
             const bool ok = voffx[k] != OOB;
-            sc[k] = ok ? 1.0f + d.scale[b * Cin + c] : 0.f;
-            sh[k] = ok ? d.shift[b * Cin + c] : 0.f;
+            sc[k] = ok ? s_aff[c & 15] : 0.f;
+            sh[k] = ok ? s_aff[16 + (c & 15)] : 0.f;
         }
     };
 
@@ -674,7 +686,7 @@ int launch_wlean(hipStream_t st, const WArgs& wa) {
     constexpr int NXSLOT = NPLL * G::ROWS * G::SEGS;
     constexpr int NXS = (NXSLOT + 255) / 256;
     const int n_grows = wa.d.Cout <= 12 ? 12 : 16;
-    const size_t lds_main = (size_t)(NPLL + 2) * G::PLANE + (size_t)(NXS * 256 - NXSLOT) * 4 + (size_t)n_grows * CSG + 64;
+    const size_t lds_main = (size_t)(NPLL + 2) * G::PLANE + (size_t)(NXS * 256 - NXSLOT) * 4 + (size_t)n_grows * CSG + 64 + 32;
     const size_t lds_red = (size_t)4 * 16 * NTW * 16;
     const size_t lds = (lds_main > lds_red ? lds_main : lds_red) * sizeof(float);
     SidePack side;

@@ -38,6 +38,10 @@ for x in range(8):
 pv = (t[:, :, 5, 1] > 0) & (t[:, :, 5, 0] > 0)
 pro = (t[:, :, 5, 1] - t[:, :, 5, 0])[pv]
 print(f"prologue (kernel entry -> first loop top), cycles: median {np.median(pro):.0f}  p90 {np.percentile(pro, 90):.0f}  max {pro.max()}")
+pp = t[:, :, 5, :][pv]
+if (pp[:, 2] > 0).all():
+    for nm, a_, b_ in (("entry -> slot constants done", 0, 2), ("issue first tile", 2, 3), ("weight/affine loads issued", 3, 4), ("weights in LDS (waits for them)", 4, 5), ("commit (waits for the tile)", 5, 1)):
+        print(f"   {nm:34s} median {np.median(pp[:, b_] - pp[:, a_]):7.0f} cycles")
 valid[:, :, 5] = False
 names = ["top->barA", "issue", "K loop (issue)", "drain+s_out write", "barB wait", "commit", "copy-out"]
 for it in range(6):
