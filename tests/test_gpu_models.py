@@ -187,6 +187,42 @@ def test_train_trajectory_matches_oracle(use_graph):
         assert d.mean().item() <= 2e-5, (k, d.mean().item())
 
 
+def test_short_schedule_end_psnr_matches_oracle():
+    """SURVEY 8(d) parity gate: train the tiny NeRV_Boost for 3 epochs over 6 synthetic frames with the cosine schedule, same
+    init and frame order on both sides, then evaluate every frame: the end PSNR (mean over frames, fp32 model) of the HIP
+    path is within 0.02 dB of the CPU oracle's."""
+    from boosting_nerv_amd.engine import TrainStep
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    from boosting_nerv_amd.optimizer import Adan
+    from boosting_nerv_amd.synth import SyntheticVideo
+    n, epochs, lr = 6, 3, 0.003
+    vid = SyntheticVideo(n, 180, 320)
+    frames = torch.stack([vid.frame(i) for i in range(n)])
+    norm_idxs = torch.tensor([(i + 1) / n for i in range(n)], dtype=torch.float64)
+    g = torch.Generator().manual_seed(7)
+    order = [int(i) for e in range(epochs) for i in torch.randperm(n, generator=g)]
+    lrs = [lr * cpu_ref.lr_mult(((s // n) + (s % n) / n) / epochs) for s in range(len(order))]
+    torch.manual_seed(1)
+    model = NeRV_Boost(1, args=configs.tiny_nerv())
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    _, _, ref_sd = _oracle_trajectory(sd0, frames, norm_idxs, order, lrs, "Fusion10_freq")
+    with torch.no_grad():
+        ref_psnr = torch.stack([cpu_ref.psnr_fn_single(cpu_ref.nerv_boost_forward(ref_sd, norm_idxs[i:i + 1]), frames[i:i + 1]) for i in range(n)]).mean().item()
+    model = model.to(DEV)
+    opt = Adan(model.parameters(), lr=lrs[0])
+    step = TrainStep(model, opt, "Fusion10_freq", False, (1, 3, 180, 320), torch.device(DEV), use_graph=True, warmup_eager=2)
+    fd, nd = frames.to(DEV), norm_idxs.to(DEV)
+    for s, fi in enumerate(order):
+        for pg in opt.param_groups:
+            pg["lr"] = lrs[s]
+        step(fd[fi:fi + 1], nd[fi:fi + 1])
+    from boosting_nerv_amd import hnerv_utils as hu
+    model.eval()
+    with torch.no_grad():
+        got = torch.stack([hu.psnr_fn_single(model(nd[i:i + 1], norm_idx=nd[i:i + 1])[0], fd[i:i + 1]) for i in range(n)]).mean().item()
+    assert abs(got - ref_psnr) <= 0.02, (got, ref_psnr)
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()

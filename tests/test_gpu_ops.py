@@ -291,3 +291,36 @@ def test_adan_against_reference_trajectory():
         opt.step()
         for i, p in enumerate(params):
             close(p, torch.from_numpy(npz[f"p{step + 1}/{i}"]), rtol=2e-5, atol=2e-6, msg=f"adan step {step} tensor {i}")
+
+
+def test_deferred_reductions_match_immediate(ops):
+    """Slab reductions queued with bnerv_reduce_slabs_deferred and executed by a hosting conv launch / by the flush give
+    the same sums as the immediate kernel (fixed summation order -> compare tightly), for both job layouts."""
+    import ctypes as C
+    from boosting_nerv_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    slabs = torch.randn(700, 1308, generator=g).to(DEV)          # weight-gradient sized job
+    parts = torch.randn(3600, 24, generator=g).to(DEV)           # per-tile epilogue sums
+    ref_a, ref_b = slabs.double().sum(0), parts.double().sum(0)
+    out_a, out_b = torch.empty(1308, device=DEV), torch.empty(24, device=DEV)
+    assert lib.bnerv_deferred_pending() == 0
+    L.check(lib.bnerv_reduce_slabs_deferred(L.ptr(slabs), 700, 1308, L.ptr(out_a)), "defer")
+    L.check(lib.bnerv_reduce_slabs_deferred(L.ptr(parts), 3600, 24, L.ptr(out_b)), "defer")
+    assert lib.bnerv_deferred_pending() == 2
+    # a lean conv launch hosts both jobs
+    x = torch.randn(1, 12, 64, 128, generator=g).to(DEV); w = (torch.randn(12, 12, 3, 3, generator=g) / 10).to(DEV); b = torch.randn(12, generator=g).to(DEV)
+    y = torch.empty_like(x)
+    ops._conv(x, w, b, y, B=1, Cin=12, Cout=12, H=64, W=128, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS)
+    assert lib.bnerv_deferred_pending() == 0
+    torch.testing.assert_close(y.cpu(), F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out_a.double().cpu(), ref_a.cpu(), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(out_b.double().cpu(), ref_b.cpu(), rtol=1e-5, atol=1e-3)
+    # flush path (no host launch) and the immediate kernel agree with it
+    out_c, out_d = torch.empty(1308, device=DEV), torch.empty(1308, device=DEV)
+    L.check(lib.bnerv_reduce_slabs_deferred(L.ptr(slabs), 700, 1308, L.ptr(out_c)), "defer")
+    L.check(lib.bnerv_flush_deferred(L.stream()), "flush")
+    assert lib.bnerv_deferred_pending() == 0
+    L.check(lib.bnerv_reduce_slabs(L.stream(), L.ptr(slabs), 700, 1308, L.ptr(out_d)), "reduce")
+    assert torch.equal(out_a, out_c)
+    torch.testing.assert_close(out_c, out_d, rtol=1e-5, atol=1e-4)
