@@ -124,6 +124,27 @@ def cpu_baseline(args, model_cpu_sd, frames, norm_idxs, budget_s=20.0, max_steps
             "sample": f"{n} full train steps (fwd + {args.loss} + bwd + Adan) of the same model/frame size after 1 warm-up, oracle/cpu_ref.py on torch CPU fp32"}
 
 
+def stock_rocm_yardstick(args, model_cpu_sd, frames, norm_idxs, dev, budget_s=10.0, max_steps=20):
+    """SURVEY 8(d) second yardstick: the SAME restatement (oracle/cpu_ref.py, plain torch ops) executed on the GPU by stock
+    PyTorch-ROCm (MIOpen convs, hipFFT, eager elementwise).  Reported next to the CPU baseline, never as `value`."""
+    from oracle import cpu_ref
+    sd = {k: v.clone().float().to(dev).requires_grad_(True) for k, v in model_cpu_sd.items()}
+    adan = cpu_ref.AdanState(list(sd.values()), lr=args.lr)
+    fr, ni = frames.to(dev), norm_idxs.to(dev)
+    for _ in range(3):                                      # warm-up (MIOpen solver search happens here)
+        cpu_ref.train_step(args.model, sd, adan, fr[0:1], ni[0:1], args.loss)
+    torch.cuda.synchronize()
+    n, t0 = 0, time.time()
+    while n < max_steps and (time.time() - t0) < budget_s:
+        i = (n + 1) % fr.shape[0]
+        cpu_ref.train_step(args.model, sd, adan, fr[i:i + 1], ni[i:i + 1], args.loss)
+        torch.cuda.synchronize()
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n / dt, 3), "unit": "frames/s", "kind": "oracle restatement on stock PyTorch-ROCm ops (MIOpen/hipFFT), same GPU",
+            "sample": f"{n} full train steps after 3 warm-up"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +153,7 @@ def main():
     ap.add_argument("--config", default="c1", choices=sorted(RECIPES))
     ap.add_argument("--no_graph", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--stock_rocm", action="store_true", help="also time the oracle restatement on stock PyTorch-ROCm ops (slow first run)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -208,6 +230,12 @@ def main():
             ncpu = torch.tensor([(i + 1) / r["n"] for i in keep[:4]], dtype=torch.float64)
             out["cpu_baseline"] = cpu_baseline(args, sd_cpu, fcpu, ncpu)
             out["gpu_over_cpu"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 1)
+            if a.stock_rocm:             # opt-in: on a fresh box MIOpen compiles / searches solvers for ~50 conv shapes (minutes)
+                try:
+                    torch.backends.cudnn.benchmark = False
+                    out["stock_rocm"] = stock_rocm_yardstick(args, sd_cpu, fcpu, ncpu, dev)
+                except Exception as e:   # the yardstick must never take the bench line down (e.g. MIOpen without a solver)
+                    out["stock_rocm"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
