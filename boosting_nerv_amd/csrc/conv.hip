@@ -1248,7 +1248,7 @@ extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
     if (d.ep_mode == BNERV_EP_DGELU) BNERV_REQUIRE(d.aux0 && d.scale && d.partial && d.out_s == 1, "conv_igemm: DGELU epilogue args");
     if (d.ep_mode == BNERV_EP_DSIN) BNERV_REQUIRE(d.aux0 && d.aux1 && d.scale && d.partial && d.out_s == 1, "conv_igemm: DSIN epilogue args");
     if (d.ep_mode == BNERV_EP_DGELU_SAVED) BNERV_REQUIRE(d.aux0 && d.aux1 && d.scale && d.partial && d.out_s == 1, "conv_igemm: DGELU_SAVED epilogue args");
-    if (d.ep_mode == BNERV_EP_BIAS_GELU) BNERV_REQUIRE(d.out2 && d.out_s == 1, "conv_igemm: BIAS_GELU epilogue needs out2, stride-1 output");
+    if (d.ep_mode == BNERV_EP_BIAS_GELU) BNERV_REQUIRE(d.out_s == 1, "conv_igemm: BIAS_GELU epilogue needs a stride-1 output");   // out2 NULL: gelu only
     if (d.in_mode == BNERV_IN_UNSHUFFLE && d.in_s == 1) d.in_mode = BNERV_IN_PLAIN;       // same gather, faster staging
     ka.tiles_x = cdiv(d.W, TW);
     ka.tiles_y = cdiv(d.H, TH);

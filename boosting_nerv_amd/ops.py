@@ -256,12 +256,12 @@ def conv2d_ps(x, w, b, shuffle=1):
 # ----------------------------------------------------------------------------------------------------------------------
 # TAT residual block and the fused SNeRV block
 # ----------------------------------------------------------------------------------------------------------------------
-def _tat_forward(y0, s0, t0, s1, t1, w0, b0, w1, b1):
+def _tat_forward(y0, s0, t0, s1, t1, w0, b0, w1, b1, train=True):
     B, Cc, H, W = y0.shape
     # conv0's epilogue stores h = gelu(v) and gp = gelu'(v) instead of v: conv1, its weight gradient and the dGELU epilogue of
     # the backward then run without erf/exp (v itself has no other consumer)
     h = torch.empty_like(y0)
-    gp = torch.empty_like(y0)
+    gp = torch.empty_like(y0) if train else None          # decode / eval (no_grad): gelu' is never read, so it is not written
     _conv(y0, w0, b0, h, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=s0, shift=t0, out2=gp)
     out = torch.empty_like(y0)
     _conv(h, w1, b1, out, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_RES, scale=s1, shift=t1, aux0=y0)
@@ -296,8 +296,10 @@ class _TATBlock(torch.autograd.Function):
         B, Cc = x0.shape[:2]
         s0, t0, s1, t1 = (_bc(t, B, Cc) for t in (s0, t0, s1, t1))
         w0, b0, w1, b1 = (L.f32c(t) for t in (w0, b0, w1, b1))
-        h, gp, out = _tat_forward(x0, s0, t0, s1, t1, w0, b0, w1, b1)
-        ctx.save_for_backward(x0, h, gp, s0, t0, s1, t1, w0, w1)
+        train = any(ctx.needs_input_grad)                   # False under torch.no_grad(): the decode path keeps nothing for backward
+        h, gp, out = _tat_forward(x0, s0, t0, s1, t1, w0, b0, w1, b1, train)
+        if train:
+            ctx.save_for_backward(x0, h, gp, s0, t0, s1, t1, w0, w1)
         ctx.mshape = (B, Cc, 1, 1)
         return out
 
@@ -326,11 +328,13 @@ class _SNeRVBlock(torch.autograd.Function):
         s = stride
         Cc = Ct // (s * s)
         s0, t0, s1, t1 = (_bc(t, B, Cc) for t in (s0, t0, s1, t1))
+        train = any(ctx.needs_input_grad)                   # False under torch.no_grad(): decode path, nothing saved
         y0 = torch.empty(B, Cc, H * s, W * s, dtype=torch.float32, device=x.device)
-        c0 = torch.empty_like(y0)
+        c0 = torch.empty_like(y0) if train else None
         _conv(x, wu, bu, y0, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_SIN, out_s=s, out2=c0)
-        h, gp, out = _tat_forward(y0, s0, t0, s1, t1, w0, b0, w1, b1)
-        ctx.save_for_backward(x, y0, c0, h, gp, s0, t0, s1, t1, wu, w0, w1)
+        h, gp, out = _tat_forward(y0, s0, t0, s1, t1, w0, b0, w1, b1, train)
+        if train:
+            ctx.save_for_backward(x, y0, c0, h, gp, s0, t0, s1, t1, wu, w0, w1)
         ctx.s, ctx.has_bu, ctx.mshape = s, bu is not None, (B, Cc, 1, 1)
         return out
 

@@ -131,7 +131,7 @@ int bnerv_deferred_pending(void);
 #define BNERV_EP_PLAIN 4         /* out = v */
 #define BNERV_EP_DGELU 5         /* out = v*(1+scale[b,c])*gelu'(aux0);   partial: ds += v*gelu(aux0), dt += v */
 #define BNERV_EP_DSIN 6          /* t = aux1 + v*(1+scale[b,c]); out = t*aux2 (aux2 NULL: 1); partial: ds += v*aux0, dt += v */
-#define BNERV_EP_BIAS_GELU 7     /* u = v + bias; out = gelu(u); out2 = gelu'(u)   (the TAT block saves both instead of u: the three
+#define BNERV_EP_BIAS_GELU 7     /* u = v + bias; out = gelu(u); out2 = gelu'(u) (out2 may be NULL: decode)  (the TAT block saves both instead of u: the three
                                     consumers -- next conv, its weight gradient, the dGELU epilogue -- then need no erf/exp) */
 #define BNERV_EP_DGELU_SAVED 8   /* out = v*(1+scale[b,c])*aux0 (aux0 = saved gelu');  partial: ds += v*aux1 (aux1 = saved gelu), dt += v */
 
