@@ -410,16 +410,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const KArgs ka) {
 
     const int qstride = ka.w_resident ? ka.nq_total : NQ;
     const bool vec_in = ka.vec && (IN != BNERV_IN_UNSHUFFLE || d.in_s == 2);
-    const bool piped = vec_in && Cin <= CC;               // one K chunk: software-pipelined path
-    const int nch1 = ((min(Cin, CC) + 3) >> 2) * 4;       // staged channels of the single chunk
+    // Software pipeline over (item, K chunk) stages whenever the float4 staging applies: the global loads of stage s+1 are
+    // issued into registers before the MFMA phase of stage s and committed to LDS after it (one s_in buffer, two LDS-only
+    // barriers per stage), so neither the chunks of one tile nor consecutive tiles expose their load latency.
+    const bool piped = vec_in;
+    auto chunk_begin = [&](const Item& i) { return ka.ksplit > 1 ? i.ks * ka.chunks_per_split * CC : 0; };
+    auto chunk_end = [&](const Item& i) { return ka.ksplit > 1 ? min(Cin, chunk_begin(i) + ka.chunks_per_split * CC) : Cin; };
+    auto chunk_nch = [&](int c0, int c_end) { return ((min(CC, c_end - c0) + 3) >> 2) * 4; };
     VecStage<KS, IN> vs;
     int cur_g = -1;
 
     int itx = r0 + lb;
     if (itx < r1 && piped) {
         const Item it = decode_item(ka, itx);
-        vs.issue(d, it.b, 0, nch1, it.ty0, it.tx0);
-        vs.commit(d, s_in, it.b, 0, nch1, it.ty0, it.tx0);
+        const int c0 = chunk_begin(it);
+        vs.issue(d, it.b, c0, chunk_nch(c0, chunk_end(it)), it.ty0, it.tx0);
+        vs.commit(d, s_in, it.b, c0, chunk_nch(c0, chunk_end(it)), it.ty0, it.tx0);
     }
     for (; itx < r1; itx += nlb) {
         const Item it = decode_item(ka, itx);
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const KArgs ka) {
             for (int n = 0; n < NTB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         if (ka.w_resident && cur_g != it.g) {
-            __syncthreads();                               // nobody still reads the previous group's fragments
+            lds_barrier();                                 // nobody still reads the previous group's fragments
             stage_weights<KS, NTB>(d, s_w, co_base, 0, ka.nq_total, qstride);
             cur_g = it.g;
         }
@@ -439,20 +445,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const KArgs ka) {
         Item nxt = it;
         if (has_next) nxt = decode_item(ka, itx + nlb);
 
-        const int c_begin = ka.ksplit > 1 ? it.ks * ka.chunks_per_split * CC : 0;
-        const int c_end = ka.ksplit > 1 ? min(Cin, c_begin + ka.chunks_per_split * CC) : Cin;
+        const int c_begin = chunk_begin(it), c_end = chunk_end(it);
         for (int c0 = c_begin; c0 < c_end; c0 += CC) {
             const int cc = min(CC, Cin - c0);
             const int nq = (cc + 3) >> 2;
             const int q0 = c0 >> 2;
+            const bool last_chunk = c0 + CC >= c_end;
             if (!piped) {
                 __syncthreads();                           // previous chunk / tile fully consumed
                 if (vec_in) { vs.issue(d, it.b, c0, nq * 4, it.ty0, it.tx0); vs.commit(d, s_in, it.b, c0, nq * 4, it.ty0, it.tx0); }
                 else stage_scalar<KS, IN>(d, s_in, it.b, c0, nq * 4, it.ty0, it.tx0);
             }
-            if (!ka.w_resident) stage_weights<KS, NTB>(d, s_w, co_base, q0, nq, qstride);
-            __syncthreads();
-            if (piped && has_next) vs.issue(d, nxt.b, 0, nch1, nxt.ty0, nxt.tx0);      // flies under the MFMA phase
+            if (!ka.w_resident) stage_weights<KS, NTB>(d, s_w, co_base, q0, nq, qstride);   // (after the previous stage's barrier B)
+            lds_barrier();                                 // (A) this stage's s_in / s_w visible
+            if (piped) {                                   // next stage's loads fly under the MFMA phase
+                if (!last_chunk) vs.issue(d, it.b, c0 + CC, chunk_nch(c0 + CC, c_end), it.ty0, it.tx0);
+                else if (has_next) vs.issue(d, nxt.b, chunk_begin(nxt), chunk_nch(chunk_begin(nxt), chunk_end(nxt)), nxt.ty0, nxt.tx0);
+            }
             const int qb = ka.w_resident ? q0 : 0;
 #pragma unroll
             for (int tap = 0; tap < G::T; ++tap) {
@@ -470,24 +479,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const KArgs ka) {
                             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[n], acc[m][n], 0, 0, 0);
                 }
             }
+            if (piped && !last_chunk) {
+                lds_barrier();                             // (B) every wave is done reading this chunk
+                vs.commit(d, s_in, it.b, c0 + CC, chunk_nch(c0 + CC, c_end), it.ty0, it.tx0);
+            }
         }
 
         // ---- epilogue, one cout-tile at a time through s_out (D layout: lane holds pixels 4*kq..4*kq+3 of cout li) ----
 #pragma unroll
         for (int n = 0; n < NTB; ++n) {
             if (co_base + n * 16 < d.Cout) {
-                if (n > 0) __syncthreads();                // previous cout-tile copied out
+                if (n > 0) lds_barrier();                  // previous cout-tile copied out
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const int py = 2 * wave + (m >> 1), px = (m & 1) * 16 + 4 * kq;
                     *reinterpret_cast<f32x4*>(&s_out[li * CS + py * TW + px]) = acc[m][n];
                 }
-                __syncthreads();                           // s_out complete; every wave is also done reading s_in / s_w(chunk)
-                if (n == 0 && piped && has_next) vs.commit(d, s_in, nxt.b, 0, nch1, nxt.ty0, nxt.tx0);
+                lds_barrier();                             // s_out complete; every wave is also done reading s_in / s_w(chunk)
+                if (n == 0 && piped && has_next)
+                    vs.commit(d, s_in, nxt.b, chunk_begin(nxt), chunk_nch(chunk_begin(nxt), chunk_end(nxt)), nxt.ty0, nxt.tx0);
                 copy_out_tile<EP>(ka, s_out, it, co_base + n * 16);
             }
         }
-        __syncthreads();                                   // s_out free for the next item; s_in(next) visible
+        lds_barrier();                                     // s_out free for the next item; s_in(next) visible
     }
 }
 
