@@ -20,6 +20,7 @@
 //
 // MS-SSIM follows pytorch_msssim 0.2.1 (third-party; PARITY UNPINNED).
 #include "common.h"
+#include <vector>
 #include <math.h>
 #include <map>
 #include <mutex>
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(256) void ssim_bwd_from_g_kernel(const SsimArgs a) 
 // mixed-radix FFT in LDS
 // =====================================================================================================================
 constexpr int MAXRAD = 16;
-struct FftPlan { int N, nrad; int rad[MAXRAD]; const float2* tw; };   // tw[k] = exp(-2*pi*i*k/N)
+struct FftPlan { int N, nrad; int rad[MAXRAD]; const float2* tw; const int* pos; };   // tw[k] = exp(-2*pi*i*k/N)
+// pos[f] = buffer position that holds frequency f after the in-place DIF forward (mixed-radix digit reversal)
 
 std::mutex g_tw_mutex;
 std::map<int, float2*> g_tw;
@@ -337,6 +339,31 @@ static const float2* get_twiddles(int N) {
     return d;
 }
 
+std::map<int, int*> g_pos;
+// forward DIF with radices [R, rest] on size Ns: frequency k = q + R*k' ends up in sub-block q (size M = Ns/R) at the position
+// the rest of the plan gives k'  =>  pos(k) = (k % R) * M + pos_rest(k / R)
+static const int* get_positions(const FftPlan& pl) {
+    std::lock_guard<std::mutex> lk(g_tw_mutex);
+    auto it = g_pos.find(pl.N);
+    if (it != g_pos.end()) return it->second;
+    std::vector<int> h(pl.N);
+    for (int f = 0; f < pl.N; ++f) {
+        int k = f, Ns = pl.N, p = 0;
+        for (int st = 0; st < pl.nrad; ++st) {
+            const int R = pl.rad[st], M = Ns / R;
+            p += (k % R) * M;
+            k /= R;
+            Ns = M;
+        }
+        h[f] = p;
+    }
+    int* d = nullptr;
+    if (hipMalloc(&d, sizeof(int) * pl.N) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), sizeof(int) * pl.N, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    g_pos[pl.N] = d;
+    return d;
+}
+
 static bool make_plan(int N, FftPlan* p) {
     p->N = N; p->nrad = 0;
     int n = N;
@@ -350,7 +377,8 @@ static bool make_plan(int N, FftPlan* p) {
     if (n != 1 || p->nrad >= MAXRAD) return false;
     if (N == 1) { p->nrad = 0; }
     p->tw = get_twiddles(N);
-    return p->tw != nullptr;
+    p->pos = get_positions(*p);
+    return p->tw != nullptr && p->pos != nullptr;
 }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return float2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
@@ -359,32 +387,59 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return float2{a.x 
 // One butterfly of radix R at sub-transform size Ns (M = Ns/R) on the in-place buffer.
 //  forward (DIF):  y_q = w_Ns^{jq} * sum_m x_m w_R^{mq}             x_m = buf[base+m*M], y_q -> buf[base+q*M]
 //  adjoint      :  x_m = sum_q conj(w_R^{mq}) conj(w_Ns^{jq}) y_q   (exact conjugate transpose of the forward stage)
+// Radix 2/3/4/5 cores use the closed forms (adds, +-i swaps, two or four real constants): the kernels are instruction-bound, and
+// a table-driven core costs ~300 instructions per radix-4 butterfly against ~50 here.  SGN = -1 forward, +1 adjoint: the
+// adjoint core is the forward core with i -> -i, i.e. the exact conjugate transpose with the same constants.
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return float2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return float2{a.x - b.x, a.y - b.y}; }
+template <int SGN> __device__ __forceinline__ float2 mul_i(float2 a) { return SGN > 0 ? float2{-a.y, a.x} : float2{a.y, -a.x}; }   // (SGN*i) * a
+
+template <int R, int SGN>
+__device__ __forceinline__ void dft_core(const float2 (&v)[R], float2 (&o)[R]) {
+    if constexpr (R == 2) {
+        o[0] = cadd(v[0], v[1]);
+        o[1] = csub(v[0], v[1]);
+    } else if constexpr (R == 4) {
+        const float2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), dd = mul_i<SGN>(csub(v[1], v[3]));
+        o[0] = cadd(a, c); o[2] = csub(a, c); o[1] = cadd(b, dd); o[3] = csub(b, dd);
+    } else if constexpr (R == 3) {
+        constexpr float C = 0.86602540378443864676f;                       // sin(2 pi / 3)
+        const float2 sum = cadd(v[1], v[2]), t = mul_i<SGN>(csub(v[1], v[2]));
+        const float2 h = float2{v[0].x - 0.5f * sum.x, v[0].y - 0.5f * sum.y};
+        o[0] = cadd(v[0], sum);
+        o[1] = float2{h.x + C * t.x, h.y + C * t.y};
+        o[2] = float2{h.x - C * t.x, h.y - C * t.y};
+    } else {                                                               // R == 5
+        constexpr float C1 = 0.30901699437494742410f, C2 = -0.80901699437494742410f;   // cos(2 pi / 5), cos(4 pi / 5)
+        constexpr float S1 = 0.95105651629515357212f, S2 = 0.58778525229247312917f;    // sin(2 pi / 5), sin(4 pi / 5)
+        const float2 s1 = cadd(v[1], v[4]), s2 = cadd(v[2], v[3]), d1 = csub(v[1], v[4]), d2 = csub(v[2], v[3]);
+        const float2 a1 = float2{v[0].x + C1 * s1.x + C2 * s2.x, v[0].y + C1 * s1.y + C2 * s2.y};
+        const float2 a2 = float2{v[0].x + C2 * s1.x + C1 * s2.x, v[0].y + C2 * s1.y + C1 * s2.y};
+        const float2 b1 = mul_i<SGN>(float2{S1 * d1.x + S2 * d2.x, S1 * d1.y + S2 * d2.y});
+        const float2 b2 = mul_i<SGN>(float2{S2 * d1.x - S1 * d2.x, S2 * d1.y - S1 * d2.y});
+        o[0] = float2{v[0].x + s1.x + s2.x, v[0].y + s1.y + s2.y};
+        o[1] = cadd(a1, b1); o[4] = csub(a1, b1); o[2] = cadd(a2, b2); o[3] = csub(a2, b2);
+    }
+}
+
 template <int R, bool ADJ>
 __device__ __forceinline__ void butterfly(float2* buf, int base, int M, int j, int tstride /* N/Ns */, const FftPlan& pl, const float2* tw) {
-    float2 v[R], o[R], wr[R];
-    const int rstep = pl.N / R;
+    float2 v[R], o[R];
+    (void)pl;
 #pragma unroll
-    for (int k = 0; k < R; ++k) wr[k] = tw[rstep * k];
-#pragma unroll
-    for (int m = 0; m < R; ++m) v[m] = buf[base + m * M];
+    for (int m = 0; m < R; ++m) v[m] = buf[base + __mul24(m, M)];
+    const int t1 = __mul24(tstride, j);                   // j < Ns/R: t1 * q < N for q < R, no wrap
     if (ADJ) {
 #pragma unroll
-        for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], tw[tstride * j * q]);      // j < Ns/R: tstride * j * q < N, no wrap
+        for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], tw[t1 * q]);
+        dft_core<R, +1>(v, o);
+    } else {
+        dft_core<R, -1>(v, o);
+#pragma unroll
+        for (int q = 1; q < R; ++q) o[q] = cmul(o[q], tw[t1 * q]);
     }
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
-        float2 s = v[0];
-#pragma unroll
-        for (int m = 1; m < R; ++m) s = ADJ ? float2{s.x + cmulc(v[m], wr[(m * q) % R]).x, s.y + cmulc(v[m], wr[(m * q) % R]).y}
-                                            : float2{s.x + cmul(v[m], wr[(m * q) % R]).x, s.y + cmul(v[m], wr[(m * q) % R]).y};
-        o[q] = s;
-    }
-    if (!ADJ) {
-#pragma unroll
-        for (int q = 1; q < R; ++q) o[q] = cmul(o[q], tw[tstride * j * q]);
-    }
-#pragma unroll
-    for (int q = 0; q < R; ++q) buf[base + q * M] = o[q];
+    for (int q = 0; q < R; ++q) buf[base + __mul24(q, M)] = o[q];
 }
 
 // generic radix (primes 7..31): O(R^2) with the table, operands staged in registers one output at a time
@@ -412,10 +467,14 @@ __device__ void butterfly_generic(float2* buf, int base, int M, int j, int tstri
 template <bool ADJ>
 __device__ void fft_stage(float2* buf, int nlines, int lstride, int Ns, int R, const FftPlan& pl, const float2* tw) {
     const int N = pl.N, M = Ns / R, per_line = N / R, tstride = N / Ns;
+    // index split by reciprocal multiplication (operands < 2^20, quotients < 2^11: the +0.5 margin dwarfs the rounding error) and
+    // 24-bit multiplies: a runtime integer division costs ~40 instructions and a 32-bit multiply issues at quarter rate, and this
+    // loop is instruction-latency bound (a few butterflies per thread per stage, one block per CU)
+    const float inv_pl = 1.0f / (float)per_line, inv_M = 1.0f / (float)M;
     for (int bf = threadIdx.x; bf < nlines * per_line; bf += blockDim.x) {
-        const int line = bf / per_line, rem = bf - line * per_line;
-        const int blk = rem / M, j = rem - blk * M;
-        const int base = line * lstride + blk * Ns + j;
+        const int line = (int)(((float)bf + 0.5f) * inv_pl), rem = bf - __mul24(line, per_line);
+        const int blk = (int)(((float)rem + 0.5f) * inv_M), j = rem - __mul24(blk, M);
+        const int base = __mul24(line, lstride) + __mul24(blk, Ns) + j;
         switch (R) {
             case 2: butterfly<2, ADJ>(buf, base, M, j, tstride, pl, tw); break;
             case 3: butterfly<3, ADJ>(buf, base, M, j, tstride, pl, tw); break;
@@ -441,11 +500,13 @@ __device__ void fft_adjoint(float2* buf, int nlines, int lstride, const FftPlan&
 }
 
 constexpr int ROWS_PER_BLOCK = 2;
-constexpr int COLS_PER_BLOCK = 8;
+constexpr int COLS_PER_BLOCK = 4;
 
 struct FftArgs {
     const float* pred; const float* target;
-    float2* T;            // [BC][H][W] complex workspace
+    float2* T;            // [BC][H][Wh] complex workspace: the input is real, so only the Wh = W/2 + 1 non-redundant columns of the
+                          // row transform are kept (natural frequency order); the others are their conjugate mirrors
+    int Wh;
     float* partial;       // [BC][ncolblk]
     float* grad;          // [BC][H][W]
     int BC, H, W;
@@ -480,14 +541,18 @@ __global__ __launch_bounds__(256) void fft_rows_fwd_kernel(const FftArgs a) {
     }
     __syncthreads();
     fft_forward(buf, nl, W, a.prow, tw);
-    for (int i = threadIdx.x; i < nl * W; i += blockDim.x) a.T[row0 * W + i] = buf[i];
+    const int Wh = a.Wh;
+    for (int i = threadIdx.x; i < nl * Wh; i += blockDim.x) {
+        const int line = i / Wh, f = i - line * Wh;
+        a.T[(row0 + line) * Wh + f] = buf[line * W + a.prow.pos[f]];
+    }
 }
 
 __global__ __launch_bounds__(256) void fft_cols_kernel(const FftArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float2* buf = reinterpret_cast<float2*>(sm);                          // [COLS_PER_BLOCK][H]
     __shared__ float red[4];
-    const int H = a.H, W = a.W, bc = blockIdx.y;
+    const int H = a.H, W = a.Wh, bc = blockIdx.y;                          // W: kept columns (half spectrum)
     const int v0 = blockIdx.x * COLS_PER_BLOCK;
     const int nc = min(COLS_PER_BLOCK, W - v0);
     float2* T = a.T + (size_t)bc * H * W;
@@ -513,7 +578,9 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const FftArgs a) {
     float acc = 0.f;
     for (int i = threadIdx.x; i < H * nc; i += blockDim.x) {
         const float2 f = buf[i];           // lines are contiguous: nc*H elements
-        acc += fabsf(f.x) + fabsf(f.y);
+        const int col = v0 + i / H;        // a kept column stands for itself and for its mirror W_full - col, unless it is its own mirror
+        const float wgt = (col == 0 || 2 * col == a.W) ? 1.f : 2.f;
+        acc += wgt * (fabsf(f.x) + fabsf(f.y));
         buf[i] = float2{(f.x > 0.f) ? 1.f : ((f.x < 0.f) ? -1.f : 0.f), (f.y > 0.f) ? 1.f : ((f.y < 0.f) ? -1.f : 0.f)};
     }
     acc = wave_sum(acc);
@@ -537,17 +604,22 @@ __global__ __launch_bounds__(256) void fft_rows_adj_kernel(const FftArgs a) {
     const int nl = (int)min((size_t)ROWS_PER_BLOCK, nrows - row0);
     float2* tw = buf + ROWS_PER_BLOCK * W;
     load_twiddles(tw, a.prow);
-    for (int i0 = threadIdx.x; i0 < nl * W; i0 += blockDim.x * 8) {
+    const int Wh = a.Wh;
+    for (int i0 = threadIdx.x; i0 < nl * Wh; i0 += blockDim.x * 8) {      // kept columns + their conjugate mirrors, into DIF order
         float2 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = i0 + u * blockDim.x;
-            v[u] = i < nl * W ? a.T[row0 * W + i] : float2{0.f, 0.f};
+            v[u] = i < nl * Wh ? a.T[row0 * Wh + i] : float2{0.f, 0.f};
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = i0 + u * blockDim.x;
-            if (i < nl * W) buf[i] = v[u];
+            if (i < nl * Wh) {
+                const int line = i / Wh, f = i - line * Wh;
+                buf[line * W + a.prow.pos[f]] = v[u];
+                if (f > 0 && 2 * f != W) buf[line * W + a.prow.pos[W - f]] = float2{v[u].x, -v[u].y};
+            }
         }
     }
     __syncthreads();
@@ -648,8 +720,8 @@ static WsLayout make_layout(int B, int C, int H, int W, bool use_ms, bool use_ff
         L.coef = take(BC * LV);
     }
     if (use_fft) {
-        L.ncolblk = cdiv(W, COLS_PER_BLOCK);
-        L.T = take(BC * H * W * 2);
+        L.ncolblk = cdiv(W / 2 + 1, COLS_PER_BLOCK);
+        L.T = take(BC * H * (size_t)(W / 2 + 1) * 2);
         L.fft_part = take(BC * L.ncolblk);
     }
     L.total = off;
@@ -755,7 +827,7 @@ extern "C" int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* dp) {
         FftArgs a{};
         if (!make_plan(d.W, &a.prow) || !make_plan(d.H, &a.pcol))
             return bnerv_set_error(BNERV_E_ARG, "loss: FFT size %dx%d has a prime factor > %d", d.H, d.W, BNERV_FFT_MAX_RADIX);
-        a.pred = d.pred; a.target = d.target; a.T = reinterpret_cast<float2*>(ws + L.T); a.partial = ws + L.fft_part; a.grad = d.grad;
+        a.pred = d.pred; a.target = d.target; a.T = reinterpret_cast<float2*>(ws + L.T); a.Wh = d.W / 2 + 1; a.partial = ws + L.fft_part; a.grad = d.grad;
         a.BC = BC; a.H = d.H; a.W = d.W; a.gscale = d.c_fft / ((float)d.B * (float)nps * 2.0f); a.accumulate = 1;
         const size_t lds_row = (size_t)(ROWS_PER_BLOCK + 1) * d.W * sizeof(float2), lds_col = (size_t)(COLS_PER_BLOCK + 1) * d.H * sizeof(float2);   // + twiddle table
         BNERV_REQUIRE(lds_row <= 160 * 1024 && lds_col <= 160 * 1024, "loss: frame %dx%d too large for the LDS FFT", d.H, d.W);
