@@ -91,6 +91,9 @@ SYMBOLS = {
     "bnerv_conv_partial_rows": (_I, [C.POINTER(ConvDesc)]),
     "bnerv_conv_wgrad_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bnerv_conv_wgrad": (_I, [_V, C.POINTER(WgradDesc)]),
+    "bnerv_dwconv_fwd": (_I, [_V, _V, _V, _V, _V, _I, _I, _I, _I, _I, _I]),
+    "bnerv_dwconv_wgrad_ws_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "bnerv_dwconv_wgrad": (_I, [_V, _V, _V, _V, _V, _Z, _I, _I, _I, _I, _I, _I]),
     "bnerv_loss_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bnerv_fft_prepare": (_I, [_I, _I]),
     "bnerv_loss_fwd_bwd": (_I, [_V, C.POINTER(LossDesc)]),

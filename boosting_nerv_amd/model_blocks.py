@@ -323,7 +323,10 @@ class Block(nn.Module):
 
     def forward(self, x):
         inp = x
-        x = self.dwconv(x).permute(0, 2, 3, 1)
+        if x.is_cuda:        # HIP depthwise kernels (row N3); MIOpen only has its naive fp32 fallback for these shapes
+            x = ops.dwconv(x, self.dwconv.weight, self.dwconv.bias).permute(0, 2, 3, 1)
+        else:
+            x = self.dwconv(x).permute(0, 2, 3, 1)
         x = self.pwconv2(self.act(self.pwconv1(self.norm(x))))
         if self.gamma is not None:
             x = self.gamma * x
@@ -359,5 +362,21 @@ class ConvNeXt(nn.Module):
 
     def forward(self, x):
         for i in range(self.stage_num):
-            x = self.stages[i](self.downsample_layers[i](x))
+            for m in self.downsample_layers[i]:
+                x = patchify_conv(x, m) if isinstance(m, nn.Conv2d) else m(x)
+            x = self.stages[i](x)
         return x
+
+
+def patchify_conv(x, conv):
+    """nn.Conv2d with kernel_size == stride and no padding (every ConvNeXt down-sampling layer, model_blocks.py:250-262 of the
+    reference) as a GEMM over non-overlapping patches: im2col is a pure reshape here.  Same parameters / state_dict; on ROCm this
+    replaces MIOpen's naive fp32 fallback for these shapes by rocBLAS."""
+    s = conv.stride[0]
+    if conv.kernel_size != (s, s) or conv.stride != (s, s) or conv.padding != (0, 0) or conv.groups != 1 or conv.dilation != (1, 1):
+        return conv(x)
+    B, C, H, W = x.shape
+    Ho, Wo = H // s, W // s
+    xp = x[:, :, :Ho * s, :Wo * s].reshape(B, C, Ho, s, Wo, s).permute(0, 2, 4, 1, 3, 5).reshape(B * Ho * Wo, C * s * s)
+    y = F.linear(xp, conv.weight.reshape(conv.out_channels, C * s * s), conv.bias)
+    return y.reshape(B, Ho, Wo, conv.out_channels).permute(0, 3, 1, 2)

@@ -434,6 +434,47 @@ def head_tanh(x, w, b):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# depthwise conv of the ConvNeXt encoder block (first kernels of row N3)
+# ----------------------------------------------------------------------------------------------------------------------
+class _DWConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = L.f32c(L.require_device(x, "x")); w = L.f32c(w); b = None if b is None else L.f32c(b)
+        B, Cc, H, W = x.shape
+        K = w.shape[-1]
+        assert w.shape == (Cc, 1, K, K), w.shape
+        y = torch.empty_like(x)
+        L.check(L.load().bnerv_dwconv_fwd(L.stream(), L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, Cc, H, W, K, 0), "bnerv_dwconv_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = L.f32c(g)
+        B, Cc, H, W = x.shape
+        K = w.shape[-1]
+        lib = L.load()
+        nbytes = lib.bnerv_dwconv_wgrad_ws_bytes(B, Cc, H, W, K)
+        ws = _ws(nbytes, x.device)
+        dwb = torch.empty(Cc, K * K + 1, dtype=torch.float32, device=x.device)
+        L.check(lib.bnerv_dwconv_wgrad(L.stream(), L.ptr(x), L.ptr(g), L.ptr(dwb), L.ptr(ws), nbytes, B, Cc, H, W, K, 0), "bnerv_dwconv_wgrad")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.check(lib.bnerv_dwconv_fwd(L.stream(), L.ptr(g), L.ptr(w), None, L.ptr(dx), B, Cc, H, W, K, 1), "bnerv_dwconv_fwd(flip)")
+        dw = dwb[:, :K * K].reshape(Cc, 1, K, K)
+        db = dwb[:, K * K] if ctx.has_b else None
+        return dx, dw, db
+
+
+def dwconv(x, w, b):
+    """F.conv2d(x, w, b, padding=K//2, groups=C) for w [C,1,K,K], K odd <= 7 (ConvNeXt Block.dwconv, model_blocks.py:231)."""
+    return _DWConv.apply(x, w, b)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # loss / metrics
 # ----------------------------------------------------------------------------------------------------------------------
 LOSS_COEFFS = {            # (c_l1, c_l2, c_ms, c_fft) per hnerv_utils.py:338-385

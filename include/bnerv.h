@@ -196,6 +196,16 @@ int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* d);
 
 #define BNERV_LOSS_STATS 5
 /* ------------------------------------------------------------------------------------------------------------------
+ * Depthwise KxK convolution (K odd <= 7, stride 1, padding K/2) of the ConvNeXt encoder block of HNeRV_Boost
+ * (model_blocks.py:223-247: nn.Conv2d(dim, dim, 7, padding=3, groups=dim)); first kernels of SURVEY 8(f) row N3.
+ *   bnerv_dwconv_fwd(flip=0): y = conv(x, w) + bias;   flip=1: the data gradient (taps flipped, bias ignored: pass g as x)
+ *   bnerv_dwconv_wgrad: dwb[C][K*K+1] = weight gradient rows with the bias gradient in the last column (slabs in ws;
+ *   defer=1 queues the slab reduction, see bnerv_reduce_slabs_deferred).  x, y, g: [B, C, H, W];  w: [C, 1, K, K]. */
+int bnerv_dwconv_fwd(void* stream, const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W, int K, int flip);
+size_t bnerv_dwconv_wgrad_ws_bytes(int B, int C, int H, int W, int K);
+int bnerv_dwconv_wgrad(void* stream, const float* x, const float* g, float* dwb, void* ws, size_t ws_bytes, int B, int C, int H, int W, int K, int defer);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Loss and metrics.  Replaces loss_fn (hnerv_utils.py:335-397; variants L1, L2, L1_freq, Fusion10, Fusion10_freq)
  * including its autograd backward, and psnr_fn_single (hnerv_utils.py:400-403).
  *   loss_b = c_l1 * mean|d| + c_l2 * mean d^2 + c_ms * (1 - ms_ssim_b) + c_fft * mean|FFT2(pred)-FFT2(target)|_{re,im}

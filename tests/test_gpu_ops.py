@@ -324,3 +324,21 @@ def test_deferred_reductions_match_immediate(ops):
     L.check(lib.bnerv_reduce_slabs(L.stream(), L.ptr(slabs), 700, 1308, L.ptr(out_d)), "reduce")
     assert torch.equal(out_a, out_c)
     torch.testing.assert_close(out_c, out_d, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 23, 70, 7), (1, 64, 36, 64, 7), (1, 3, 9, 16, 3), (2, 4, 17, 33, 5)])
+def test_dwconv_fwd_bwd(ops, shape):
+    """Depthwise KxK conv of the ConvNeXt encoder block against F.conv2d(groups=C): output, dx, dw, db."""
+    B, C, H, W, K = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, C, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(C, 1, K, K, generator=g) / K).requires_grad_(True)
+    b = torch.randn(C, generator=g).requires_grad_(True)
+    ref = F.conv2d(x, w, b, padding=K // 2, groups=C)
+    cot = torch.randn(ref.shape, generator=g)
+    rg = torch.autograd.grad(ref, [x, w, b], cot)
+    xg, wg, bg = gpu(x), gpu(w), gpu(b)
+    out = ops.dwconv(xg, wg, bg)
+    close(out, ref, msg="dwconv fwd")
+    for n, a, r in zip("xwb", torch.autograd.grad(out, [xg, wg, bg], cot.to(DEV)), rg):
+        close(a, r, msg=f"dwconv d{n}")
