@@ -214,32 +214,38 @@ struct VecStage {
 };
 
 // B fragments: lane (j = l&15, kq = l>>4) <- W(co_base+16n+j, 4*(q0+q)+kq, tap)
+// A fragment row r = (tap, q, n) is 64 consecutive elements = one wave's worth, so its decomposition is WAVE-UNIFORM: it is
+// done once per row in scalar registers (the layers whose weights do not stay resident restage per K chunk per tile, and with
+// per-element runtime divisions this cost as many instructions as the chunk's MFMAs).  8 gathers in flight per thread.
 template <int KS, int NTB>
 __device__ __forceinline__ void stage_weights(const bnerv_conv_desc& d, float* s_w, int co_base, int q0, int nq, int qstride) {
     using G = Geo<KS>;
-    const int n_el = G::T * nq * NTB * 64;
-    for (int i0 = threadIdx.x; i0 < n_el; i0 += 256 * 8) {   // 8 gathers in flight per thread, then the LDS stores
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int n_rows = G::T * nq * NTB;
+    const float inv_nq = 1.0f / (float)nq;
+    // per-lane element offset of (co = co_base + li, ci = 4 q0 + kq) at tap 0; the row adds (16 n, 4 q, tap)
+    const int co_l = co_base + li, ci_l = q0 * 4 + kq;
+    const int lane_off = d.transposed ? (ci_l * d.wCi + co_l) * G::T : (co_l * d.wCi + ci_l) * G::T;
+    const int co_step = d.transposed ? G::T : d.wCi * G::T;          // element stride of +1 cout
+    const int ci_step = d.transposed ? d.wCi * G::T : G::T;          // element stride of +1 cin
+    for (int r0 = wave; r0 < n_rows; r0 += 4 * 8) {
         float v[8];
         int dst[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int idx = i0 + u * 256;
-            const int l = idx & 63;
-            int rest = idx >> 6;
-            const int n = rest % NTB; rest /= NTB;
-            const int q = rest % nq;
-            const int tap = rest / nq;
-            const int co = co_base + n * 16 + (l & 15), ci = (q0 + q) * 4 + (l >> 4);
+            const int r = r0 + 4 * u;                                // uniform
+            const int tq = r / NTB, n = r - tq * NTB;                // NTB is a compile-time constant
+            const int tap = (int)(((float)tq + 0.5f) * inv_nq), q = tq - tap * nq;
+            const int co = co_l + 16 * n, ci = ci_l + 4 * q;
             v[u] = 0.f;
-            if (idx < n_el && co < d.Cout && ci < d.Cin) {
-                v[u] = d.transposed ? d.w[((size_t)ci * d.wCi + co) * G::T + (G::T - 1 - tap)]
-                                    : d.w[((size_t)co * d.wCi + ci) * G::T + tap];
-            }
-            dst[u] = ((tap * qstride + q) * NTB + n) * 64 + l;
+            if (r < n_rows && co < d.Cout && ci < d.Cin)
+                v[u] = d.w[lane_off + 16 * n * co_step + 4 * q * ci_step + (d.transposed ? G::T - 1 - tap : tap)];
+            dst[u] = ((tap * qstride + q) * NTB + n) * 64 + lane;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (i0 + u * 256 < n_el) s_w[dst[u]] = v[u];
+            if (r0 + 4 * u < n_rows) s_w[dst[u]] = v[u];
     }
 }
 
