@@ -232,3 +232,24 @@ def test_dp_mean_of_per_rank_grads_equals_batch_grad_oracle():
     g0, g1 = grads(frame[:1], norm_idx[:1]), grads(frame[1:], norm_idx[1:])
     for k in gb:
         torch.testing.assert_close(gb[k], 0.5 * (g0[k] + g1[k]), rtol=1e-4, atol=1e-7)
+
+
+def test_patchify_conv_equals_conv2d():
+    """kernel == stride convs of the ConvNeXt encoder as reshape + GEMM: same values and gradients as nn.Conv2d (incl. a
+    spatial size that is not a multiple of the stride); other conv geometries fall through to the module."""
+    import torch.nn as nn
+    from boosting_nerv_amd.model_blocks import patchify_conv
+    torch.manual_seed(3)
+    for (C, Co, s, H, W) in ((3, 8, 5, 20, 37), (8, 8, 3, 9, 12), (8, 4, 2, 7, 8)):
+        conv = nn.Conv2d(C, Co, s, stride=s)
+        x = torch.randn(2, C, H, W, requires_grad=True)
+        a, b = conv(x), patchify_conv(x, conv)
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-5)
+        cot = torch.randn_like(a)
+        ga = torch.autograd.grad(a, [x, conv.weight, conv.bias], cot)
+        gb = torch.autograd.grad(b, [x, conv.weight, conv.bias], cot)
+        for u, v in zip(ga, gb):
+            torch.testing.assert_close(v, u, rtol=1e-4, atol=1e-5)
+    other = nn.Conv2d(4, 4, 3, stride=1, padding=1)
+    x = torch.randn(1, 4, 6, 6)
+    assert torch.equal(patchify_conv(x, other), other(x))
