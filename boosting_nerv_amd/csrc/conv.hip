@@ -253,7 +253,7 @@ __device__ __forceinline__ void stage_weights(const bnerv_conv_desc& d, float* s
 template <int EP>
 __device__ __forceinline__ float ep_value(const bnerv_conv_desc& d, float v, float bias, size_t o, float* out2v) {
     if constexpr (EP == BNERV_EP_BIAS) return v + bias;
-    if constexpr (EP == BNERV_EP_BIAS_SIN) { float sv, cv; sincosf(v + bias, &sv, &cv); *out2v = cv; return sv; }
+    if constexpr (EP == BNERV_EP_BIAS_SIN) { float sv, cv; sincos_f(v + bias, &sv, &cv); *out2v = cv; return sv; }
     if constexpr (EP == BNERV_EP_BIAS_GELU) { float h; gelu_pair_f(v + bias, &h, out2v); return h; }
     if constexpr (EP == BNERV_EP_BIAS_RES) return v + bias + d.aux0[o];
     if constexpr (EP == BNERV_EP_BIAS_TANH) return tanhf(v + bias) * 0.5f + 0.5f;
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
                 for (int m = 0; m < 4; ++m) {
                     f32x4 sv, cv;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { float s_, c_; sincosf(acc[m][e] + bias_l, &s_, &c_); sv[e] = s_; cv[e] = c_; }
+                    for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(acc[m][e] + bias_l, &s_, &c_); sv[e] = s_; cv[e] = c_; }
                     bstore(ro, vo[m], so[m], sv);
                     if (d.out2) bstore(ro2, vo[m], so[m], cv);
                 }

@@ -342,3 +342,20 @@ def test_dwconv_fwd_bwd(ops, shape):
     close(out, ref, msg="dwconv fwd")
     for n, a, r in zip("xwb", torch.autograd.grad(out, [xg, wg, bg], cot.to(DEV)), rg):
         close(a, r, msg=f"dwconv d{n}")
+
+
+def test_sincos_epilogue_accuracy(ops):
+    """The sin/cos pair of the block activation (common.h sincos_f), read back exactly through an identity 1x1 conv (MFMA f32
+    is exact, so the epilogue sees x itself): against float64 sin/cos on moderate and on large arguments."""
+    from boosting_nerv_amd import _lib as L
+    C, H, W = 12, 64, 128
+    g = torch.Generator().manual_seed(2)
+    for span in (8.0, 60.0, 8000.0, 3.0e4):
+        x = ((torch.rand(1, C, H, W, generator=g) * 2 - 1) * span).to(DEV)
+        w = torch.eye(C).reshape(C, C, 1, 1).to(DEV)
+        s_out, c_out = torch.empty_like(x), torch.empty_like(x)
+        ops._conv(x, w, None, s_out, B=1, Cin=C, Cout=C, H=H, W=W, k=1, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_SIN, out2=c_out)
+        xd = x.double().cpu()
+        es = (s_out.double().cpu() - torch.sin(xd)).abs().max().item()
+        ec = (c_out.double().cpu() - torch.cos(xd)).abs().max().item()
+        assert es < 3e-7 and ec < 3e-7, (span, es, ec)
