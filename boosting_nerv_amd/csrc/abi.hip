@@ -45,13 +45,14 @@ void bnerv_side_push(const void* src, int n_slabs, int count, int ncols, float* 
     g_side_queue.push_back(j);
 }
 
-void bnerv_side_take(SidePack* sp) {
+void bnerv_side_take(SidePack* sp, int max_slices) {
     sp->n_jobs = 0;
     sp->n_slices = 0;
-    const int n = (int)g_side_queue.size() < SIDE_MAX_JOBS ? (int)g_side_queue.size() : SIDE_MAX_JOBS;
-    for (int i = 0; i < n; ++i) {
-        sp->j[i] = g_side_queue[i];
-        sp->n_slices += g_side_queue[i].slices;
+    int n = 0;
+    while (n < (int)g_side_queue.size() && n < SIDE_MAX_JOBS && sp->n_slices + g_side_queue[n].slices <= max_slices) {
+        sp->j[n] = g_side_queue[n];
+        sp->n_slices += g_side_queue[n].slices;
+        ++n;
     }
     sp->n_jobs = n;
     g_side_queue.erase(g_side_queue.begin(), g_side_queue.begin() + n);
@@ -62,7 +63,7 @@ int bnerv_side_pending() { return (int)g_side_queue.size(); }
 int bnerv_side_flush(hipStream_t st) {
     while (!g_side_queue.empty()) {
         SidePack sp;
-        bnerv_side_take(&sp);
+        bnerv_side_take(&sp, 0x7fffffff);
         hipLaunchKernelGGL(side_flush_kernel, dim3(sp.n_slices), dim3(256), 0, st, sp);
         BNERV_LAUNCH_CHECK("side_flush");
     }

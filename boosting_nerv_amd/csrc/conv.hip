@@ -392,7 +392,7 @@ __device__ __forceinline__ void copy_out_tile(const KArgs& ka, const float* s_ou
 
 // ---------------------------------------------------------------------------------------------------------------- kernel
 template <int KS, int IN, int EP, int NTB>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const KArgs ka) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const KArgs ka, const SidePack side) {
     using G = Geo<KS>;
     const bnerv_conv_desc& d = ka.d;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -509,6 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const KArgs ka) {
         }
         lds_barrier();                                     // s_out free for the next item; s_in(next) visible
     }
+    side_run_hosted(side, smem);                           // queued slab reductions (sidejob.h)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- fast kernel
@@ -526,7 +527,7 @@ __device__ unsigned long long g_trace[1024 * 4 * 6 * 8];
 #define TRACE(slot) do {} while (0)
 #endif
 template <int KS, int IN, int EP, int NTB, int NQ1>
-__global__ __launch_bounds__(256, (NTB == 1 ? (NQ1 <= 3 ? 4 : 3) : 2)) void conv_fast_kernel(const KArgs ka, const int ncs /* s_out channels */) {
+__global__ __launch_bounds__(256, (NTB == 1 ? (NQ1 <= 3 ? 4 : 3) : 2)) void conv_fast_kernel(const KArgs ka, const int ncs /* s_out channels */, const SidePack side) {
     using G = Geo<KS>;
     constexpr int NCH = NQ1 * 4;
     constexpr int NSLOT = NCH * G::ROWS * G::SEGS;
@@ -681,6 +682,7 @@ __global__ __launch_bounds__(256, (NTB == 1 ? (NQ1 <= 3 ? 4 : 3) : 2)) void conv
         }
         it = nxt;                                          // barrier (A) of the next iteration also frees s_out
     }
+    side_run_hosted(side, smem);                           // queued slab reductions (sidejob.h)
 }
 
 template <int KS, int IN, int EP, int NTB, int NQ1>
@@ -706,7 +708,9 @@ int launch_fast(hipStream_t st, KArgs& ka) {
     }
     int grid = 256 * blocks_per_cu;                       // everything resident: the static item partition is then balanced
     if (grid > ka.total_items) grid = ka.total_items;
-    hipLaunchKernelGGL((conv_fast_kernel<KS, IN, EP, NTB, NQ1>), dim3(grid), dim3(256), lds, st, ka, ncs);
+    SidePack side;
+    bnerv_side_take(&side, 2 * grid);
+    hipLaunchKernelGGL((conv_fast_kernel<KS, IN, EP, NTB, NQ1>), dim3(grid), dim3(256), lds, st, ka, ncs, side);
     BNERV_LAUNCH_CHECK("conv_fast");
     return BNERV_OK;
 }
@@ -1117,7 +1121,7 @@ int launch_lean(hipStream_t st, KArgs& ka) {
     int grid = 256 * blocks_per_cu;                       // everything resident: the static item partition is then balanced
     if (grid > ka.total_items) grid = ka.total_items;
     SidePack side;
-    bnerv_side_take(&side);
+    bnerv_side_take(&side, 2 * grid);
     hipLaunchKernelGGL((conv_lean_kernel<KS, IN, EP, NQ1>), dim3(grid), dim3(256), lds, st, ka, side);
     BNERV_LAUNCH_CHECK("conv_lean");
     return BNERV_OK;
@@ -1163,7 +1167,9 @@ int launch_one(hipStream_t st, KArgs& ka) {
     const int per_cu = (int)((size_t)160 * 1024 / lds);
     int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     if (grid > ka.total_items) grid = ka.total_items;
-    hipLaunchKernelGGL((conv_igemm_kernel<KS, IN, EP, NTB>), dim3(grid), dim3(256), lds, st, ka);
+    SidePack side;
+    bnerv_side_take(&side, 2 * grid);
+    hipLaunchKernelGGL((conv_igemm_kernel<KS, IN, EP, NTB>), dim3(grid), dim3(256), lds, st, ka, side);
     BNERV_LAUNCH_CHECK("conv_igemm");
     return BNERV_OK;
 }

@@ -31,7 +31,8 @@ struct SidePack {
 
 // host side (abi.hip)
 void bnerv_side_push(const void* src, int n_slabs, int count, int ncols, float* out, float* out2);
-void bnerv_side_take(SidePack* sp);                      // moves up to SIDE_MAX_JOBS queued jobs into *sp (n_jobs = 0 if none)
+void bnerv_side_take(SidePack* sp, int max_slices);      // moves up to SIDE_MAX_JOBS queued jobs (while their slices fit max_slices)
+                                                         // into *sp (n_jobs = 0 if none): a small grid must not host a big reduction
 int bnerv_side_flush(hipStream_t st);                    // standalone launch(es) for everything still queued
 int bnerv_side_pending();
 

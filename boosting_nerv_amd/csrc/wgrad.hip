@@ -690,7 +690,7 @@ int launch_wlean(hipStream_t st, const WArgs& wa) {
     const size_t lds_red = (size_t)4 * 16 * NTW * 16;
     const size_t lds = (lds_main > lds_red ? lds_main : lds_red) * sizeof(float);
     SidePack side;
-    bnerv_side_take(&side);
+    bnerv_side_take(&side, 2 * wlean_blocks(wa.d));
     hipLaunchKernelGGL((wgrad_lean_kernel<KS, IN, GM2>), dim3(wlean_blocks(wa.d)), dim3(256), lds, st, wa, n_grows, side);
     BNERV_LAUNCH_CHECK("wgrad_lean");
     return BNERV_OK;

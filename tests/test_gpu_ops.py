@@ -308,10 +308,15 @@ def test_deferred_reductions_match_immediate(ops):
     L.check(lib.bnerv_reduce_slabs_deferred(L.ptr(slabs), 700, 1308, L.ptr(out_a)), "defer")
     L.check(lib.bnerv_reduce_slabs_deferred(L.ptr(parts), 3600, 24, L.ptr(out_b)), "defer")
     assert lib.bnerv_deferred_pending() == 2
-    # a lean conv launch hosts both jobs
-    x = torch.randn(1, 12, 64, 128, generator=g).to(DEV); w = (torch.randn(12, 12, 3, 3, generator=g) / 10).to(DEV); b = torch.randn(12, generator=g).to(DEV)
+    # a launch with a small grid must not host a big reduction (16 tiles here): the jobs stay queued ...
+    w = (torch.randn(12, 12, 3, 3, generator=g) / 10).to(DEV); b = torch.randn(12, generator=g).to(DEV)
+    xs = torch.randn(1, 12, 64, 128, generator=g).to(DEV)
+    ops._conv(xs, w, b, torch.empty_like(xs), B=1, Cin=12, Cout=12, H=64, W=128, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS)
+    assert lib.bnerv_deferred_pending() == 2
+    # ... and a lean conv launch with enough blocks hosts both
+    x = torch.randn(1, 12, 256, 512, generator=g).to(DEV)
     y = torch.empty_like(x)
-    ops._conv(x, w, b, y, B=1, Cin=12, Cout=12, H=64, W=128, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS)
+    ops._conv(x, w, b, y, B=1, Cin=12, Cout=12, H=256, W=512, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS)
     assert lib.bnerv_deferred_pending() == 0
     torch.testing.assert_close(y.cpu(), F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(out_a.double().cpu(), ref_a.cpu(), rtol=1e-5, atol=1e-4)
