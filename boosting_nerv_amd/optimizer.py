@@ -78,13 +78,23 @@ class Adan(Optimizer):
             dev = group["params"][0].device
             L.require_device(group["params"][0], "parameter")
             if gi not in self._sched:
-                # a RING of pinned slots: the async copy of step k may still be queued when the host prepares step k+1
-                self._sched[gi] = (torch.zeros(self._RING, 5, dtype=torch.float32).pin_memory(), torch.zeros(5, dtype=torch.float32, device=dev))
-            ring, devbuf = self._sched[gi]
-            host = ring[group["step"] % self._RING]
+                # a RING of pinned slots: the async copy of step k may still be queued when the host prepares step k+1.  Every slot
+                # carries an event recorded after its copy was enqueued; a slot is rewritten only once that copy has executed, which
+                # bounds the host's run-ahead to _RING steps (an un-synchronised loop of > _RING steps would otherwise hand the GPU
+                # the schedule of a later step -- tools/parity_run.py caught exactly that after ~1000 steps)
+                self._sched[gi] = (torch.zeros(self._RING, 5, dtype=torch.float32).pin_memory(), torch.zeros(5, dtype=torch.float32, device=dev),
+                                   [None] * self._RING)
+            ring, devbuf, events = self._sched[gi]
+            slot = group["step"] % self._RING
+            if events[slot] is not None:
+                events[slot].synchronize()
+            host = ring[slot]
             host[0], host[1], host[2], host[3] = group["lr"], bc1, bc2, math.sqrt(bc3)
             host[4] = 1.0 if group["step"] == 1 else 0.0
             devbuf.copy_(host, non_blocking=True)
+            if events[slot] is None:
+                events[slot] = torch.cuda.Event()
+            events[slot].record()
 
     def _ensure_state(self, p, step, clip):
         state = self.state[p]

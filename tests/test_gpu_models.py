@@ -223,6 +223,41 @@ def test_short_schedule_end_psnr_matches_oracle():
     assert abs(got - ref_psnr) <= 0.02, (got, ref_psnr)
 
 
+def test_long_unsynchronised_run_keeps_the_schedule():
+    """The per-step scalars (lr, Adan bias corrections) reach the GPU through a ring of pinned slots.  With the GPU held back
+    (a long sleep kernel) the host enqueues far more steps than the ring has slots: every step must still see its OWN
+    schedule record -- final weights identical to a run that synchronises every step."""
+    from boosting_nerv_amd.engine import TrainStep
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    from boosting_nerv_amd.optimizer import Adan
+    from boosting_nerv_amd.synth import SyntheticVideo
+    vid = SyntheticVideo(2, 180, 320)
+    fd = torch.stack([vid.frame(i) for i in range(2)]).to(DEV)
+    nd = torch.tensor([0.5, 1.0], dtype=torch.float64, device=DEV)
+    n_steps = Adan._RING + 200
+    lrs = [0.002 * (0.2 + 0.8 * abs(((s * 7) % 100) / 50.0 - 1.0)) for s in range(n_steps)]      # changes every step
+
+    def run(sync_every_step):
+        torch.manual_seed(1)
+        model = NeRV_Boost(1, args=configs.tiny_nerv()).to(DEV)
+        opt = Adan(model.parameters(), lr=lrs[0])
+        step = TrainStep(model, opt, "Fusion10_freq", False, (1, 3, 180, 320), torch.device(DEV), use_graph=True, warmup_eager=2)
+        for s in range(n_steps):
+            if s == 8 and not sync_every_step:
+                torch.cuda._sleep(int(3e9))                 # ~1.5 s: the host runs hundreds of steps ahead of the GPU
+            for pg in opt.param_groups:
+                pg["lr"] = lrs[s]
+            step(fd[s % 2:s % 2 + 1], nd[s % 2:s % 2 + 1])
+            if sync_every_step:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return {k: v.clone() for k, v in model.state_dict().items()}
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
