@@ -80,8 +80,8 @@ class Adan(Optimizer):
             if gi not in self._sched:
                 # a RING of pinned slots: the async copy of step k may still be queued when the host prepares step k+1.  Every slot
                 # carries an event recorded after its copy was enqueued; a slot is rewritten only once that copy has executed, which
-                # bounds the host's run-ahead to _RING steps (an un-synchronised loop of > _RING steps would otherwise hand the GPU
-                # the schedule of a later step -- tools/parity_run.py caught exactly that after ~1000 steps)
+                # bounds the host's run-ahead to _RING steps by construction (in practice the HIP launch queue already blocks the host
+                # long before 512 graph launches are outstanding; the guard makes that an invariant instead of an observation)
                 self._sched[gi] = (torch.zeros(self._RING, 5, dtype=torch.float32).pin_memory(), torch.zeros(5, dtype=torch.float32, device=dev),
                                    [None] * self._RING)
             ring, devbuf, events = self._sched[gi]
