@@ -509,38 +509,44 @@ __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(cons
     };
 
     f32x4 xa[NXS], ga[NGS], gb[GTWO ? NGS : 1];
-    auto issue = [&](const LTile& a) {
-        const int ty0 = a.ty * TH, tx0 = a.tx * TW;
-        const unsigned sbx = (unsigned)((((a.b * Cin) * H + ty0) * W + tx0) * 4);
-        const unsigned sbg = GM2 == 1 ? (unsigned)(((((a.b * (Cout >> 2)) * 2 * H) + 2 * ty0) * (2 * W) + 2 * tx0) * 4)
-                                      : (unsigned)((((a.b * Cout) * H + ty0) * W + tx0) * 4);
-        const bool interior = ty0 >= G::PAD && ty0 + TH + G::PAD <= H && tx0 >= G::XOFF && tx0 + TW + G::XOFF <= W;
-        const bool gfull = ty0 + TH <= H && tx0 + TW <= W;
-        if (gfull) {
-#pragma unroll
-            for (int k = 0; k < NGS; ++k) {
-                ga[k] = bload(rg, voffg[k], sbg);
-                if constexpr (GM2 == 1) gb[k] = bload(rg, voffg[k] + 16u, sbg);
-                if constexpr (GM2 == 2) gb[k] = bload(rg2, voffg[k], sbg);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NGS; ++k) {
+    // The prefetch of the next tile is issued ONE LOAD AT A TIME, spread over the K loop of the current tile: after a barrier
+    // every wave of the CU would otherwise fire its 8-9 loads at once and sit in the vector-memory issue queue for 2-4 k cycles
+    // per tile before its first MFMA (tools/ktrace_w.py).  part p < NGS: g slot p; otherwise x slot p - NGS.
+    constexpr int NPART = NGS + NXS;
+    struct Pre { unsigned sbx, sbg; int ty0, tx0; bool interior, gfull; };
+    auto prep = [&](const LTile& a) {
+        Pre q;
+        q.ty0 = a.ty * TH; q.tx0 = a.tx * TW;
+        q.sbx = (unsigned)((((a.b * Cin) * H + q.ty0) * W + q.tx0) * 4);
+        q.sbg = GM2 == 1 ? (unsigned)(((((a.b * (Cout >> 2)) * 2 * H) + 2 * q.ty0) * (2 * W) + 2 * q.tx0) * 4)
+                         : (unsigned)((((a.b * Cout) * H + q.ty0) * W + q.tx0) * 4);
+        q.interior = q.ty0 >= G::PAD && q.ty0 + TH + G::PAD <= H && q.tx0 >= G::XOFF && q.tx0 + TW + G::XOFF <= W;
+        q.gfull = q.ty0 + TH <= H && q.tx0 + TW <= W;
+        return q;
+    };
+    auto issue_part = [&](const Pre& q, int p) {           // p is a compile-time constant at every call site
+        if (p < NGS) {
+            const int k = p;
+            unsigned vo = voffg[k];
+            if (!q.gfull) {
                 const int sidx = tid + k * 256;
                 const int r = (sidx >> 3) & 7, sg = sidx & 7;
-                const unsigned vo = (ty0 + r < H && tx0 + 4 * sg < W) ? voffg[k] : OOB;
-                ga[k] = bload(rg, vo, sbg);
-                if constexpr (GM2 == 1) gb[k] = bload(rg, vo == OOB ? OOB : vo + 16u, sbg);
-                if constexpr (GM2 == 2) gb[k] = bload(rg2, vo, sbg);
+                vo = (q.ty0 + r < H && q.tx0 + 4 * sg < W) ? vo : OOB;
             }
-        }
-        if (interior) {
-#pragma unroll
-            for (int k = 0; k < NXS; ++k) xa[k] = bload(rx, voffx[k], sbx);
+            ga[k] = bload(rg, vo, q.sbg);
+            if constexpr (GM2 == 1) gb[k] = bload(rg, vo == OOB ? OOB : vo + 16u, q.sbg);
+            if constexpr (GM2 == 2) gb[k] = bload(rg2, vo, q.sbg);
         } else {
-#pragma unroll
-            for (int k = 0; k < NXS; ++k) xa[k] = bload(rx, x_inside(k, ty0, tx0) ? voffx[k] : OOB, sbx);
+            const int k = p - NGS;
+            unsigned vo = voffx[k];
+            if (!q.interior) vo = x_inside(k, q.ty0, q.tx0) ? vo : OOB;
+            xa[k] = bload(rx, vo, q.sbx);
         }
+    };
+    auto issue = [&](const LTile& a) {                     // all parts at once (first tile of a block)
+        const Pre q = prep(a);
+#pragma unroll
+        for (int p = 0; p < NPART; ++p) issue_part(q, p);
     };
     auto commit = [&](const LTile& a) {
         const int ty0 = a.ty * TH, tx0 = a.tx * TW;
@@ -622,9 +628,14 @@ __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(cons
         LTile nxt = it;
         if (has_next) nxt = advance(it);
         lds_barrier();                                     // tile t staged by everyone
-        if (has_next) issue(nxt);                          // flies under the MFMA phase
+        const Pre pre = prep(nxt);
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
+            if (has_next) {                                // the next tile's loads, spread over the K steps
+#pragma unroll
+                for (int p = 0; p < NPART; ++p)
+                    if (p * 16 / NPART == st) issue_part(pre, p);
+            }
             float bf[NTW];
             const float af = s_g[abase + st * 4];
 #pragma unroll
