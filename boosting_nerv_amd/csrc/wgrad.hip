@@ -386,6 +386,12 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 
 struct LTile { int b, ty, tx; };
 
+#ifdef BNERV_TRACE   // debug variant only (tools/ktrace_w.py): s_memtime phase stamps of wgrad_lean_kernel
+__device__ unsigned long long g_trace_w[1024 * 4 * 8 * 8];
+#define WTRACE(it_, slot) do { if (lane == 0 && blockIdx.x < 1024 && (it_) < 8) g_trace_w[((blockIdx.x * 4 + wave) * 8 + (it_)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WTRACE(it_, slot) do {} while (0)
+#endif
 // GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient (two float4 per channel PAIR), 2 = tanh-grad (g, gaux)
 template <int KS, int IN, int GM2>
 __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(const WArgs wa, const int n_grows /* s_g rows kept */, const SidePack side) {
@@ -410,6 +416,7 @@ __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(cons
     const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
     const int nW = Cin * G::T;
     const int tiles_x = wa.tiles_x, tiles_y = wa.tiles_y;
+    WTRACE(7, 0);
 
     // XCD x owns a contiguous slice of the tile list; its blocks take it round-robin
     const int total = d.B * tiles_x * tiles_y;
@@ -623,12 +630,17 @@ __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(cons
         if constexpr (AFF) { load_affine(it.b); aff_b = it.b; }
         commit(it);
     }
-    for (; itx < r1; itx += nlb) {
+    WTRACE(7, 1);
+    int wt = 0; (void)wt;
+    for (; itx < r1; itx += nlb, ++wt) {
+        WTRACE(wt, 0);
         const bool has_next = itx + nlb < r1;
         LTile nxt = it;
         if (has_next) nxt = advance(it);
         lds_barrier();                                     // tile t staged by everyone
+        WTRACE(wt, 1);
         const Pre pre = prep(nxt);
+        WTRACE(wt, 2);
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
             if (has_next) {                                // the next tile's loads, spread over the K steps
@@ -643,13 +655,17 @@ __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(cons
 #pragma unroll
             for (int n = 0; n < NTW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[n], acc[n], 0, 0, 0);
         }
+        WTRACE(wt, 3);
         lds_barrier();                                     // everyone done reading tile t
+        WTRACE(wt, 5);
         if (has_next) {
             if constexpr (AFF) { if (nxt.b != aff_b) { load_affine(nxt.b); aff_b = nxt.b; } }
             commit(nxt);
         }
+        WTRACE(wt, 6);
         it = nxt;
     }
+    WTRACE(7, 2);
 
     // cross-wave reduction through LDS (fixed order => deterministic), then ONE slab per block
     __syncthreads();
@@ -666,7 +682,9 @@ __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(cons
         if (row < Cout && col < wa.ncols)
             slab[(size_t)row * wa.ncols + col] = (s_red[idx] + s_red[RSZ + idx]) + (s_red[2 * RSZ + idx] + s_red[3 * RSZ + idx]);
     }
+    WTRACE(7, 3);
     side_run_hosted(side, smem);                           // queued slab reductions of EARLIER launches (sidejob.h)
+    WTRACE(7, 4);
 }
 
 constexpr size_t WLEAN_MAX_BYTES = 0x7ff00000;
@@ -794,6 +812,9 @@ int launch_modes(hipStream_t st, const WArgs& wa, const Plan& p) {
 
 }  // namespace
 
+#ifdef BNERV_TRACE
+extern "C" int bnerv_debug_trace_read_w(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_w), sizeof(g_trace_w)); }
+#endif
 extern "C" size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int k) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (k != 1 && k != 3)) return 0;
     const Plan p = make_plan(B, Cin, Cout, H, W, k);
