@@ -301,3 +301,61 @@ def test_dp_step_path_on_one_rank_group():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _dp2_worker(rank, port, out_dir):
+    import os
+    import torch.distributed as dist
+    from boosting_nerv_amd.engine import TrainStep
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    from boosting_nerv_amd.optimizer import Adan
+    from boosting_nerv_amd.synth import SyntheticVideo
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)          # gloo moves device tensors through the host: 2 ranks, 1 GPU
+    try:
+        vid = SyntheticVideo(4, 180, 320)
+        frames = torch.stack([vid.frame(i) for i in range(4)]).to(DEV)
+        norm = torch.tensor([(i + 1) / 4 for i in range(4)], dtype=torch.float64, device=DEV)
+        torch.manual_seed(1)
+        model = NeRV_Boost(1, args=configs.tiny_nerv()).to(DEV)
+        opt = Adan(model.parameters(), lr=0.003)
+        step = TrainStep(model, opt, "Fusion10_freq", False, (1, 3, 180, 320), torch.device(DEV), use_graph=True, warmup_eager=2, world_size=2)
+        for s in range(6):                                            # rank r trains frame 2*(s%2) + r: the two shards of a batch of 2
+            fi = 2 * (s % 2) + rank
+            step(frames[fi:fi + 1], norm[fi:fi + 1])
+        torch.cuda.synchronize()
+        assert step.graph_b is not None
+        torch.save([p.detach().cpu() for p in model.parameters()], os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_two_ranks_on_one_gpu_match_batch_of_two(tmp_path):
+    """The N > 1 step (graph A -> all-reduce of the flat bucket -> graph B) with world_size 2: two processes share the one GPU and
+    exchange through gloo.  Both ranks must end with identical weights, equal (to reduction-order tolerance) to a single
+    process training on batches of the two ranks' frames (DDP mean semantics)."""
+    import torch.multiprocessing as mp
+    from boosting_nerv_amd import hnerv_utils as hu
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    from boosting_nerv_amd.optimizer import Adan
+    from boosting_nerv_amd.synth import SyntheticVideo
+    mp.spawn(_dp2_worker, args=(29653, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b)
+    vid = SyntheticVideo(4, 180, 320)
+    frames = torch.stack([vid.frame(i) for i in range(4)]).to(DEV)
+    norm = torch.tensor([(i + 1) / 4 for i in range(4)], dtype=torch.float64, device=DEV)
+    torch.manual_seed(1)
+    model = NeRV_Boost(1, args=configs.tiny_nerv()).to(DEV)
+    opt = Adan(model.parameters(), lr=0.003)
+    for s in range(6):
+        sl = slice(2 * (s % 2), 2 * (s % 2) + 2)
+        img, _, _ = model(norm[sl], norm_idx=norm[sl])
+        loss = hu.loss_fn(img, frames[sl], "Fusion10_freq")           # batch mean == mean of the two per-rank losses
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    for a, p in zip(r0, model.parameters()):
+        d = (a - p.detach().cpu()).abs()
+        assert d.max().item() <= 0.1 * 6 * 0.003 and d.mean().item() <= 2e-5, (d.max().item(), d.mean().item())
