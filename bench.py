@@ -163,10 +163,15 @@ def main():
         if a.gpus > 1 and world == 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
+    # Test hook (never set by the driver): BNERV_BENCH_SHARE_GPU=1 runs all ranks of an N > 1 launch on device 0 over gloo, so the
+    # multi-GPU code path of this script can be smoke-tested on a 1-GPU box.  The numbers of such a run mean nothing.
+    share = os.environ.get("BNERV_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(backend="gloo" if share else "nccl", init_method="env://", world_size=world, rank=rank)
 
     from boosting_nerv_amd.dp import shard_indices
     from boosting_nerv_amd.engine import TrainStep
