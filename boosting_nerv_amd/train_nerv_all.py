@@ -27,6 +27,7 @@ import yaml
 from torch.utils.data import Subset
 
 from .engine import TrainStep
+from . import ops
 from .hnerv_utils import (RoundTensor, TransformInput, VideoDataSet, adjust_lr, all_reduce, data_split, msssim_fn_batch,
                           psnr_fn_batch, quant_tensor, worker_init_fn)
 from .model_enerv import ENeRV_Boost
@@ -505,9 +506,10 @@ def evaluate(model, full_dataloader, local_rank, args, dump_vis=False, huffman_c
                 for _ in range(100):
                     _, _, dec_time = cur_model(cur_input, embed_list[0], norm_idx=norm_idx)
                     time_list.append(dec_time)
-            pred_psnr, pred_ssim = psnr_fn_batch([img_out], img_gt), msssim_fn_batch([img_out], img_gt)
+            # metrics stay on the device (row N4): no per-frame .cpu(); they are read when a line is printed and at the end
+            pred_psnr, pred_ssim = ops.psnr(img_out, img_gt)[None], ops.msssim(img_out.float(), img_gt)[None]
             for metric_idx, cur_v in enumerate([pred_psnr, pred_ssim]):
-                for batch_i, cur_img_idx in enumerate(img_idx.tolist()):
+                for batch_i, cur_img_idx in enumerate(sample['idx'].tolist()):      # the loader's host copy: no device sync
                     metric_idx_start = 2 if cur_img_idx in args.val_ind_list else 0
                     metric_list[metric_idx_start + metric_idx + 4 * model_ind].append(cur_v[:, batch_i])
             if dump_vis:
@@ -517,7 +519,7 @@ def evaluate(model, full_dataloader, local_rank, args, dump_vis=False, huffman_c
                 print_str = '[{}] Rank:{}, Eval at Step [{}/{}] , FPS {}, '.format(datetime.now().strftime("%Y/%m/%d %H:%M:%S"), local_rank, i + 1,
                                                                                    len(full_dataloader), round(fps, 1))
                 for v_name, v_list in zip(args.metric_names, metric_list):
-                    cur_value = torch.stack(v_list, dim=-1).mean(-1) if len(v_list) else torch.zeros(1)
+                    cur_value = torch.stack(v_list, dim=-1).mean(-1).cpu() if len(v_list) else torch.zeros(1)
                     print_str += f'{v_name}: {RoundTensor(cur_value, 4)} | '
                 if local_rank in [0, None]:
                     print(print_str, flush=True)
@@ -538,7 +540,7 @@ def evaluate(model, full_dataloader, local_rank, args, dump_vis=False, huffman_c
     results_list = []
     for v_list in metric_list:
         if len(v_list):
-            s = torch.stack(v_list, dim=1).sum(1)
+            s = torch.stack(v_list, dim=1).sum(1).cpu()
             n = torch.tensor([float(len(v_list))])
         else:
             s, n = torch.zeros(1), torch.zeros(1)
