@@ -298,12 +298,49 @@ def gen_host(R):
     np.savez_compressed(os.path.join(OUT, "host.npz"), **out)
 
 
+def gen_cem(R):
+    """CEM pieces of the compression train step: lib/transform_ops.py Scale_T / ScaleBeta_T, lib/entropy_model.py
+    DiffEntropyModel (training draw with a fixed torch seed, and the deterministic evaluation form via get_bits)."""
+    T, E = R.lib_transform_ops, R.lib_entropy_model
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    for name, shape in (("w", (24, 12, 3, 3)), ("b", (24,))):
+        x = (torch.randn(*shape, generator=g) * 0.05).requires_grad_(True)
+        q = T.Scale_T(8, signed=True, per_channel=False)
+        q.init_form(x)
+        q.init_data(x.detach())
+        code, quant, deq = q(x)
+        cot = torch.randn(*shape, generator=g)
+        gx, gs = torch.autograd.grad((deq * cot).sum(), [x, q.scale], retain_graph=True)
+        out.update({f"scale/{name}/x": npf(x), f"scale/{name}/cot": npf(cot), f"scale/{name}/scale": npf(q.scale), f"scale/{name}/code": npf(code),
+                    f"scale/{name}/quant": npf(quant), f"scale/{name}/dequant": npf(deq), f"scale/{name}/gx": npf(gx), f"scale/{name}/gscale": npf(gs)})
+        em = E.DiffEntropyModel(distribution="gaussian")
+        torch.manual_seed(5)
+        noise = torch.empty_like(code).uniform_(-0.5, 0.5)
+        torch.manual_seed(5)
+        r = em.cal_bitrate(code, quant, True)
+        gx2, gs2 = torch.autograd.grad(r["bitrate"], [x, q.scale], retain_graph=True)
+        ev = em.get_bits(quant, torch.mean(code), torch.std(code)).sum()
+        out.update({f"rate/{name}/noise": npf(noise), f"rate/{name}/bitrate": npf(r["bitrate"]), f"rate/{name}/mean": npf(r["mean"]),
+                    f"rate/{name}/std": npf(r["std"]), f"rate/{name}/gx": npf(gx2), f"rate/{name}/gscale": npf(gs2), f"rate/{name}/eval_bits": npf(ev)})
+    e = torch.rand(2, 16, 9, 16, generator=g).requires_grad_(True)
+    qe = T.ScaleBeta_T(8, signed=False, per_channel=False)
+    qe.init_form(e)
+    qe.init_data(e.detach())
+    code, quant, deq = qe(e)
+    cot = torch.randn(e.shape, generator=g)
+    ge, gs, gb = torch.autograd.grad((deq * cot).sum(), [e, qe.scale, qe.beta])
+    out.update({"scalebeta/x": npf(e), "scalebeta/cot": npf(cot), "scalebeta/scale": npf(qe.scale), "scalebeta/beta": npf(qe.beta), "scalebeta/code": npf(code),
+                "scalebeta/quant": npf(quant), "scalebeta/dequant": npf(deq), "scalebeta/gx": npf(ge), "scalebeta/gscale": npf(gs), "scalebeta/gbeta": npf(gb)})
+    np.savez_compressed(os.path.join(OUT, "cem.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = ref_harness.load_reference()
-    which = sys.argv[1:] or ["pe", "blocks", "tiny", "full", "loss", "optim", "host"]
-    fns = dict(pe=gen_pe, blocks=gen_blocks, tiny=gen_tiny_models, full=gen_full_models, loss=gen_loss, optim=gen_optim, host=gen_host)
+    which = sys.argv[1:] or ["pe", "blocks", "tiny", "full", "loss", "optim", "host", "cem"]
+    fns = dict(pe=gen_pe, blocks=gen_blocks, tiny=gen_tiny_models, full=gen_full_models, loss=gen_loss, optim=gen_optim, host=gen_host, cem=gen_cem)
     for w in which:
         print("generating", w, flush=True)
         fns[w](R)

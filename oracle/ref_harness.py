@@ -79,6 +79,8 @@ def install_stubs():
         if name not in sys.modules:
             _mod(name)
     sys.modules["dahuffman"].__dict__.setdefault("HuffmanCodec", object)
+    for nm in ("BufferedRansEncoder", "RansDecoder"):          # names lib/entropy_model.py:9 imports (never called by the goldens)
+        sys.modules["compressai.ans"].__dict__.setdefault(nm, object)
     if "torch.utils.tensorboard" not in sys.modules:
         try:
             importlib.import_module("torch.utils.tensorboard")
@@ -109,10 +111,15 @@ def load_reference():
     install_stubs()
     saved = {n: sys.modules.pop(n) for n in list(sys.modules) if n in _REF_NAMES or n.startswith("lib.")}
     sys.path.insert(0, REFERENCE_ROOT)
+    # the reference's lib/ has no __init__.py (namespace package) and would lose against the product's same-named shim package
+    # at the repo root whatever the sys.path order: bind the name to the reference directory for the duration of the import
+    ref_lib = types.ModuleType("lib")
+    ref_lib.__path__ = [os.path.join(REFERENCE_ROOT, "lib")]
+    sys.modules["lib"] = ref_lib
     out = _RefModules()
     try:
-        for n in ("lib.quant_ops", "model_blocks", "model_nerv", "model_enerv", "model_hnerv", "hnerv_utils",
-                  "optimizer"):
+        for n in ("lib.quant_ops", "lib.transform_ops", "lib.entropy_model", "model_blocks", "model_nerv", "model_enerv", "model_hnerv",
+                  "hnerv_utils", "optimizer"):
             setattr(out, n.replace(".", "_"), importlib.import_module(n))
     finally:
         sys.path.remove(REFERENCE_ROOT)

@@ -133,3 +133,42 @@ def test_adan_trajectory_and_lr():
     for x, c, h in zip(npz["lr/x"], npz["lr/cosine"], npz["lr/hybrid"]):
         assert abs(0.003 * cpu_ref.lr_mult(float(x), "cosine_0.1_1_0.1") - c) < 1e-15
         assert abs(0.003 * cpu_ref.lr_mult(float(x), "hybrid_0.2_1_2_0.1_0.05") - h) < 1e-15
+
+
+def test_cem_quantisers_and_rate_against_reference():
+    """oracle/cem_ref.py against the reference's lib/transform_ops.py (Scale_T, ScaleBeta_T) and lib/entropy_model.py
+    (DiffEntropyModel, training draw and evaluation form): values and gradients."""
+    from oracle import cem_ref
+    npz = load_golden("cem.npz")
+    for name in ("w", "b"):
+        x = torch.from_numpy(npz[f"scale/{name}/x"]).clone().requires_grad_(True)
+        scale = torch.from_numpy(npz[f"scale/{name}/scale"]).clone().requires_grad_(True)
+        torch.testing.assert_close(cem_ref.scale_init(x.detach(), 8, True).reshape(1), scale.detach(), rtol=0, atol=0)
+        code, quant, deq = cem_ref.scale_t(x, scale)
+        for k, v in (("code", code), ("quant", quant), ("dequant", deq)):
+            torch.testing.assert_close(v.detach(), torch.from_numpy(npz[f"scale/{name}/{k}"]), rtol=0, atol=0)
+        cot = torch.from_numpy(npz[f"scale/{name}/cot"])
+        gx, gs = torch.autograd.grad((deq * cot).sum(), [x, scale], retain_graph=True)
+        torch.testing.assert_close(gx, torch.from_numpy(npz[f"scale/{name}/gx"]), rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(gs, torch.from_numpy(npz[f"scale/{name}/gscale"]), rtol=1e-5, atol=1e-6)
+        r = cem_ref.cal_bitrate(code, quant, True, noise=torch.from_numpy(npz[f"rate/{name}/noise"]))
+        assert abs(r["bitrate"].item() - float(npz[f"rate/{name}/bitrate"])) <= 1e-5 * float(npz[f"rate/{name}/bitrate"])
+        gx2, gs2 = torch.autograd.grad(r["bitrate"], [x, scale], retain_graph=True)
+        torch.testing.assert_close(gx2, torch.from_numpy(npz[f"rate/{name}/gx"]), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(gs2, torch.from_numpy(npz[f"rate/{name}/gscale"]), rtol=1e-4, atol=1e-2)
+        ev = cem_ref.cal_bitrate(code, quant, False)["bitrate"]
+        assert abs(ev.item() - float(npz[f"rate/{name}/eval_bits"])) <= 1e-5 * float(npz[f"rate/{name}/eval_bits"])
+        # the ideal code length of the integers is what the estimate approximates (the 1e-5 floor and the [min,max] renormalisation apart)
+        assert abs(cem_ref.ideal_bits(quant, r["mean"], r["std"]) - ev.item()) <= 0.05 * ev.item()
+    x = torch.from_numpy(npz["scalebeta/x"]).clone().requires_grad_(True)
+    scale = torch.from_numpy(npz["scalebeta/scale"]).clone().requires_grad_(True)
+    beta = torch.from_numpy(npz["scalebeta/beta"]).clone().requires_grad_(True)
+    s0, b0 = cem_ref.scalebeta_init(x.detach(), 8, False)
+    torch.testing.assert_close(s0.reshape(1), scale.detach(), rtol=0, atol=0)
+    torch.testing.assert_close(b0.reshape(1), beta.detach(), rtol=0, atol=0)
+    code, quant, deq = cem_ref.scalebeta_t(x, scale, beta)
+    for k, v in (("code", code), ("quant", quant), ("dequant", deq)):
+        torch.testing.assert_close(v.detach(), torch.from_numpy(npz[f"scalebeta/{k}"]), rtol=0, atol=0)
+    g = torch.autograd.grad((deq * torch.from_numpy(npz["scalebeta/cot"])).sum(), [x, scale, beta])
+    for a, k in zip(g, ("gx", "gscale", "gbeta")):
+        torch.testing.assert_close(a, torch.from_numpy(npz[f"scalebeta/{k}"]), rtol=1e-5, atol=1e-5)
