@@ -2,27 +2,37 @@
 ``CustomLinear`` are ``nn.Conv2d`` / ``nn.Linear`` (same constructor, same init RNG consumption, same state_dict
 keys) whose forward uses ``dequant_w`` / ``dequant_b`` when a CEM quantiser has set them (lib/quant_ops.py:39-41).
 
-The arithmetic goes to the HIP kernels (ops.conv2d_ps / ops.dense_grouped).  The learned-quantiser branch
-(``args.quant``; lib/transform_ops.py) belongs to the CEM compression path, SURVEY 8(f) row N2 -- not built yet."""
+The arithmetic goes to the HIP kernels (ops.conv2d_ps / ops.dense_grouped).  With ``args.quant`` (CEM compression path,
+train_nerv_compression.py) every container also carries its learned quantisers and rate dictionaries,
+exactly as lib/quant_ops.py:22-37 builds them; the model's cal_params() fills dequant_w / dequant_b each step."""
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .transform_ops import quant_map
 
 
-def _no_quant(args):
-    if getattr(args, "quant", False):
-        raise NotImplementedError("args.quant (CEM learned quantisers, train_nerv_compression.py) is SURVEY 8(f) row N2: "
-                                  "not part of this build")
+def _setup_quant(m, args, bias):
+    """lib/quant_ops.py:22-37 (same attribute names, hence the same state_dict keys weight_quantizer.scale / bias_quantizer.scale)."""
+    m.quant = bool(getattr(args, "quant", False))
+    if m.quant:
+        m.weight_quantizer = quant_map[args.quantizer_w](args.quant_model_bit, signed=True, per_channel=args.per_channel_w)
+        m.weight_quantizer.init_form(m.weight)
+        if bias:
+            m.bias_quantizer = quant_map[args.quantizer_b](args.quant_bias_bit, signed=True, per_channel=args.per_channel_b)
+            m.bias_quantizer.init_form(m.bias)
+        else:
+            m.bias_quantizer = None
+        m.bitrate_w_dict = {}
+        m.bitrate_b_dict = {}
+    m.dequant_w = None
+    m.dequant_b = None
 
 
 class CustomConv2d(nn.Conv2d):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, **kargs):
         super().__init__(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
-        _no_quant(kargs["args"])
-        self.dequant_w = None
-        self.dequant_b = None
-        self.quant = False
+        _setup_quant(self, kargs["args"], bias)
 
     def effective_weight(self):
         return self.weight if self.dequant_w is None else self.dequant_w
@@ -52,10 +62,7 @@ class CustomLinear(nn.Linear):
 
     def __init__(self, in_features, out_features, bias=True, **kargs):
         super().__init__(in_features, out_features, bias=bias)
-        _no_quant(kargs["args"])
-        self.dequant_w = None
-        self.dequant_b = None
-        self.quant = False
+        _setup_quant(self, kargs["args"], bias)
 
     def forward(self, x):
         return F.linear(x, self.weight if self.dequant_w is None else self.dequant_w,

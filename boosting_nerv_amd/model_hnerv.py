@@ -7,6 +7,7 @@ import torch.nn as nn
 
 from .model_blocks import *  # noqa: F401,F403
 from .model_blocks import ConvNeXt, CustomConv2d, NeRV_MLP, NeRVBlock, PositionEncoding, head_out
+from .lib.transform_ops import quant_map
 from .model_nerv import _CEMHooks, decoder_layers_forward
 
 
@@ -50,9 +51,11 @@ class HNeRV_Boost(_CEMHooks, nn.Module):
         self.decoder = nn.ModuleList(decoder_layers)
         self.head_layer = CustomConv2d(ngf, 3, 3, 1, 1, args=args)
         self.out_bias = args.out_bias
-        if args.quant:
-            raise NotImplementedError("args.quant (CEM) is SURVEY 8(f) row N2")
-        self.embed_quantizer = None
+        if args.quant:                                         # model_hnerv.py:216-220
+            self.embed_quantizer = quant_map[args.quantizer_e](args.quant_embed_bit, signed=False, per_channel=args.per_channel_e)
+            self.bitrate_e_dict = {}
+        else:
+            self.embed_quantizer = None
         self.outf = args.outf
         self.time_decode = False
 
@@ -69,6 +72,11 @@ class HNeRV_Boost(_CEMHooks, nn.Module):
 
     def forward(self, input, input_embed=None, entropy_model=None, pre_img=None, post_img=None, norm_idx=None):
         img_embed = input_embed if input_embed is not None else self.encoder(input)
+        if self.embed_quantizer is not None:                   # model_hnerv.py:230-234
+            self.embed_quantizer.init_data(img_embed)
+            code_e, quant_e, img_embed = self.embed_quantizer(img_embed)
+            if entropy_model is not None:
+                self.bitrate_e_dict.update(entropy_model.cal_bitrate(code_e, quant_e, self.training))
         if pre_img is not None and post_img is not None:
             img_embed = 0.5 * (self.encoder(pre_img) + self.encoder(post_img))
         return self._decode(img_embed, norm_idx)
@@ -76,8 +84,11 @@ class HNeRV_Boost(_CEMHooks, nn.Module):
     def forward_encoder(self, input):
         return self.encoder(input)
 
-    def forward_embed_quant(self, img_embed, entropy_model=None):
-        raise NotImplementedError("embedding quantiser (CEM) is SURVEY 8(f) row N2")
+    def forward_embed_quant(self, img_embed, entropy_model=None):      # model_hnerv.py:256-260
+        code, quant, img_embed = self.embed_quantizer(img_embed)
+        if entropy_model is not None:
+            self.bitrate_e_dict.update(entropy_model.cal_bitrate(code, quant, self.training))
+        return code, quant, img_embed
 
     def forward_decoder(self, img_embed, norm_idx):
         return self._decode(img_embed, norm_idx)

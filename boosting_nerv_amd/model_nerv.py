@@ -12,12 +12,37 @@ from .lib.quant_ops import CustomLinear
 
 
 class _CEMHooks:
-    """cal_params / get_bitrate_sum / init_data (model_nerv.py:67-94): CEM compression path, SURVEY 8(f) row N2."""
+    """cal_params / get_bitrate_sum / init_data (model_nerv.py:67-94, model_hnerv.py:292-322): the per-step hooks of the CEM
+    compression path (train_nerv_compression.py:354-361).  Active on models built with ``args.quant``."""
+
+    def _quant_modules(self):
+        return [m for m in self.modules() if type(m) in (CustomConv2d, CustomLinear)]
 
     def cal_params(self, entropy_model=None):
-        raise NotImplementedError("CEM compression hooks (train_nerv_compression.py) are SURVEY 8(f) row N2: not built yet")
+        for m in self._quant_modules():
+            code_w, quant_w, dequant_w = m.weight_quantizer(m.weight)
+            m.dequant_w = dequant_w
+            if m.bias is not None:
+                code_b, quant_b, dequant_b = m.bias_quantizer(m.bias)
+                m.dequant_b = dequant_b
+            if entropy_model is not None:
+                m.bitrate_w_dict.update(entropy_model.cal_bitrate(code_w, quant_w, self.training))
+                if m.bias is not None:
+                    m.bitrate_b_dict.update(entropy_model.cal_bitrate(code_b, quant_b, self.training))
 
-    get_bitrate_sum = init_data = cal_params
+    def get_bitrate_sum(self, name="bitrate"):
+        total = 0
+        for m in self._quant_modules():
+            total = total + m.bitrate_w_dict[name]
+            if name in m.bitrate_b_dict.keys():
+                total = total + m.bitrate_b_dict[name]
+        return total
+
+    def init_data(self):
+        for m in self._quant_modules():
+            m.weight_quantizer.init_data(m.weight)
+            if m.bias is not None:
+                m.bias_quantizer.init_data(m.bias)
 
 
 def decoder_layers_forward(layers, output, t_embed, out_list):

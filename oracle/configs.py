@@ -38,5 +38,12 @@ def tiny_hnerv():  # 180x320 input, encoder strides 5,2,2 (x20) -> 9x16 embeddin
                  ks="0_1_5", reduce=1.2, lower_width=6, fc_dim=10)
 
 
+def tiny_hnerv_quant():  # the same model built for the CEM compression path (scripts/compression/hnerv_boost.sh quantiser flags)
+    a = tiny_hnerv()
+    a.__dict__.update(quant=True, quant_model_bit=8, quant_bias_bit=8, quant_embed_bit=8, per_channel_w=False, per_channel_b=False,
+                      per_channel_e=False, quantizer_w="scale", quantizer_b="scale", quantizer_e="scalebeta", embed_entropy=True)
+    return a
+
+
 def tiny_enerv():
     return _base(model="ENeRV_Boost", dec_strds=[5, 2, 2], dec_blks=[1, 1, 2], fc_dim=8, lower_width=6, block_dim=64)

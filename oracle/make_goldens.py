@@ -335,12 +335,41 @@ def gen_cem(R):
     np.savez_compressed(os.path.join(OUT, "cem.npz"), **out)
 
 
+def gen_cem_model(R):
+    """The per-step hooks of the compression train loop (train_nerv_compression.py:354-367) on the tiny HNeRV_Boost built with
+    --quant: init_data, cal_params(entropy_model), forward(entropy_model=...), get_bitrate_sum; loss = L1 + 1e-6 * bits."""
+    args = configs.tiny_hnerv_quant()
+    torch.manual_seed(1)
+    model = R.model_hnerv.HNeRV_Boost(args)
+    model.init_data()
+    em = R.lib_entropy_model.DiffEntropyModel(distribution="gaussian")
+    frame = torch.rand(1, 3, 180, 320, generator=torch.Generator().manual_seed(5))
+    norm_idx = torch.tensor([3 / 7], dtype=torch.float64)
+    model.train()
+    torch.manual_seed(9)                                     # the uniform draws of cal_bitrate come from the default generator
+    model.cal_params(em)
+    img, _, _ = model(frame, entropy_model=em, norm_idx=norm_idx)
+    bits_w = model.get_bitrate_sum(name="bitrate")
+    bits_e = model.bitrate_e_dict["bitrate"]
+    loss = (img - frame).abs().mean() + 1e-6 * (bits_w + bits_e)
+    loss.backward()
+    out = {"frame_seed": np.int64(5), "bits_w": npf(bits_w), "bits_e": npf(bits_e), "loss": npf(loss)}
+    out.update(sd_np(model, "sd/"))                          # after init_data and the first forward (embed quantiser initialised)
+    summary(img, "img", out)
+    for k, p in model.named_parameters():
+        out[f"gnorm/{k}"] = np.float64(p.grad.double().norm().item() if p.grad is not None else -1.0)
+    for k in ("decoder.1.conv.upconv.0.weight_quantizer.scale", "embed_quantizer.scale", "embed_quantizer.beta", "head_layer.weight"):
+        p = dict(model.named_parameters())[k]
+        out[f"grad/{k}"] = npf(p.grad)
+    np.savez_compressed(os.path.join(OUT, "cem_model.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = ref_harness.load_reference()
-    which = sys.argv[1:] or ["pe", "blocks", "tiny", "full", "loss", "optim", "host", "cem"]
-    fns = dict(pe=gen_pe, blocks=gen_blocks, tiny=gen_tiny_models, full=gen_full_models, loss=gen_loss, optim=gen_optim, host=gen_host, cem=gen_cem)
+    which = sys.argv[1:] or ["pe", "blocks", "tiny", "full", "loss", "optim", "host", "cem", "cem_model"]
+    fns = dict(pe=gen_pe, blocks=gen_blocks, tiny=gen_tiny_models, full=gen_full_models, loss=gen_loss, optim=gen_optim, host=gen_host, cem=gen_cem, cem_model=gen_cem_model)
     for w in which:
         print("generating", w, flush=True)
         fns[w](R)

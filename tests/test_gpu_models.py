@@ -359,3 +359,53 @@ def test_dp_two_ranks_on_one_gpu_match_batch_of_two(tmp_path):
     for a, p in zip(r0, model.parameters()):
         d = (a - p.detach().cpu()).abs()
         assert d.max().item() <= 0.1 * 6 * 0.003 and d.mean().item() <= 2e-5, (d.max().item(), d.mean().item())
+
+
+def test_cem_hooks_against_reference_golden():
+    """Row N2: the compression train step's hooks on the tiny HNeRV_Boost built with --quant -- state_dict keys (quantiser scales
+    included), init_data, cal_params(entropy_model), forward(entropy_model=...), get_bitrate_sum and the gradients of
+    L1 + 1e-6 * bits -- against the reference's own run (tests/golden/cem_model.npz).  The uniform rate noise is drawn from the
+    CPU generator in the reference's order, so both sides add the same numbers."""
+    from boosting_nerv_amd.lib.entropy_model import DiffEntropyModel
+    from boosting_nerv_amd.model_hnerv import HNeRV_Boost
+    npz = load_golden("cem_model.npz")
+    gold_sd = group(npz, "sd/")
+    torch.manual_seed(1)
+    model = HNeRV_Boost(configs.tiny_hnerv_quant())
+    assert list(model.state_dict().keys()) == list(gold_sd.keys())
+    sd = dict(gold_sd)
+    enc_keys = [k for k in sd if k.startswith("encoder.")]
+    model.load_state_dict({k: v for k, v in sd.items() if k in enc_keys or "quantizer" not in k}, strict=False)   # weights (the ConvNeXt
+    model = model.to(DEV)                                                                                       # init is not bit-stable)
+    model.init_data()
+    for k, v in model.state_dict().items():
+        if "weight_quantizer" in k or "bias_quantizer" in k:
+            torch.testing.assert_close(v.cpu(), sd[k], rtol=1e-6, atol=0, msg=k)
+    em = DiffEntropyModel("gaussian")
+    em.noise_source = lambda code: torch.empty(code.shape).uniform_(-0.5, 0.5).to(code.device)
+    frame = torch.rand(1, 3, 180, 320, generator=torch.Generator().manual_seed(int(npz["frame_seed"]))).to(DEV)
+    norm_idx = torch.tensor([3 / 7], dtype=torch.float64, device=DEV)
+    model.train()
+    torch.manual_seed(9)
+    model.cal_params(em)
+    img, _, _ = model(frame, entropy_model=em, norm_idx=norm_idx)
+    bits_w, bits_e = model.get_bitrate_sum(name="bitrate"), model.bitrate_e_dict["bitrate"]
+    loss = (img - frame).abs().mean() + 1e-6 * (bits_w + bits_e)
+    loss.backward()
+    assert abs(bits_w.item() - float(npz["bits_w"])) <= 1e-4 * float(npz["bits_w"])
+    assert abs(bits_e.item() - float(npz["bits_e"])) <= 1e-3 * float(npz["bits_e"])
+    assert abs(loss.item() - float(npz["loss"])) <= 1e-4 * float(npz["loss"])
+    check_summary(img, npz, "img", rtol=1e-3, atol=1e-4)
+    for k in ("embed_quantizer.scale", "embed_quantizer.beta"):     # min / max of the encoder output (stock + HIP depthwise ops vs CPU)
+        torch.testing.assert_close(model.state_dict()[k].cpu(), sd[k], rtol=1e-4, atol=1e-5, msg=lambda m, k=k: f"{k}: {m}")
+    for k, p in model.named_parameters():
+        g = float(npz[f"gnorm/{k}"])
+        if g < 0:
+            assert p.grad is None, k
+        else:
+            assert abs(p.grad.double().norm().item() - g) <= 2e-3 * g + 1e-6, (k, p.grad.double().norm().item(), g)
+    for k in ("decoder.1.conv.upconv.0.weight_quantizer.scale", "embed_quantizer.scale", "embed_quantizer.beta", "head_layer.weight"):
+        p = dict(model.named_parameters())[k]
+        # (d/d beta is analytically 0 for the distortion path -- dequant = ste((x - beta)/scale)*scale + beta -- and ~1e-8 of rounding
+        #  noise on both sides for the rate path: absolute floor)
+        torch.testing.assert_close(p.grad.cpu(), torch.from_numpy(npz[f"grad/{k}"]), rtol=2e-3, atol=2e-3 * float(np.abs(npz[f"grad/{k}"]).max()) + 1e-6)
