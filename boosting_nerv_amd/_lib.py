@@ -69,6 +69,25 @@ class BucketChunk(C.Structure):
                 ("off", C.c_int * (ADAN_MAX_TENSORS * 2)), ("n_tensors", C.c_int)]
 
 
+CEM_MAX_TENSORS = 48
+
+
+class CemItem(C.Structure):
+    _fields_ = [("w", _fp), ("scale", _fp), ("noise", _fp), ("dequant", _fp), ("n", C.c_int), ("_pad", C.c_int)]
+
+
+class CemChunk(C.Structure):
+    _fields_ = [("it", CemItem * CEM_MAX_TENSORS), ("n_items", C.c_int), ("training", C.c_int), ("first", C.c_int), ("_pad", C.c_int)]
+
+
+class CemItemBwd(C.Structure):
+    _fields_ = [("w", _fp), ("scale", _fp), ("noise", _fp), ("d_dequant", _fp), ("dw", _fp), ("n", C.c_int), ("_pad", C.c_int)]
+
+
+class CemChunkBwd(C.Structure):
+    _fields_ = [("it", CemItemBwd * CEM_MAX_TENSORS), ("n_items", C.c_int), ("training", C.c_int), ("first", C.c_int), ("_pad", C.c_int)]
+
+
 # every symbol include/bnerv.h declares: name -> (restype, argtypes)
 _I, _Z, _V, _F = C.c_int, C.c_size_t, C.c_void_p, C.c_float
 SYMBOLS = {
@@ -91,6 +110,8 @@ SYMBOLS = {
     "bnerv_conv_partial_rows": (_I, [C.POINTER(ConvDesc)]),
     "bnerv_conv_wgrad_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bnerv_conv_wgrad": (_I, [_V, C.POINTER(WgradDesc)]),
+    "bnerv_cem_scale_fwd": (_I, [_V, C.POINTER(CemChunk), _V]),
+    "bnerv_cem_scale_bwd": (_I, [_V, C.POINTER(CemChunkBwd), _V, _V, _V]),
     "bnerv_dwconv_fwd": (_I, [_V, _V, _V, _V, _V, _I, _I, _I, _I, _I, _I]),
     "bnerv_dwconv_wgrad_ws_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "bnerv_dwconv_wgrad": (_I, [_V, _V, _V, _V, _V, _Z, _I, _I, _I, _I, _I, _I]),

@@ -434,6 +434,73 @@ def head_tanh(x, w, b):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# CEM compression path: fused quantise + rate term over all weight / bias tensors (row N2)
+# ----------------------------------------------------------------------------------------------------------------------
+class _CemScaleRate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n, training, *tensors):
+        ws, scales, noises = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n]
+        lib = L.load()
+        dev = ws[0].device
+        wc = [L.f32c(L.require_device(w, "w")) for w in ws]
+        sc = [L.f32c(s) for s in scales]
+        nz = [None if z is None else L.f32c(z) for z in noises]
+        deq = [torch.empty_like(w) for w in wc]
+        stats = torch.empty(n, 4, dtype=torch.float32, device=dev)
+        for i0 in range(0, n, L.CEM_MAX_TENSORS):
+            ck = L.CemChunk()
+            m = min(L.CEM_MAX_TENSORS, n - i0)
+            for j in range(m):
+                i = i0 + j
+                assert sc[i].numel() == 1, "the fused CEM kernel handles per-tensor scales"
+                ck.it[j].w, ck.it[j].scale, ck.it[j].dequant, ck.it[j].n = wc[i].data_ptr(), sc[i].data_ptr(), deq[i].data_ptr(), wc[i].numel()
+                ck.it[j].noise = nz[i].data_ptr() if nz[i] is not None else None
+            ck.n_items, ck.training, ck.first = m, int(training), i0
+            L.check(lib.bnerv_cem_scale_fwd(L.stream(), C.byref(ck), L.ptr(stats)), "bnerv_cem_scale_fwd")
+        ctx.n, ctx.training = n, training
+        ctx.save_for_backward(stats, *wc, *sc, *[z for z in nz if z is not None])
+        ctx.has_noise = [z is not None for z in nz]
+        ctx.wshapes = [tuple(w.shape) for w in ws]
+        ctx.mark_non_differentiable(stats)
+        bits = stats[:, 0].clone()
+        return (bits, stats, *deq)
+
+    @staticmethod
+    def backward(ctx, d_bits, _d_stats, *d_deq):
+        n = ctx.n
+        sv = ctx.saved_tensors
+        stats, wc, sc = sv[0], sv[1:1 + n], sv[1 + n:1 + 2 * n]
+        rest = list(sv[1 + 2 * n:])
+        nz = [rest.pop(0) if h else None for h in ctx.has_noise]
+        lib = L.load()
+        dev = stats.device
+        d_bits = None if d_bits is None else L.f32c(d_bits)
+        dds = [None if g is None else L.f32c(g) for g in d_deq]
+        dws = [torch.empty_like(w) for w in wc]
+        dscale = torch.empty(n, dtype=torch.float32, device=dev)
+        for i0 in range(0, n, L.CEM_MAX_TENSORS):
+            ck = L.CemChunkBwd()
+            m = min(L.CEM_MAX_TENSORS, n - i0)
+            for j in range(m):
+                i = i0 + j
+                ck.it[j].w, ck.it[j].scale, ck.it[j].dw, ck.it[j].n = wc[i].data_ptr(), sc[i].data_ptr(), dws[i].data_ptr(), wc[i].numel()
+                ck.it[j].noise = nz[i].data_ptr() if nz[i] is not None else None
+                ck.it[j].d_dequant = dds[i].data_ptr() if dds[i] is not None else None
+            ck.n_items, ck.training, ck.first = m, int(ctx.training), i0
+            L.check(lib.bnerv_cem_scale_bwd(L.stream(), C.byref(ck), L.ptr(stats), L.ptr(d_bits), L.ptr(dscale)), "bnerv_cem_scale_bwd")
+        gs = [dscale[i:i + 1].reshape(sc[i].shape) for i in range(n)]
+        return (None, None, *[dw.reshape(sh) for dw, sh in zip(dws, ctx.wshapes)], *gs, *([None] * n))
+
+
+def cem_scale_rate(ws, scales, noises, training):
+    """Scale_T quantise + Gaussian rate for a list of tensors in one fused pass (include/bnerv.h, bnerv_cem_scale_fwd).
+    Returns (bits [n], stats [n,4] = {bits, mean, std, numel}, [dequant_i]).  noises: list of U(-.5,.5) tensors (training) or Nones."""
+    n = len(ws)
+    out = _CemScaleRate.apply(n, bool(training), *ws, *scales, *noises)
+    return out[0], out[1], list(out[2:])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # depthwise conv of the ConvNeXt encoder block (first kernels of row N3)
 # ----------------------------------------------------------------------------------------------------------------------
 class _DWConv(torch.autograd.Function):

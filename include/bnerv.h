@@ -196,6 +196,23 @@ int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* d);
 
 #define BNERV_LOSS_STATS 5
 /* ------------------------------------------------------------------------------------------------------------------
+ * CEM compression path: the per-step quantise + rate term of model.cal_params(entropy_model)
+ * (model_hnerv.py:292-303) fused over tensors.  Per tensor (per-tensor `scale`, Gaussian rate model):
+ *   code = w / scale;  dequant = round(code) * scale                                   Scale_T.forward, lib/transform_ops.py:239-251
+ *   mu = mean(code), sigma = std(code);  x = code + noise (training) | round(code)      DiffEntropyModel, lib/entropy_model.py:21-43
+ *   bits = sum max(-log2(Phi((x+.5-mu)/sigma) - Phi((x-.5-mu)/sigma) + 1e-5), 0)
+ * stats[item] = {bits, mu, sigma, n}.  Backward: d_bits[item] = dL/d bits, d_dequant = dL/d dequant (NULL: none);
+ * writes dw (NULL: skipped) and dscale[item], including the paths through mu, sigma and the LowerBound gate (:100-114).
+ * `first` = index of the chunk's first tensor in stats / d_bits / dscale (tables travel by value, <= 48 tensors per launch). */
+#define BNERV_CEM_MAX_TENSORS 48
+typedef struct { const float* w; const float* scale; const float* noise; float* dequant; int n; int _pad; } bnerv_cem_item;
+typedef struct { bnerv_cem_item it[BNERV_CEM_MAX_TENSORS]; int n_items; int training; int first; int _pad; } bnerv_cem_chunk;
+typedef struct { const float* w; const float* scale; const float* noise; const float* d_dequant; float* dw; int n; int _pad; } bnerv_cem_item_bwd;
+typedef struct { bnerv_cem_item_bwd it[BNERV_CEM_MAX_TENSORS]; int n_items; int training; int first; int _pad; } bnerv_cem_chunk_bwd;
+int bnerv_cem_scale_fwd(void* stream, const bnerv_cem_chunk* chunk, float* stats);
+int bnerv_cem_scale_bwd(void* stream, const bnerv_cem_chunk_bwd* chunk, const float* stats, const float* d_bits, float* dscale);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Depthwise KxK convolution (K odd <= 7, stride 1, padding K/2) of the ConvNeXt encoder block of HNeRV_Boost
  * (model_blocks.py:223-247: nn.Conv2d(dim, dim, 7, padding=3, groups=dim)); first kernels of SURVEY 8(f) row N3.
  *   bnerv_dwconv_fwd(flip=0): y = conv(x, w) + bias;   flip=1: the data gradient (taps flipped, bias ignored: pass g as x)

@@ -364,3 +364,35 @@ def test_sincos_epilogue_accuracy(ops):
         es = (s_out.double().cpu() - torch.sin(xd)).abs().max().item()
         ec = (c_out.double().cpu() - torch.cos(xd)).abs().max().item()
         assert es < 3e-7 and ec < 3e-7, (span, es, ec)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_cem_fused_quantise_rate_vs_oracle(ops, training):
+    """bnerv_cem_scale_fwd / _bwd against the CPU restatement (oracle/cem_ref.py, itself pinned to the reference): bits, mean, std,
+    dequant and the gradients wrt every tensor and scale of L = sum_i a_i * bits_i + <cot_i, dequant_i>, over tensors of very
+    different sizes and spreads (tiny biases, a 200k-element weight, a nearly constant tensor that drives bits to the 0 floor)."""
+    from oracle import cem_ref
+    g = torch.Generator().manual_seed(21)
+    shapes = [(24, 12, 3, 3), (24,), (750, 30, 3, 3), (3,), (64, 160, 1, 1), (16,)]
+    ws = [(torch.randn(*s, generator=g) * (0.05 if i != 5 else 1e-2) + (0.0 if i != 5 else 0.3)).requires_grad_(True) for i, s in enumerate(shapes)]
+    scales = [cem_ref.scale_init(w.detach(), 8, True).reshape(1).clone().requires_grad_(True) for w in ws]
+    scales[5] = torch.tensor([0.2], requires_grad=True)        # codes 1.5 +- 0.05: sigma << 1, the rate hits the LowerBound floor
+    noises = [torch.rand(w.shape, generator=g) - 0.5 for w in ws]
+    cots = [torch.randn(w.shape, generator=g) for w in ws]
+    a = torch.tensor([1.0, 0.5, 2.0, -1.0, 0.25, 1.5])         # a negative weight exercises the `grad < 0` arm of LowerBound
+    ref_bits, ref_deq = [], []
+    for w, s, z in zip(ws, scales, noises):
+        code, quant, deq = cem_ref.scale_t(w, s)
+        ref_bits.append(cem_ref.cal_bitrate(code, quant, training, noise=z)["bitrate"])
+        ref_deq.append(deq)
+    ref_loss = sum(ai * b for ai, b in zip(a, ref_bits)) + sum((d * c).sum() for d, c in zip(ref_deq, cots))
+    ref_g = torch.autograd.grad(ref_loss, ws + scales)
+    wg, sg = [gpu(w) for w in ws], [gpu(s) for s in scales]
+    bits, stats, deq = ops.cem_scale_rate(wg, sg, [z.to(DEV) for z in noises] if training else [None] * len(ws), training)
+    for i in range(len(ws)):
+        assert abs(bits[i].item() - ref_bits[i].item()) <= 2e-4 * abs(ref_bits[i].item()) + 1e-2, (i, bits[i].item(), ref_bits[i].item())
+        torch.testing.assert_close(deq[i].cpu(), ref_deq[i].detach(), rtol=0, atol=0)
+    loss = (bits * a.to(DEV)).sum() + sum((d * c.to(DEV)).sum() for d, c in zip(deq, cots))
+    got = torch.autograd.grad(loss, wg + sg)
+    for i, (x, r) in enumerate(zip(got, ref_g)):
+        close(x, r, rtol=2e-3, atol=2e-3 * float(r.abs().max()) + 1e-6, msg=f"cem grad {i}")
