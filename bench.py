@@ -44,6 +44,13 @@ RECIPES = {
                "--conv_type convnext pshuffel_3x3 --act sin --norm none --crop_list 1080_1920 --resize_list -1 --loss Fusion10_freq "
                "--embed pe_1.25_80 --fc_hw 9_16 --dec_strds 5 3 2 2 2 --ks 0_3_3 --reduce 2 --dec_blks 1 1 2 2 2 --modelsize 1.8 -e 300 "
                "--eval_freq 30 --lower_width 12 -b 1 --lr 0.0015", name="E-NeRV-boost 3M"),
+    # scripts/compression/hnerv_boost.sh:7-16 (BASELINE configs[4]: the C3 model built with --quant, rate-distortion step)
+    "c5": dict(n=600, h=1080, w=1920, flags="--model HNeRV_Boost --sft_block res_sft --ch_t 32 --optim_type Adan --conv_type convnext pshuffel_3x3 "
+               "--act sin --norm none --crop_list 1080_1920 --resize_list -1 --loss Fusion10_freq --embed pe_1.25_80 --enc_strds 5 3 2 2 2 "
+               "--enc_dim 64_16 --dec_strds 5 3 2 2 2 --ks 0_1_5 --reduce 1.2 --dec_blks 1 1 2 2 2 --modelsize 2.8 -e 100 --eval_freq 30 "
+               "--lower_width 12 -b 1 --lr 0.0005 --lr_type cosine_0_1_0.1 --embed_entropy --quant --quant_model_bit 8 --quant_bias_bit 8 "
+               "--quant_embed_bit 8 --quantizer_w scale --quantizer_b scale --quantizer_e scalebeta --lambda_rate 0.05 --target_bit 4",
+               name="HNeRV-boost 3M, CEM compression step"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
 PEAK_HBM_GBS = 8000.0
@@ -52,7 +59,9 @@ PEAK_HBM_GBS = 8000.0
 def build(cfg_name):
     from boosting_nerv_amd import train_nerv_all as T
     r = RECIPES[cfg_name]
-    args = T.build_parser().parse_args(r["flags"].split() + ["--data_path", f"synthetic:{r['n']}x{r['h']}x{r['w']}", "--vid", "bench"])
+    if cfg_name == "c5":
+        from boosting_nerv_amd import train_nerv_compression as T5
+    args = (T5 if cfg_name == "c5" else T).build_parser().parse_args(r["flags"].split() + ["--data_path", f"synthetic:{r['n']}x{r['h']}x{r['w']}", "--vid", "bench"])
     args.final_size = r["h"] * r["w"]
     args.full_data_length = r["n"]
     args.outf = "bench"
@@ -197,6 +206,31 @@ def main():
     args.epochs = 300
     n_iter = len(keep)
 
+    if a.config == "c5":                                       # compression step (train_nerv_compression.py:354-367), eager
+        from boosting_nerv_amd import ops
+        from boosting_nerv_amd.hnerv_utils import loss_fn
+        from boosting_nerv_amd.lib.entropy_model import DiffEntropyModel
+        em = DiffEntropyModel("gaussian")
+        model.init_data()
+        model.train()
+        final_size, n_full = r["h"] * r["w"], r["n"]
+        target_bpp = args.target_bit * (sum(p.numel() for p in model.parameters()) / 1e6) * 1e6 / final_size / n_full
+
+        class _CemStep:
+            loss_out = psnr_out = None
+
+            def __call__(self, img, nidx):
+                model.cal_params(em)
+                img_out, _, _ = model(img, entropy_model=em, norm_idx=nidx)
+                bpp = (model.get_bitrate_sum(name="bitrate") + model.bitrate_e_dict["bitrate"] * n_full) / final_size
+                out_loss = loss_fn(img_out, img, args.loss)
+                final = out_loss + (bpp.detach() / n_full > target_bpp).to(out_loss.dtype) * args.lambda_rate * bpp
+                opt.zero_grad()
+                final.backward()
+                opt.step()
+                self.loss_out, self.psnr_out = final.detach(), ops.psnr(img_out.detach(), img)
+        step = _CemStep()
+
     def run(k0, k):
         for s in range(k0, k0 + k):
             i = s % n_iter
@@ -224,10 +258,11 @@ def main():
                "warmup": max(a.warmup, 5), "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
                "config": {"workload": f"{r['name']} ({n_params} params, fc_dim {args.fc_dim}) train step on a synthetic "
-                                      f"{'Bunny' if a.config == 'c1' else 'UVG'}-shaped clip {r['n']}x3x{r['h']}x{r['w']}: decoder fwd + {args.loss} + bwd + "
+                                      f"{'Bunny' if a.config == 'c1' else 'UVG'}-shaped clip {r['n']}x3x{r['h']}x{r['w']}: "
+                                      f"{'quantise + rate term (CEM) + ' if a.config == 'c5' else ''}decoder fwd + {args.loss} + bwd + "
                                       f"{'flat-bucket RCCL all-reduce + ' if world > 1 else ''}fused Adan; frames resident in HBM",
-                          "baseline_config": {"c1": "configs[1]", "c3": "configs[2]", "c4": "configs[3]"}[a.config], "global_batch": per_gpu_batch * world,
-                          "per_gpu_batch": per_gpu_batch, "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
+                          "baseline_config": {"c1": "configs[1]", "c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]"}[a.config], "global_batch": per_gpu_batch * world,
+                          "per_gpu_batch": per_gpu_batch, "parallelism": f"dp{world}", "hipgraph": (not a.no_graph) and a.config != "c5",
                           "last_loss": round(loss, 4), "last_train_psnr_db": round(psnr, 3)}}
         out["roofline"] = dominant_kernel_roofline(dev) if a.config == "c1" else None
         if world == 1 and not a.no_cpu_baseline:

@@ -253,3 +253,22 @@ def test_patchify_conv_equals_conv2d():
     other = nn.Conv2d(4, 4, 3, stride=1, padding=1)
     x = torch.randn(1, 4, 6, 6)
     assert torch.equal(patchify_conv(x, other), other(x))
+
+
+def test_cem_model_surface_matches_reference():
+    """--quant build of HNeRV_Boost: state_dict keys (quantiser parameters included) equal the reference's (golden), the
+    compression CLI parses the recipe's flags, and the un-built quantisers fail loudly."""
+    from boosting_nerv_amd import train_nerv_compression as C
+    from boosting_nerv_amd.lib.transform_ops import quant_map
+    from boosting_nerv_amd.model_hnerv import HNeRV_Boost
+    npz = load_golden("cem_model.npz")
+    keys = [k[len("sd/"):] for k in npz.files if k.startswith("sd/")]
+    torch.manual_seed(1)
+    model = HNeRV_Boost(configs.tiny_hnerv_quant())
+    assert list(model.state_dict().keys()) == keys
+    assert sum("quantizer" in k for k in keys) > 50
+    a = C.build_parser().parse_args("--quant --quant_model_bit 8 --quant_bias_bit 8 --quant_embed_bit 8 --quantizer_w scale --quantizer_b scale "
+                                    "--quantizer_e scalebeta --lambda_rate 0.05 --target_bit 4 --embed_entropy --lr_type cosine_0_1_0.1 --not_resume".split())
+    assert a.quant and a.quantizer_e == "scalebeta" and a.lambda_rate == 0.05 and a.target_bit == 4 and a.embed_entropy
+    with pytest.raises(NotImplementedError):
+        quant_map["lsq"](8, signed=True)
