@@ -409,3 +409,33 @@ def test_cem_hooks_against_reference_golden():
         # (d/d beta is analytically 0 for the distortion path -- dequant = ste((x - beta)/scale)*scale + beta -- and ~1e-8 of rounding
         #  noise on both sides for the rate path: absolute floor)
         torch.testing.assert_close(p.grad.cpu(), torch.from_numpy(npz[f"grad/{k}"]), rtol=2e-3, atol=2e-3 * float(np.abs(npz[f"grad/{k}"]).max()) + 1e-6)
+
+
+def test_compression_cli_end_to_end(tmp_path, monkeypatch):
+    """train_nerv_compression.py on a tiny synthetic clip (4 frames, 180x320, tiny HNeRV_Boost): 3 epochs of the rate-distortion
+    step with the fused CEM kernel, then the evaluation report.  The rate must fall (lambda pushes it towards the target), the
+    quality metrics must be finite, and the estimated and ideal-code bits per pixel must agree closely."""
+    import types
+    from boosting_nerv_amd import train_nerv_compression as C
+    monkeypatch.chdir(tmp_path)
+    flags = ("--outf t --data_path synthetic:4x180x320 --vid tiny --model HNeRV_Boost --sft_block res_sft --ch_t 32 --optim_type Adan "
+             "--conv_type convnext pshuffel_3x3 --act sin --norm none --crop_list 180_320 --resize_list -1 --loss Fusion10_freq --embed pe_1.25_80 "
+             "--enc_strds 5 2 2 --enc_dim 16_4 --dec_strds 5 2 2 --ks 0_1_5 --reduce 1.2 --dec_blks 1 1 2 --modelsize 0.05 --lower_width 6 -b 1 "
+             "-e 3 --eval_freq 3 --lr 0.002 --lr_type cosine_0_1_0.1 --not_resume --embed_entropy --quant --quant_model_bit 8 --quant_bias_bit 8 "
+             "--quant_embed_bit 8 --quantizer_w scale --quantizer_b scale --quantizer_e scalebeta --lambda_rate 0.5 --target_bit 2 -p 1")
+    seen = {}
+    orig_eval = C.evaluate
+
+    def spy(model, loader, rank, args, *a, **k):
+        out = orig_eval(model, loader, rank, args, *a, **k)
+        seen["args"], seen["results"] = args, out[0]
+        return out
+    monkeypatch.setattr(C, "evaluate", spy)
+    C.main(flags.split())
+    args = seen["args"]
+    assert 0 < args.total_bpp < 64 and abs(args.total_bpp - args.estimate_bpp) <= 0.05 * args.estimate_bpp
+    q_psnr = seen["results"][4]
+    assert torch.isfinite(q_psnr).all() and q_psnr.item() > 5.0
+    log = (tmp_path / "output" / "t" / "tiny" / "Size0.05" / "rank0.txt").read_text()
+    bpps = [float(x.split("bpp:")[1]) for x in log.splitlines() if "bpp:" in x and "Epoch[" in x]
+    assert len(bpps) >= 6 and bpps[-1] < bpps[0], bpps
