@@ -737,6 +737,13 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 }
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, (int)voff, (int)soff, 0);
+    // Measured on gfx950 (tools/klean2.py, ROCm 7.2): a VALU write of the store's data VGPRs two instructions after a 128-bit
+    // buffer store WITH AN SGPR soffset corrupts lanes 12..15 of every row of 16 (the store reads its upper data late).  LLVM's
+    // hazard recognizer pads this case only when soffset is not a register, so the wait states are inserted here, fenced so that
+    // the scheduler cannot move a VALU instruction in between.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 3");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 struct LItem { int b, ty, tx; };
@@ -1127,6 +1134,366 @@ int launch_lean(hipStream_t st, KArgs& ka) {
     return BNERV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- lean2 kernel
+// The lean recipe for the layers the first lean kernel does not take: Cin > 16 (K walked in chunks of 16 channels, the next
+// (tile, chunk) stage prefetched into registers under the MFMA phase of the current one) and/or Cout > 16 (NTB <= 3 cout
+// tiles per block, the input tile staged once for all of them).  Stride-1 outputs only: the epilogue works straight from the
+// accumulators for every cout tile.  These are the TAT convolutions, heads and their data gradients of the 3M models
+// (22..55 channels) and of C1's 30-channel stage; the generic kernel keeps PixelShuffle outputs and the unshuffle prologue.
+template <int KS, int IN, int EP, int NTB>
+__global__ __launch_bounds__(256, (NTB <= 2 ? 3 : 2)) void conv_lean2_kernel(const KArgs ka, const SidePack side) {
+    using G = Geo<KS>;
+    constexpr int NQ1 = 4, NCH = 16;
+    constexpr int NSLOT = NCH * G::ROWS * G::SEGS;
+    constexpr int NPRE = (NSLOT + 255) / 256;
+    constexpr int S_IN = NCH * G::PLANE + (NPRE * 256 - NSLOT) * 4;
+    constexpr bool TWO = (IN == BNERV_IN_TANHGRAD);
+    constexpr bool AFF = (IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE);
+    constexpr bool RED = (EP == BNERV_EP_DGELU || EP == BNERV_EP_DSIN || EP == BNERV_EP_DGELU_SAVED);
+    constexpr int AFF_MAX = 128;                           // input channels whose affine parameters fit the LDS table
+    const bnerv_conv_desc& d = ka.d;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;
+    float* s_red = smem + S_IN;                            // [4 waves][2][NTB*16]
+    float* s_aff = s_red + 4 * 2 * NTB * 16;               // [2][AFF_MAX]
+    float* s_w = s_aff + 2 * AFF_MAX;                      // resident: T*nq_total*NTB*64 ; else T*NQ1*NTB*64
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
+    const int nchunks = (Cin + NCH - 1) / NCH;
+    const int qstride = ka.w_resident ? ka.nq_total : NQ1;
+
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const int nlb = (gridDim.x - xcd + 7) >> 3;
+    const int per = ka.total_items >> 3, extra = ka.total_items & 7;
+    const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
+    int itx = r0 + lb;
+    if (itx >= r1) { side_run_hosted(side, smem); return; }
+
+    auto slot_geom = [&](int k, int& c, int& r, int& sg) {
+        const int sidx = tid + k * 256;
+        c = sidx / (G::ROWS * G::SEGS);
+        const int rem = sidx - c * (G::ROWS * G::SEGS);
+        r = rem / G::SEGS;
+        sg = rem - r * G::SEGS;
+    };
+    auto slot_inside = [&](int k, int ty0, int tx0) {
+        int c, r, sg;
+        slot_geom(k, c, r, sg);
+        const int gy = ty0 + r - G::PAD, gx = tx0 + 4 * sg - G::XOFF;
+        return (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    };
+    auto loff = [&](int k) {
+        const int sidx = tid + k * 256;
+        if constexpr (G::PLANE == G::PLANE_RAW) return sidx * 16;
+        int c, r, sg;
+        slot_geom(k, c, r, sg);
+        return sidx < NSLOT ? (c * G::PLANE + r * G::RS + 4 * sg) * 4 : (NCH * G::PLANE + (sidx - NSLOT) * 4) * 4;
+    };
+    unsigned voff[NPRE];                                   // chunk-local: channel c of the chunk
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        int c, r, sg;
+        slot_geom(k, c, r, sg);
+        voff[k] = (tid + k * 256 < NSLOT) ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB;
+    }
+    const unsigned shift = (unsigned)((G::PAD * W + G::XOFF) * 4);
+    const unsigned in_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
+    const unsigned out_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, in_bytes);
+    const __amdgpu_buffer_rsrc_t rx2 = make_rsrc(TWO ? d.aux0 : d.x, shift, in_bytes);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ro2 = make_rsrc(((EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) && d.out2) ? d.out2 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ra0 = make_rsrc((!TWO && d.aux0) ? d.aux0 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(d.aux1 ? d.aux1 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ra2 = make_rsrc(d.aux2 ? d.aux2 : d.out, 0, out_bytes);
+
+    auto load_affine = [&](int b) {                        // s_aff[c] = 1 + scale[b][c], s_aff[AFF_MAX + c] = shift[b][c]; 0 beyond Cin
+        lds_barrier();
+        for (int i = tid; i < 2 * AFF_MAX; i += 256) {
+            const int c = i < AFF_MAX ? i : i - AFF_MAX;
+            float v = 0.f;
+            if (c < Cin) v = i < AFF_MAX ? 1.0f + d.scale[b * Cin + c] : d.shift[b * Cin + c];
+            s_aff[i] = v;
+        }
+        lds_barrier();
+    };
+
+    f32x4 ra[NPRE], rb[TWO ? NPRE : 1];
+    // stage = (item, chunk); issue its loads / commit them to s_in
+    auto issue = [&](const Item& a, int c0) {
+        const unsigned sb = (unsigned)((((a.b * Cin + c0) * H + a.ty0) * W + a.tx0) * 4);
+        const bool interior = a.ty0 >= G::PAD && a.ty0 + TH + G::PAD <= H && a.tx0 >= G::XOFF && a.tx0 + TW + G::XOFF <= W;
+        const int nch = min(NCH, Cin - c0);
+        const bool plain = interior && nch == NCH;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            unsigned vo = voff[k];
+            if (!plain) {
+                int c, r, sg;
+                slot_geom(k, c, r, sg);
+                if (c >= nch || (!interior && !slot_inside(k, a.ty0, a.tx0))) vo = OOB;
+            }
+            ra[k] = bload(rx, vo, sb);
+            if constexpr (TWO) rb[k] = bload(rx2, vo, sb);
+        }
+    };
+    auto commit = [&](const Item& a, int c0) {
+        const bool interior = a.ty0 >= G::PAD && a.ty0 + TH + G::PAD <= H && a.tx0 >= G::XOFF && a.tx0 + TW + G::XOFF <= W;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            f32x4 v = ra[k];
+            if constexpr (IN != BNERV_IN_PLAIN) {
+                float sc_ = 0.f, sh_ = 0.f;
+                if constexpr (AFF) {
+                    int c, r, sg;
+                    slot_geom(k, c, r, sg);
+                    const int ci = min(c0 + c, AFF_MAX - 1);          // channels >= Cin hold 0 (loads returned 0 -> stays 0)
+                    sc_ = s_aff[ci];
+                    sh_ = s_aff[AFF_MAX + ci];
+                    if (!interior) {
+                        const bool ok = slot_inside(k, a.ty0, a.tx0);
+                        sc_ = ok ? sc_ : 0.f;
+                        sh_ = ok ? sh_ : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = xform1<IN>(v[e], sc_, sh_, TWO ? rb[k][e] : 0.f);
+            }
+            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(s_in) + loff(k)) = v;
+        }
+    };
+    auto flush_partials = [&](const Item& a, int co_base) {
+        if (wave == 0) {
+            for (int idx = lane; idx < 2 * NTB * 16; idx += 64) {
+                const int q = idx / (NTB * 16), c = idx - q * (NTB * 16);
+                const float sum = ((s_red[(0 * 2 + q) * NTB * 16 + c] + s_red[(1 * 2 + q) * NTB * 16 + c]) + s_red[(2 * 2 + q) * NTB * 16 + c]) + s_red[(3 * 2 + q) * NTB * 16 + c];
+                const size_t row = (size_t)a.tile * d.B + a.b;
+                if (co_base + c < Cout) d.partial[(row * 2 + q) * Cout + co_base + c] = sum;
+            }
+        }
+    };
+
+    Item it = decode_item(ka, itx);
+    int cur_g = -1, aff_b = -1;
+    if constexpr (AFF) { load_affine(it.b); aff_b = it.b; }
+    issue(it, 0);
+    commit(it, 0);
+    const int abase = kq * G::PLANE + (2 * wave) * G::RS + li + G::COL0;
+    Item prev = it;
+    bool have_prev = false;
+    float scl[NTB];
+#pragma unroll
+    for (int n = 0; n < NTB; ++n) scl[n] = 0.f;
+
+    for (; itx < r1; itx += nlb) {
+        const int co_base = it.g * NTB * 16;
+        f32x4 acc[4][NTB];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < NTB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ka.w_resident && cur_g != it.g) {
+            lds_barrier();
+            stage_weights<KS, NTB>(d, s_w, co_base, 0, ka.nq_total, qstride);
+            cur_g = it.g;
+        }
+        const bool has_next = itx + nlb < r1;
+        Item nxt = it;
+        if (has_next) nxt = decode_item(ka, itx + nlb);
+
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int c0 = ch * NCH;
+            const int nq = (min(NCH, Cin - c0) + 3) >> 2;
+            const bool last_chunk = ch == nchunks - 1;
+            if (!ka.w_resident) stage_weights<KS, NTB>(d, s_w, co_base, c0 >> 2, nq, qstride);   // after the previous stage's barrier (B)
+            lds_barrier();                                 // (A) this stage's s_in / s_w (and s_red of the previous item) visible
+            if (!last_chunk) issue(it, c0 + NCH);          // next stage's loads fly under the MFMA phase
+            else if (has_next) issue(nxt, 0);
+            if constexpr (RED) { if (ch == 0 && have_prev) flush_partials(prev, prev.g * NTB * 16); }
+            const int qb = ka.w_resident ? (c0 >> 2) : 0;
+#pragma unroll 1
+            for (int ky = 0; ky < KS; ++ky) {
+                const float* a_row = s_in + abase + ky * G::RS;
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const float* b_row = s_w + ((ky * KS + kx) * qstride + qb) * NTB * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < NQ1; ++q) {
+                        if (q < nq) {
+                            float af[4], bf[NTB];
+#pragma unroll
+                            for (int n = 0; n < NTB; ++n) bf[n] = b_row[(q * NTB + n) * 64];
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) af[m] = a_row[q * 4 * G::PLANE + (m >> 1) * G::RS + (m & 1) * 16 + kx];
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                                for (int n = 0; n < NTB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[n], acc[m][n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            lds_barrier();                                 // (B) every wave is done reading this stage
+            if (!last_chunk) commit(it, c0 + NCH);
+            else if (has_next) {
+                if constexpr (AFF) { if (nxt.b != aff_b) { load_affine(nxt.b); aff_b = nxt.b; } }
+                commit(nxt, 0);
+            }
+        }
+
+        // ---- epilogue straight from the accumulators, one cout tile after the other
+        {
+            const int ty0 = it.ty0, tx0 = it.tx0;
+            const bool full = ty0 + TH <= H && tx0 + TW <= W;
+            if constexpr (RED) {
+                {
+#pragma unroll
+                    for (int n = 0; n < NTB; ++n) { const int co = co_base + n * 16 + li; scl[n] = co < Cout ? 1.0f + d.scale[it.b * Cout + co] : 0.f; }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NTB; ++n) {
+                const int co = co_base + n * 16 + li;
+                if (co_base + n * 16 >= Cout) continue;    // uniform
+                const unsigned ovoff = co < Cout ? (unsigned)(((co * H) * W + 4 * kq) * 4) : OOB;
+                const float bias_l = (EP != BNERV_EP_PLAIN && !RED && d.bias && co < Cout) ? d.bias[co] : 0.f;
+                const unsigned ob = (unsigned)((((it.b * Cout) * H + ty0 + 2 * wave) * W + tx0) * 4);
+                unsigned so[4], vo[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    so[m] = ob + (unsigned)(((m >> 1) * W + (m & 1) * 16) * 4);
+                    vo[m] = ovoff;
+                    if (!full) {
+                        const bool ok = ty0 + 2 * wave + (m >> 1) < H && tx0 + (m & 1) * 16 + 4 * kq < W;
+                        vo[m] = ok ? ovoff : OOB;
+                        if constexpr (RED) { if (!ok) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    }
+                }
+                if constexpr (EP == BNERV_EP_BIAS || EP == BNERV_EP_PLAIN) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) bstore(ro, vo[m], so[m], acc[m][n] + bias_l);
+                } else if constexpr (EP == BNERV_EP_BIAS_GELU) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        f32x4 hv, gv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { float h_, g_; gelu_pair_f(acc[m][n][e] + bias_l, &h_, &g_); hv[e] = h_; gv[e] = g_; }
+                        bstore(ro, vo[m], so[m], hv);
+                        if (d.out2) bstore(ro2, vo[m], so[m], gv);
+                    }
+                } else if constexpr (EP == BNERV_EP_BIAS_SIN) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        f32x4 sv, cv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(acc[m][n][e] + bias_l, &s_, &c_); sv[e] = s_; cv[e] = c_; }
+                        bstore(ro, vo[m], so[m], sv);
+                        if (d.out2) bstore(ro2, vo[m], so[m], cv);
+                    }
+                } else if constexpr (EP == BNERV_EP_BIAS_TANH) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        f32x4 r;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[e] = tanhf(acc[m][n][e] + bias_l) * 0.5f + 0.5f;
+                        bstore(ro, vo[m], so[m], r);
+                    }
+                } else if constexpr (EP == BNERV_EP_BIAS_RES) {
+                    f32x4 a0[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a0[m] = bload(ra0, vo[m], so[m]);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) bstore(ro, vo[m], so[m], acc[m][n] + bias_l + a0[m]);
+                } else {                                   // DGELU / DGELU_SAVED / DSIN
+                    f32x4 a0[4], a1[4], a2[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        a0[m] = bload(ra0, vo[m], so[m]);
+                        if constexpr (EP == BNERV_EP_DGELU_SAVED) a1[m] = bload(ra1, vo[m], so[m]);
+                        if constexpr (EP == BNERV_EP_DSIN) {
+                            a1[m] = bload(ra1, vo[m], so[m]);
+                            a2[m] = f32x4{1.f, 1.f, 1.f, 1.f};
+                            if (d.aux2) a2[m] = bload(ra2, vo[m], so[m]);
+                        }
+                    }
+                    float ps = 0.f, pt = 0.f;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        f32x4 r;
+                        const f32x4 v = acc[m][n];
+                        if constexpr (EP == BNERV_EP_DGELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { r[e] = v[e] * scl[n] * gelu_grad_f(a0[m][e]); ps = fmaf(v[e], gelu_f(a0[m][e]), ps); pt += v[e]; }
+                        } else if constexpr (EP == BNERV_EP_DGELU_SAVED) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { r[e] = v[e] * scl[n] * a0[m][e]; ps = fmaf(v[e], a1[m][e], ps); pt += v[e]; }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { r[e] = (a1[m][e] + v[e] * scl[n]) * a2[m][e]; ps = fmaf(v[e], a0[m][e], ps); pt += v[e]; }
+                        }
+                        bstore(ro, vo[m], so[m], r);
+                    }
+                    ps += __shfl_xor(ps, 16, 64);
+                    pt += __shfl_xor(pt, 16, 64);
+                    ps += __shfl_xor(ps, 32, 64);
+                    pt += __shfl_xor(pt, 32, 64);
+                    if (lane < 16) { s_red[(wave * 2 + 0) * NTB * 16 + n * 16 + lane] = ps; s_red[(wave * 2 + 1) * NTB * 16 + n * 16 + lane] = pt; }
+                }
+            }
+        }
+        prev = it;
+        have_prev = true;
+        it = nxt;
+    }
+    if constexpr (RED) {
+        lds_barrier();
+        flush_partials(prev, prev.g * NTB * 16);
+    }
+    side_run_hosted(side, smem);
+}
+
+template <int KS, int IN, int EP, int NTB>
+int launch_lean2(hipStream_t st, KArgs& ka) {
+    using G = Geo<KS>;
+    const bnerv_conv_desc& d = ka.d;
+    constexpr int NSLOT = 16 * G::ROWS * G::SEGS;
+    constexpr int NPRE = (NSLOT + 255) / 256;
+    const int nt = cdiv(d.Cout, 16);
+    ka.ngroups = cdiv(nt, NTB);
+    ka.total_items = ka.ngroups * d.B * ka.tiles_x * ka.tiles_y;
+    ka.nq_total = cdiv(d.Cin, 16) * 4;                     // chunk-aligned: chunk ch owns q = 4 ch .. 4 ch + 3
+    const size_t wres = (size_t)G::T * ka.nq_total * NTB * 64;
+    ka.w_resident = wres <= (size_t)W_RESIDENT_MAX ? 1 : 0;
+    const size_t wfl = ka.w_resident ? wres : (size_t)G::T * 4 * NTB * 64;
+    const size_t lds = ((size_t)16 * G::PLANE + (size_t)(NPRE * 256 - NSLOT) * 4 + (size_t)4 * 2 * NTB * 16 + 2 * 128 + wfl) * sizeof(float);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean2_kernel<KS, IN, EP, NTB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_lean2_kernel<KS, IN, EP, NTB>), 256, lds) != hipSuccess || nb < 1) nb = 1;
+    int grid = 256 * (nb > 4 ? 4 : nb);
+    if (grid > ka.total_items) grid = ka.total_items;
+    SidePack side;
+    bnerv_side_take(&side, 2 * grid);
+    hipLaunchKernelGGL((conv_lean2_kernel<KS, IN, EP, NTB>), dim3(grid), dim3(256), lds, st, ka, side);
+    BNERV_LAUNCH_CHECK("conv_lean2");
+    return BNERV_OK;
+}
+
+static bool lean2_ok(const KArgs& ka) {
+    const bnerv_conv_desc& d = ka.d;
+    const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
+    static const bool off = getenv("BNERV_NO_LEAN2") != nullptr;          // A/B switch for tools/kbench.py
+    if (off) return false;
+    return ka.vec && d.out_s == 1 && d.k == 3 && (d.Cin > 16 || d.Cout > 16) && d.Cin <= 128 && ka.ksplit == 1 &&
+           (size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 < LEAN_MAX_BYTES;
+}
+
 static bool lean_ok(const KArgs& ka) {
     const bnerv_conv_desc& d = ka.d;
     const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
@@ -1136,6 +1503,11 @@ static bool lean_ok(const KArgs& ka) {
 
 template <int KS, int IN, int EP, int NTB>
 int launch_one(hipStream_t st, KArgs& ka) {
+    if constexpr (KS == 3 && IN != BNERV_IN_UNSHUFFLE && NTB <= 3 &&
+                  (EP == BNERV_EP_BIAS || EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU || EP == BNERV_EP_BIAS_RES || EP == BNERV_EP_BIAS_TANH || EP == BNERV_EP_PLAIN ||
+                   EP == BNERV_EP_DGELU_SAVED || EP == BNERV_EP_DSIN)) {
+        if (lean2_ok(ka)) return launch_lean2<KS, IN, EP, NTB>(st, ka);
+    }
     if constexpr (IN != BNERV_IN_UNSHUFFLE && NTB == 1) {
         if (lean_ok(ka)) {
             if (ka.d.Cin <= 12) return launch_lean<KS, IN, EP, 3>(st, ka);

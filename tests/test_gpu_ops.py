@@ -143,7 +143,7 @@ def _tat_ref(x0, mods, w0, b0, w1, b1):
     return x0 + F.conv2d(f * (s1 + 1) + t1, w1, b1, padding=1)
 
 
-@pytest.mark.parametrize("shape", [(1, 12, 16, 64), (2, 15, 11, 13), (1, 30, 45, 80), (2, 38, 9, 40)])
+@pytest.mark.parametrize("shape", [(1, 12, 16, 64), (2, 15, 11, 13), (1, 30, 45, 80), (2, 38, 9, 40), (2, 55, 17, 36), (1, 95, 10, 44), (3, 17, 8, 32)])
 def test_tat_block(ops, shape):
     x0, mods, w0, b0, w1, b1, g = _tat_inputs(*shape, seed=7)
     ref = _tat_ref(x0, mods, w0, b0, w1, b1)
