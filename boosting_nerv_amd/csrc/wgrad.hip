@@ -66,15 +66,19 @@ __device__ __forceinline__ float load_g_scalar(const bnerv_wgrad_desc& d, int b,
     }
 }
 
+// input planes spanned by NTW*16 consecutive (ci, tap) columns starting anywhere
+template <int KS, int NTW> constexpr int wgrad_npl() { return KS == 3 ? (NTW * 16 + 7) / 9 + 1 : NTW * 16; }
+
 template <int KS, int IN, int GM, int MTW, int NTW>
 __global__ __launch_bounds__(256, (MTW * NTW <= 7 ? 3 : 2)) void conv_wgrad_kernel(const WArgs wa) {
     using G = Geo<KS>;
     constexpr bool PIPE = (MTW == 1);                          // register-prefetch the next tile under the MFMA phase
+    constexpr int NPL = wgrad_npl<KS, NTW>();                  // data planes (input channels) a block's NTW*16 columns can touch
     constexpr bool GTWO = true;                                // GM is UNSHUFFLE or TANHGRAD: both may need a second float4
     const bnerv_wgrad_desc& d = wa.d;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_g = smem;                                  // MTW*16*CSG
-    float* s_in = smem + MTW * 16 * CSG;                // (NPL + 2) * PLANE
+    float* s_g = smem;                                  // g_rows * CSG: rows beyond Cout are not kept -- the A reads of those rows see
+                                                        // s_in data, which only reaches output rows that are dropped
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -82,6 +86,8 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 7 ? 3 : 2)) void conv_wgrad_kern
     const int co_base = mg * MTW * 16;
     const int n_base = ngp * NTW * 16;
     const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
+    const int g_rows = min(MTW * 16, Cout - co_base);
+    float* s_in = smem + g_rows * CSG;                  // (NPL + 2) * PLANE
     const int nW = Cin * G::T;                          // weight columns; column nW is the bias column
     const int ci_lo = min(n_base, nW - 1) / G::T;
     const int ci_hi = min(n_base + NTW * 16 - 1, nW - 1) / G::T;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 7 ? 3 : 2)) void conv_wgrad_kern
     const int nx_slots = npl * G::ROWS * G::SEGS;
 
     // constant planes: ones (bias column) and zeros (columns beyond the matrix)
-    for (int i = tid; i < 2 * G::PLANE; i += 256) s_in[G::NPL * G::PLANE + i] = i < G::PLANE ? 1.0f : 0.0f;
+    for (int i = tid; i < 2 * G::PLANE; i += 256) s_in[NPL * G::PLANE + i] = i < G::PLANE ? 1.0f : 0.0f;
 
     // per-lane fragment bases.  pixel of (wave, step, kq): p = wave*64 + step*4 + kq
     int bbase[NTW];
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 7 ? 3 : 2)) void conv_wgrad_kern
             const int ci = n / G::T, tap = n - ci * G::T;
             off = (ci - ci_lo) * G::PLANE + (tap / KS) * G::RS + (tap % KS) + G::COL0;
         } else {
-            off = (n == nW ? G::NPL : G::NPL + 1) * G::PLANE;
+            off = (n == nW ? NPL : NPL + 1) * G::PLANE;
         }
         bbase[nt] = off + (2 * wave) * G::RS + kq;
     }
@@ -141,6 +147,7 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 7 ? 3 : 2)) void conv_wgrad_kern
     auto g_store = [&](int sidx, f32x4 a, f32x4 bq) {
         if (sidx >= ng_slots) return;
         const int c = sidx >> 6, rem = sidx & 63, r = rem >> 3, sg = rem & 7;
+        if ((pair ? 2 * c : c) >= g_rows) return;          // (Cout is even on the pair path)
         if (pair) {
             float* dst = s_g + (2 * c) * CSG + r * TW + 4 * sg;                 // 8-B aligned (CSG*4 = 1032)
             *reinterpret_cast<float2*>(dst) = float2{a[0], a[2]};
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 7 ? 3 : 2)) void conv_wgrad_kern
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int idx = i0 + u * 256;
-                if (idx < MTW * 16 * TH * TW) s_g[(idx >> 8) * CSG + (idx & 255)] = v[u];
+                if (idx < MTW * 16 * TH * TW && (idx >> 8) < g_rows) s_g[(idx >> 8) * CSG + (idx & 255)] = v[u];
             }
         }
     };
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 7 ? 3 : 2)) void conv_wgrad_kern
     };
 
     constexpr int NGS = MTW * 16 * TH * (TW / 4) / 256;           // g slots per thread (pair path uses half of them)
-    constexpr int NXS = (G::NPL * G::ROWS * G::SEGS + 255) / 256;
+    constexpr int NXS = (NPL * G::ROWS * G::SEGS + 255) / 256;
     f32x4 ga[PIPE ? NGS : 1], gb[PIPE && GTWO ? NGS : 1], xa[PIPE ? NXS : 1];
 
     auto issue = [&](int b, int ty0, int tx0) {                  // PIPE only
@@ -322,24 +329,32 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 7 ? 3 : 2)) void conv_wgrad_kern
         }
     }
 
-    // cross-wave reduction through LDS (fixed order => deterministic), then ONE slab per block:
-    // slab[block][co][n]; D layout: lane holds rows (cout) 4*kq..4*kq+3 of column (n) li
+    // cross-wave reduction through LDS, then ONE slab per block: slab[block][co][n]; D layout: lane holds rows (cout)
+    // 4*kq..4*kq+3 of column (n) li.  The waves add their accumulators ONE AFTER THE OTHER into a single [MTW*16][NTW*16] area
+    // (fixed order 0,1,2,3 => deterministic): four separate areas would need more LDS than the staging buffers (86 KB for the
+    // 3x7 shape) and cost the second resident block per CU.
     __syncthreads();
     float* s_red = smem;
     constexpr int RW = NTW * 16, RSZ = MTW * 16 * RW;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int m = 0; m < MTW; ++m)
+            for (int m = 0; m < MTW; ++m)
 #pragma unroll
-        for (int n = 0; n < NTW; ++n)
+                for (int n = 0; n < NTW; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_red[wave * RSZ + (m * 16 + 4 * kq + r) * RW + n * 16 + li] = acc[m][n][r];
-    __syncthreads();
+                    for (int r = 0; r < 4; ++r) {
+                        float* q = s_red + (m * 16 + 4 * kq + r) * RW + n * 16 + li;
+                        *q = (w == 0) ? acc[m][n][r] : *q + acc[m][n][r];
+                    }
+        }
+        __syncthreads();
+    }
     float* slab = wa.slab + (size_t)blockIdx.x * Cout * wa.ncols;
     for (int idx = tid; idx < RSZ; idx += 256) {
         const int row = idx / RW, colq = idx - row * RW;
         const int co = co_base + row, col = n_base + colq;
-        if (co < Cout && col < wa.ncols)
-            slab[(size_t)co * wa.ncols + col] = (s_red[idx] + s_red[RSZ + idx]) + (s_red[2 * RSZ + idx] + s_red[3 * RSZ + idx]);
+        if (co < Cout && col < wa.ncols) slab[(size_t)co * wa.ncols + col] = s_red[idx];
     }
 }
 
@@ -770,14 +785,17 @@ Plan make_plan(int B, int Cin, int Cout, int H, int W, int k) {
 template <int KS, int IN, int GM, int MTW, int NTW>
 int launch_w(hipStream_t st, const WArgs& wa, const Plan& p) {
     using G = Geo<KS>;
-    constexpr size_t lds_main = (size_t)MTW * 16 * CSG + (size_t)(G::NPL + 2) * G::PLANE;
-    constexpr size_t lds_red = (size_t)4 * MTW * 16 * NTW * 16;
-    constexpr size_t lds = (lds_main > lds_red ? lds_main : lds_red) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    constexpr int NPL = wgrad_npl<KS, NTW>();
+    const int g_rows = wa.d.Cout < MTW * 16 ? wa.d.Cout : MTW * 16;
+    size_t lds_fl = (size_t)g_rows * CSG + (size_t)(NPL + 2) * G::PLANE;
+    if (lds_fl < (size_t)MTW * 16 * CSG) lds_fl = (size_t)MTW * 16 * CSG;         // the A reads of the dropped rows stay inside the block's LDS
+    if (lds_fl < (size_t)MTW * 16 * NTW * 16) lds_fl = (size_t)MTW * 16 * NTW * 16;
+    const size_t lds = lds_fl * sizeof(float);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<KS, IN, GM, MTW, NTW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+        attr_lds = lds;
     }
     dim3 grid(p.nsplit, p.n_mgroups * p.n_ngroups);
     hipLaunchKernelGGL((conv_wgrad_kernel<KS, IN, GM, MTW, NTW>), grid, dim3(256), lds, st, wa);
