@@ -755,6 +755,345 @@ int launch_wlean_modes(hipStream_t st, const WArgs& wa) {
     return -1;                                            // not covered: the caller falls back to the general kernel
 }
 
+// ---------------------------------------------------------------------------------------------------------------- wide kernel
+// The lean recipe for the stride-1 3x3 layers with more than 16 output channels or more than 12 input channels (TAT convs,
+// stride-1 up-convs and heads of the 3M models: 22..64 channels).  One block = MTW*16 couts x NTW*16 (ci, tap) columns
+// (column group `grp`); the 4 waves split the 64 K-steps of a tile; the next tile's buffer loads are issued one at a time under
+// the MFMA phase of the current one.  The column groups of one tile slot sit next to each other in the SAME XCD, so the gradient
+// tile they all re-read comes from that XCD's L2.  Shapes (MTW, NTW) are picked per layer to minimise the padded columns
+// (38 ch: 3x6 -> 4 groups of 96 for 343 columns; 46 ch: 3x7 -> 4 groups of 112 for 415), within the 256-VGPR budget.
+// GM2: 0 = g as is, 2 = tanh-grad (g, gaux)
+template <int IN, int GM2, int MTW, int NTW>
+__global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kernel(const WArgs wa, const int slots, const SidePack side) {
+    using G = Geo<3>;
+    constexpr int NPL = wgrad_npl<3, NTW>();
+    constexpr int NXSLOT = NPL * G::ROWS * G::SEGS;
+    constexpr int NXS = (NXSLOT + 255) / 256;
+    constexpr int NGS = MTW * 4;                                             // g slot k of wave w: cout row w + 4 k (wave-uniform)
+    constexpr bool GTWO = (GM2 == 2);
+    constexpr bool AFF = (IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE);
+    constexpr int AFFN = 32;                                                 // >= NPL
+    static_assert(NPL <= AFFN, "affine table too small");
+    const bnerv_wgrad_desc& d = wa.d;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
+    const int g_rows = min(MTW * 16, Cout);
+    float* s_g = smem;                                                       // g_rows rows of CSG (rows beyond Cout: see conv_wgrad_kernel)
+    float* s_in = smem + g_rows * CSG;                                       // (NPL + 2) planes
+    float* s_aff = s_in + (NPL + 2) * G::PLANE;                              // [2][AFFN]
+    const int nW = Cin * G::T;
+    const int tiles_x = wa.tiles_x, tiles_y = wa.tiles_y;
+
+    // block -> (xcd, slot, column group); the XCD owns a contiguous slice of the tile list, its slots take it round-robin
+    const int ngroups = wa.n_ngroups;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int slot = q / ngroups, grp = q - slot * ngroups;
+    const int total = d.B * tiles_x * tiles_y;
+    const int per = total >> 3, extra = total & 7;
+    const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
+    int itx = r0 + slot;
+    const bool has_work = itx < r1;                                          // (a block without tiles still writes its zero slab part)
+    const int step_q = slots / tiles_x, step_r = slots - step_q * tiles_x;
+    LTile it{0, 0, 0};
+    if (has_work) {
+        const int tiles = tiles_x * tiles_y;
+        it.b = itx / tiles;
+        const int t = itx - it.b * tiles;
+        it.ty = t / tiles_x;
+        it.tx = t - it.ty * tiles_x;
+    }
+    auto advance = [&](LTile a) {
+        a.tx += step_r;
+        a.ty += step_q;
+        if (a.tx >= tiles_x) { a.tx -= tiles_x; ++a.ty; }
+        while (a.ty >= tiles_y) { a.ty -= tiles_y; ++a.b; }
+        return a;
+    };
+    const int n_base = grp * NTW * 16;
+    const int ci_lo = min(n_base, nW - 1) / G::T;
+    const int ci_hi = min(n_base + NTW * 16 - 1, nW - 1) / G::T;
+    const int npl = ci_hi - ci_lo + 1;                                       // <= NPL
+
+    for (int i = tid; i < 2 * G::PLANE; i += 256) s_in[NPL * G::PLANE + i] = i < G::PLANE ? 1.0f : 0.0f;
+
+    auto xslot = [&](int k, int& c, int& r, int& sg) {
+        const int sidx = tid + k * 256;
+        c = sidx / (G::ROWS * G::SEGS);
+        const int rem = sidx - c * (G::ROWS * G::SEGS);
+        r = rem / G::SEGS;
+        sg = rem - r * G::SEGS;
+    };
+    auto x_inside = [&](int k, int ty0, int tx0) {
+        int c, r, sg;
+        xslot(k, c, r, sg);
+        const int gy = ty0 + r - G::PAD, gx = tx0 + 4 * sg - G::XOFF;
+        return (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    };
+    unsigned voffx[NXS];
+    int loffx[NXS];
+#pragma unroll
+    for (int k = 0; k < NXS; ++k) {
+        int c, r, sg;
+        xslot(k, c, r, sg);
+        const bool real = tid + k * 256 < NXSLOT && c < npl;
+        voffx[k] = real ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB;
+        loffx[k] = (c * G::PLANE + r * G::RS + 4 * sg) * 4;
+    }
+    // g slot k of this thread: cout row wave + 4 k, tile row (tid >> 3) & 7, segment tid & 7
+    const int g_r = (tid >> 3) & 7, g_sg = tid & 7;
+    const unsigned voffg0 = (unsigned)((g_r * W + 4 * g_sg) * 4);
+    const int loffg0 = (wave * CSG + g_r * TW + 4 * g_sg) * 4;
+    const unsigned hw4 = (unsigned)(H * W * 4);
+    const unsigned shift = (unsigned)((G::PAD * W + G::XOFF) * 4);
+    const unsigned x_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
+    const unsigned g_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, x_bytes);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(d.g, 0, g_bytes);
+    const __amdgpu_buffer_rsrc_t rg2 = make_rsrc(GM2 == 2 ? d.gaux : d.g, 0, g_bytes);
+
+    auto load_affine = [&](int b) {                        // s_aff[c] = 1 + scale[b][ci_lo + c], s_aff[AFFN + c] = shift; 0 beyond npl
+        float v = 0.f;
+        if (tid < 2 * AFFN) {
+            const int c = tid & (AFFN - 1);
+            if (c < npl) v = tid < AFFN ? 1.0f + d.scale[b * Cin + ci_lo + c] : d.shift[b * Cin + ci_lo + c];
+        }
+        lds_barrier();
+        if (tid < 2 * AFFN) s_aff[tid] = v;
+        lds_barrier();
+    };
+
+    f32x4 xa[NXS], ga[NGS], gb[GTWO ? NGS : 1];
+    constexpr int NPART = NGS + NXS;
+    struct Pre { unsigned sbx, sbg, vog; int ty0, tx0; bool interior; };
+    auto prep = [&](const LTile& a) {
+        Pre p;
+        p.ty0 = a.ty * TH; p.tx0 = a.tx * TW;
+        p.sbx = (unsigned)((((a.b * Cin + ci_lo) * H + p.ty0) * W + p.tx0) * 4);
+        p.sbg = (unsigned)((((a.b * Cout + wave) * H + p.ty0) * W + p.tx0) * 4);
+        p.interior = p.ty0 >= G::PAD && p.ty0 + TH + G::PAD <= H && p.tx0 >= G::XOFF && p.tx0 + TW + G::XOFF <= W;
+        p.vog = (p.ty0 + g_r < H && p.tx0 + 4 * g_sg < W) ? voffg0 : OOB;
+        return p;
+    };
+    auto issue_part = [&](const Pre& p, int part) {        // `part` is a compile-time constant at every call site
+        if (part < NGS) {
+            const int k = part;
+            if (wave + 4 * k < g_rows) {                   // wave-uniform
+                ga[k] = bload(rg, p.vog, p.sbg + (unsigned)(4 * k) * hw4);
+                if constexpr (GM2 == 2) gb[k] = bload(rg2, p.vog, p.sbg + (unsigned)(4 * k) * hw4);
+            }
+        } else {
+            const int k = part - NGS;
+            unsigned vo = voffx[k];
+            if (!p.interior) vo = x_inside(k, p.ty0, p.tx0) ? vo : OOB;
+            xa[k] = bload(rx, vo, p.sbx);
+        }
+    };
+    auto commit = [&](const LTile& a) {
+        const int ty0 = a.ty * TH, tx0 = a.tx * TW;
+        const bool interior = ty0 >= G::PAD && ty0 + TH + G::PAD <= H && tx0 >= G::XOFF && tx0 + TW + G::XOFF <= W;
+#pragma unroll
+        for (int k = 0; k < NGS; ++k) {
+            if (wave + 4 * k < g_rows) {
+                f32x4 v = ga[k];
+                if constexpr (GM2 == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float t = 2.0f * gb[k][e] - 1.0f; v[e] = v[e] * 0.5f * (1.0f - t * t); }
+                }
+                char* dst = reinterpret_cast<char*>(s_g) + loffg0 + k * (4 * CSG * 4);
+                *reinterpret_cast<float2*>(dst) = float2{v[0], v[1]};
+                *reinterpret_cast<float2*>(dst + 8) = float2{v[2], v[3]};
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NXS; ++k) {
+            if (k == NXS - 1 && tid + k * 256 >= NXSLOT) continue;          // idle slots of the last round
+            f32x4 v = xa[k];
+            if constexpr (IN != BNERV_IN_PLAIN) {
+                int c, r, sg;
+                xslot(k, c, r, sg);
+                float sc_ = s_aff[c & (AFFN - 1)], sh_ = s_aff[AFFN + (c & (AFFN - 1))];
+                if (!interior) {                                             // zero padding is applied AFTER the prologue
+                    const bool ok = x_inside(k, ty0, tx0);
+                    sc_ = ok ? sc_ : 0.f;
+                    sh_ = ok ? sh_ : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = xf_in<IN>(v[e], sc_, sh_);
+            }
+            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(s_in) + loffx[k]) = v;
+        }
+    };
+
+    int bbase[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int n = n_base + nt * 16 + li;
+        int off;
+        if (n < nW) {
+            const int ci = n / G::T, tap = n - ci * G::T;
+            off = (ci - ci_lo) * G::PLANE + (tap / 3) * G::RS + (tap % 3) + G::COL0;
+        } else {
+            off = (n == nW ? NPL : NPL + 1) * G::PLANE;
+        }
+        bbase[nt] = off + (2 * wave) * G::RS + kq;
+    }
+    const int abase = li * CSG + wave * 64 + kq;
+
+    f32x4 acc[MTW][NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int aff_b = -1;
+    if (has_work) {
+        const Pre p0 = prep(it);
+#pragma unroll
+        for (int part = 0; part < NPART; ++part) issue_part(p0, part);
+        if constexpr (AFF) { load_affine(it.b); aff_b = it.b; }
+        commit(it);
+    }
+    for (; itx < r1; itx += slots) {
+        const bool has_next = itx + slots < r1;
+        LTile nxt = it;
+        if (has_next) nxt = advance(it);
+        lds_barrier();                                     // tile t staged by everyone
+        const Pre pre = prep(nxt);
+        // fragments of step st + 1 are read while the MFMAs of step st run; the scheduler fence per step keeps the compiler from
+        // hoisting all 16 steps' LDS reads (which costs more registers than the kernel has)
+        float af[2][MTW], bf[2][NTW];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) af[0][m] = s_g[abase + m * 16 * CSG];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) bf[0][n] = s_in[bbase[n]];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            if (has_next) {                                // the next tile's loads, spread over the K steps
+#pragma unroll
+                for (int part = 0; part < NPART; ++part)
+                    if (part * 16 / NPART == st) issue_part(pre, part);
+            }
+            if (st < 15) {
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) af[(st + 1) & 1][m] = s_g[abase + m * 16 * CSG + (st + 1) * 4];
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) bf[(st + 1) & 1][n] = s_in[bbase[n] + (((st + 1) >> 3) * G::RS + ((st + 1) & 7) * 4)];
+            }
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st & 1][m], bf[st & 1][n], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_barrier();                                     // everyone done reading tile t
+        if (has_next) {
+            if constexpr (AFF) { if (nxt.b != aff_b) { load_affine(nxt.b); aff_b = nxt.b; } }
+            commit(nxt);
+        }
+        it = nxt;
+    }
+
+    // cross-wave reduction, one wave after the other into one area (fixed order), then this block's columns of the slot's slab
+    __syncthreads();
+    float* s_red = smem;
+    constexpr int RW = NTW * 16, RSZ = MTW * 16 * RW;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* qd = s_red + (m * 16 + 4 * kq + r) * RW + n * 16 + li;
+                        *qd = (w == 0) ? acc[m][n][r] : *qd + acc[m][n][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* slab = wa.slab + (size_t)(xcd * slots + slot) * Cout * wa.ncols;
+    for (int idx = tid; idx < RSZ; idx += 256) {
+        const int row = idx / RW, colq = idx - row * RW;
+        const int col = n_base + colq;
+        if (row < Cout && col < wa.ncols) slab[(size_t)row * wa.ncols + col] = s_red[idx];
+    }
+    side_run_hosted(side, smem);
+}
+
+struct WidePlan { int mtw, ntw, ngroups, slots; };
+
+static WidePlan wide_plan(const bnerv_wgrad_desc& d) {
+    WidePlan p{0, 0, 0, 0};
+    const int ncols = d.Cin * 9 + 1, nt = cdiv(ncols, 16), mt = cdiv(d.Cout, 16);
+    auto best = [&](int a, int b) { return cdiv(nt, a) * a < cdiv(nt, b) * b ? a : b; };   // fewer padded columns; ties -> b
+    if (mt == 1) { p.mtw = 1; p.ntw = 8; }
+    else if (mt == 2) { p.mtw = 2; p.ntw = best(7, 9); }
+    else if (mt == 3) { p.mtw = 3; p.ntw = best(6, 7); }
+    else if (mt == 4) { p.mtw = 4; p.ntw = 4; }
+    else return p;
+    p.ngroups = cdiv(nt, p.ntw);
+    const int per_cu = p.mtw * p.ntw <= 8 ? 3 : 2;
+    const int total_tiles = d.B * cdiv(d.H, TH) * cdiv(d.W, TW);
+    int s = (256 * per_cu) / (8 * p.ngroups);              // slots per XCD with every block resident
+    const int want = cdiv(total_tiles, 8);
+    if (s > want) s = want;
+    if (s < 1) s = 1;
+    p.slots = s;
+    return p;
+}
+
+static bool wide_ok(const WArgs& wa) {
+    const bnerv_wgrad_desc& d = wa.d;
+    static const bool off = getenv("BNERV_NO_WIDE") != nullptr;            // A/B switch for tools/kwide.py
+    if (off || !wa.vec || d.k != 3 || d.Cout > 64 || d.g_s != 1) return false;
+    if (d.in_mode != BNERV_IN_PLAIN && d.in_mode != BNERV_IN_AFFINE) return false;
+    if (d.g_mode == BNERV_IN_TANHGRAD && (d.in_mode != BNERV_IN_PLAIN || d.Cout > 16)) return false;
+    const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
+    return (size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 < WLEAN_MAX_BYTES;
+}
+
+template <int IN, int GM2, int MTW, int NTW>
+int launch_wide(hipStream_t st, const WArgs& wa, const WidePlan& p) {
+    using G = Geo<3>;
+    constexpr int NPL = wgrad_npl<3, NTW>();
+    const int g_rows = wa.d.Cout < MTW * 16 ? wa.d.Cout : MTW * 16;
+    size_t lds_fl = (size_t)g_rows * CSG + (size_t)(NPL + 2) * G::PLANE + 64;
+    if (lds_fl < (size_t)MTW * 16 * CSG) lds_fl = (size_t)MTW * 16 * CSG;
+    if (lds_fl < (size_t)MTW * 16 * NTW * 16) lds_fl = (size_t)MTW * 16 * NTW * 16;
+    const size_t lds = lds_fl * sizeof(float);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_kernel<IN, GM2, MTW, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    const int grid = 8 * p.slots * p.ngroups;
+    SidePack side;
+    bnerv_side_take(&side, 2 * grid);
+    hipLaunchKernelGGL((wgrad_wide_kernel<IN, GM2, MTW, NTW>), dim3(grid), dim3(256), lds, st, wa, p.slots, side);
+    BNERV_LAUNCH_CHECK("wgrad_wide");
+    return BNERV_OK;
+}
+
+template <int IN, int GM2>
+int launch_wide_shape(hipStream_t st, const WArgs& wa, const WidePlan& p) {
+    if (p.mtw == 1) return launch_wide<IN, GM2, 1, 8>(st, wa, p);
+    if constexpr (GM2 == 0) {
+        if (p.mtw == 2) return p.ntw == 9 ? launch_wide<IN, GM2, 2, 9>(st, wa, p) : launch_wide<IN, GM2, 2, 7>(st, wa, p);
+        if (p.mtw == 3) return p.ntw == 7 ? launch_wide<IN, GM2, 3, 7>(st, wa, p) : launch_wide<IN, GM2, 3, 6>(st, wa, p);
+        if (p.mtw == 4) return launch_wide<IN, GM2, 4, 4>(st, wa, p);
+    }
+    return -1;
+}
+
+static int launch_wide_modes(hipStream_t st, const WArgs& wa, const WidePlan& p) {
+    if (wa.d.g_mode == BNERV_IN_TANHGRAD) return launch_wide_shape<BNERV_IN_PLAIN, 2>(st, wa, p);
+    if (wa.d.in_mode == BNERV_IN_PLAIN) return launch_wide_shape<BNERV_IN_PLAIN, 0>(st, wa, p);
+    return launch_wide_shape<BNERV_IN_AFFINE, 0>(st, wa, p);
+}
+
 struct Plan { int mtw, ntw, n_mgroups, n_ngroups, nsplit; };
 
 Plan make_plan(int B, int Cin, int Cout, int H, int W, int k) {
@@ -838,7 +1177,12 @@ extern "C" size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int
     const Plan p = make_plan(B, Cin, Cout, H, W, k);
     bnerv_wgrad_desc t{};
     t.B = B; t.H = H; t.W = W; t.k = k;
-    const int nb = wlean_blocks(t) > p.nsplit ? wlean_blocks(t) : p.nsplit;     // covers whichever kernel the launcher picks
+    int nb = wlean_blocks(t) > p.nsplit ? wlean_blocks(t) : p.nsplit;           // covers whichever kernel the launcher picks
+    if (k == 3 && Cout <= 64) {
+        t.Cin = Cin; t.Cout = Cout;
+        const WidePlan wp = wide_plan(t);
+        if (8 * wp.slots > nb) nb = 8 * wp.slots;
+    }
     return (size_t)nb * Cout * (Cin * k * k + 1) * sizeof(float);
 }
 
@@ -869,6 +1213,16 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
     if (wlean_ok(wa)) {
         rc = d.k == 1 ? launch_wlean_modes<1>(st, wa) : launch_wlean_modes<3>(st, wa);
         if (rc == BNERV_OK) n_slabs = wlean_blocks(d);
+    }
+    if (rc == -1 && wide_ok(wa)) {
+        const WidePlan wp = wide_plan(d);
+        if (wp.mtw) {
+            wa.n_ngroups = wp.ngroups;
+            wa.n_mgroups = 1;
+            rc = launch_wide_modes(st, wa, wp);
+            if (rc == BNERV_OK) n_slabs = 8 * wp.slots;
+            else { wa.n_ngroups = p.n_ngroups; wa.n_mgroups = p.n_mgroups; }
+        }
     }
     if (rc == -1) rc = d.k == 1 ? launch_modes<1>(st, wa, p) : launch_modes<3>(st, wa, p);
     if (rc != BNERV_OK) return rc;

@@ -1,0 +1,68 @@
+"""A/B of wgrad_wide_kernel against the general weight-gradient kernel on the stride-1 3x3 shapes of the 3M models.
+usage: python tools/kwide.py             (spawns itself twice: default and BNERV_NO_WIDE=1; compares dw/db, prints times)"""
+import os
+import subprocess
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+SHAPES = [  # (B, Cin, Cout, H, W)
+    (1, 30, 30, 45, 80), (2, 38, 38, 9, 40), (3, 17, 20, 24, 36), (1, 95, 64, 18, 32), (2, 13, 5, 19, 44),
+    (1, 38, 38, 1080, 1920), (1, 46, 46, 540, 960), (1, 55, 55, 270, 480), (1, 22, 22, 540, 960), (1, 44, 44, 270, 480), (1, 38, 3, 1080, 1920),
+]
+
+
+def leg(path):
+    from boosting_nerv_amd import _lib as L, ops
+    dev = torch.device("cuda:0")
+    res, times = {}, {}
+    for (B, Ci, Co, H, W) in SHAPES:
+        g = torch.Generator().manual_seed(B * 1000 + Ci + Co + H)
+        rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+        x, gr, gaux = rnd(B, Ci, H, W), rnd(B, Co, H, W), torch.rand(B, Co, H, W, generator=g).to(dev)
+        sci, shi = rnd(B, Ci, sc=0.3), rnd(B, Ci, sc=0.3)
+        kw = dict(B=B, Cin=Ci, Cout=Co, H=H, W=W, k=3)
+        modes = {
+            "plain": lambda dw, db: ops._wgrad(x, gr, dw, db, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, **kw),
+            "affine": lambda dw, db: ops._wgrad(x, gr, dw, db, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=sci, shift=shi, **kw),
+        }
+        if Co <= 16:
+            modes["tanhgrad"] = lambda dw, db: ops._wgrad(x, gr, dw, db, in_mode=L.IN_PLAIN, g_mode=L.IN_TANHGRAD, gaux=gaux, **kw)
+        for name, fn in modes.items():
+            dw = torch.zeros(Co, Ci, 3, 3, device=dev)
+            db = torch.zeros(Co, device=dev)
+            key = f"{name} {B}x{Ci}->{Co}@{H}x{W}"
+            fn(dw, db)
+            torch.cuda.synchronize()
+            res[key] = (dw.cpu(), db.cpu())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn(dw, db)
+            e1.record()
+            torch.cuda.synchronize()
+            times[key] = e0.elapsed_time(e1) * 100.0
+    torch.save((res, times), path)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "dump":
+        leg(sys.argv[2])
+        sys.exit(0)
+    env = dict(os.environ)
+    subprocess.check_call([sys.executable, __file__, "dump", "/tmp/kw_new.pt"], env=env)
+    env["BNERV_NO_WIDE"] = "1"
+    subprocess.check_call([sys.executable, __file__, "dump", "/tmp/kw_old.pt"], env=env)
+    rn, tn = torch.load("/tmp/kw_new.pt")
+    ro, to = torch.load("/tmp/kw_old.pt")
+    for k in ro:
+        errs = [float((a - b).abs().max() / (b.abs().max() + 1e-20)) for a, b in zip(rn[k], ro[k])]
+        flag = "ok " if max(errs) < 1e-4 else "BAD"
+        B, rest = k.split(" ")[1].split("x", 1)
+        ci, rest = rest.split("->")
+        co, hw = rest.split("@")
+        h, w = hw.split("x")
+        fl = 2.0 * int(B) * int(ci) * int(co) * 9 * int(h) * int(w)
+        print(f"{k:36s} {flag} rel dw {errs[0]:.1e} db {errs[1]:.1e}   general {to[k]:8.1f} us   wide {tn[k]:8.1f} us ({fl / tn[k] / 1e6:5.1f} TF)   x{to[k] / tn[k]:.2f}")
