@@ -1141,7 +1141,7 @@ int launch_lean(hipStream_t st, KArgs& ka) {
 // accumulators for every cout tile.  These are the TAT convolutions, heads and their data gradients of the 3M models
 // (22..55 channels) and of C1's 30-channel stage; the generic kernel keeps PixelShuffle outputs and the unshuffle prologue.
 template <int KS, int IN, int EP, int NTB>
-__global__ __launch_bounds__(256, (NTB <= 2 ? 3 : 2)) void conv_lean2_kernel(const KArgs ka, const SidePack side) {
+__global__ __launch_bounds__(256, (NTB == 1 ? 3 : 2)) void conv_lean2_kernel(const KArgs ka, const SidePack side) {
     using G = Geo<KS>;
     constexpr int NQ1 = 4, NCH = 16;
     constexpr int NSLOT = NCH * G::ROWS * G::SEGS;
@@ -1276,10 +1276,43 @@ __global__ __launch_bounds__(256, (NTB <= 2 ? 3 : 2)) void conv_lean2_kernel(con
         }
     };
 
+    // Weights that do not stay resident (Cin * NTB too large for the LDS budget) are restaged per (tile, chunk) stage; like the
+    // input tile they are prefetched into registers under the MFMA phase of the previous stage.  Row r = (tap, q, n) of the
+    // stage's B fragments is wave-uniform (wave w owns rows w, w + 4, ...): its decomposition is scalar arithmetic.
+    // Wave w owns channel quad q = w of the chunk: row j of its set is (tap, n) = (j / NTB, j % NTB) -- compile-time, so the
+    // prefetch needs no index arithmetic at all (a per-row runtime decomposition cost ~100 spilled VGPRs here).
+    constexpr bool WPRE = !TWO && NTB >= 2;                // (single-tile layers and the tanh-grad prologue: resident weights only)
+    constexpr int NWR = WPRE ? G::T * NTB : 1;
+    float wr[NWR];
+    const int w_co_step = d.transposed ? G::T : d.wCi * G::T;
+    const int w_ci_step = d.transposed ? d.wCi * G::T : G::T;
+    const int w_tap0 = d.transposed ? G::T - 1 : 0, w_tapstep = d.transposed ? -1 : 1;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(d.w, 0, (unsigned)((size_t)d.wCo * d.wCi * G::T * 4));
+    auto w_issue = [&](int co_b, int q0, int nq) {         // one VGPR offset per lane, the (tap, n) part in the scalar offset
+        const int co_l = co_b + li, ci_l = (q0 + wave) * 4 + kq;
+        const bool ok = wave < nq && ci_l < Cin;
+        const unsigned vo = (unsigned)((d.transposed ? (ci_l * d.wCi + co_l) * G::T : (co_l * d.wCi + ci_l) * G::T) * 4);
+#pragma unroll
+        for (int j = 0; j < NWR; ++j) {
+            const int tap = j / NTB, n = j % NTB;
+            const unsigned so = (unsigned)((16 * n * w_co_step + w_tap0 + tap * w_tapstep) * 4);
+            wr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, (int)((ok && co_l + 16 * n < Cout) ? vo : OOB), (int)so, 0));
+        }
+    };
+    auto w_commit = [&](int nq) {
+        if (wave < nq) {
+            float* dst = s_w + wave * NTB * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < NWR; ++j) dst[((j / NTB) * NQ1 * NTB + (j % NTB)) * 64] = wr[j];
+        }
+    };
+    auto chunk_nq = [&](int c0) { return (min(NCH, Cin - c0) + 3) >> 2; };
+
     Item it = decode_item(ka, itx);
     int cur_g = -1, aff_b = -1;
     if constexpr (AFF) { load_affine(it.b); aff_b = it.b; }
     issue(it, 0);
+    if (WPRE && !ka.w_resident) { w_issue(it.g * NTB * 16, 0, chunk_nq(0)); w_commit(chunk_nq(0)); }
     commit(it, 0);
     const int abase = kq * G::PLANE + (2 * wave) * G::RS + li + G::COL0;
     Item prev = it;
@@ -1308,10 +1341,14 @@ __global__ __launch_bounds__(256, (NTB <= 2 ? 3 : 2)) void conv_lean2_kernel(con
             const int c0 = ch * NCH;
             const int nq = (min(NCH, Cin - c0) + 3) >> 2;
             const bool last_chunk = ch == nchunks - 1;
-            if (!ka.w_resident) stage_weights<KS, NTB>(d, s_w, co_base, c0 >> 2, nq, qstride);   // after the previous stage's barrier (B)
             lds_barrier();                                 // (A) this stage's s_in / s_w (and s_red of the previous item) visible
-            if (!last_chunk) issue(it, c0 + NCH);          // next stage's loads fly under the MFMA phase
-            else if (has_next) issue(nxt, 0);
+            if (!last_chunk) {                             // next stage's loads fly under the MFMA phase
+                issue(it, c0 + NCH);
+                if (WPRE && !ka.w_resident) w_issue(co_base, (c0 + NCH) >> 2, chunk_nq(c0 + NCH));
+            } else if (has_next) {
+                issue(nxt, 0);
+                if (WPRE && !ka.w_resident) w_issue(nxt.g * NTB * 16, 0, chunk_nq(0));
+            }
             if constexpr (RED) { if (ch == 0 && have_prev) flush_partials(prev, prev.g * NTB * 16); }
             const int qb = ka.w_resident ? (c0 >> 2) : 0;
 #pragma unroll 1
@@ -1337,9 +1374,12 @@ __global__ __launch_bounds__(256, (NTB <= 2 ? 3 : 2)) void conv_lean2_kernel(con
                 }
             }
             lds_barrier();                                 // (B) every wave is done reading this stage
-            if (!last_chunk) commit(it, c0 + NCH);
-            else if (has_next) {
+            if (!last_chunk) {
+                if (WPRE && !ka.w_resident) w_commit(chunk_nq(c0 + NCH));
+                commit(it, c0 + NCH);
+            } else if (has_next) {
                 if constexpr (AFF) { if (nxt.b != aff_b) { load_affine(nxt.b); aff_b = nxt.b; } }
+                if (WPRE && !ka.w_resident) w_commit(chunk_nq(0));
                 commit(nxt, 0);
             }
         }
@@ -1467,6 +1507,7 @@ int launch_lean2(hipStream_t st, KArgs& ka) {
     ka.nq_total = cdiv(d.Cin, 16) * 4;                     // chunk-aligned: chunk ch owns q = 4 ch .. 4 ch + 3
     const size_t wres = (size_t)G::T * ka.nq_total * NTB * 64;
     ka.w_resident = wres <= (size_t)W_RESIDENT_MAX ? 1 : 0;
+    if ((IN == BNERV_IN_TANHGRAD || NTB == 1) && !ka.w_resident) return -1;       // caller falls back to the generic kernel
     const size_t wfl = ka.w_resident ? wres : (size_t)G::T * 4 * NTB * 64;
     const size_t lds = ((size_t)16 * G::PLANE + (size_t)(NPRE * 256 - NSLOT) * 4 + (size_t)4 * 2 * NTB * 16 + 2 * 128 + wfl) * sizeof(float);
     static size_t attr_lds = 0;
@@ -1506,7 +1547,7 @@ int launch_one(hipStream_t st, KArgs& ka) {
     if constexpr (KS == 3 && IN != BNERV_IN_UNSHUFFLE && NTB <= 3 &&
                   (EP == BNERV_EP_BIAS || EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU || EP == BNERV_EP_BIAS_RES || EP == BNERV_EP_BIAS_TANH || EP == BNERV_EP_PLAIN ||
                    EP == BNERV_EP_DGELU_SAVED || EP == BNERV_EP_DSIN)) {
-        if (lean2_ok(ka)) return launch_lean2<KS, IN, EP, NTB>(st, ka);
+        if (lean2_ok(ka)) { const int rc = launch_lean2<KS, IN, EP, NTB>(st, ka); if (rc != -1) return rc; }
     }
     if constexpr (IN != BNERV_IN_UNSHUFFLE && NTB == 1) {
         if (lean_ok(ka)) {
