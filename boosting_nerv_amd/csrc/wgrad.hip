@@ -762,15 +762,15 @@ int launch_wlean_modes(hipStream_t st, const WArgs& wa) {
 // the MFMA phase of the current one.  The column groups of one tile slot sit next to each other in the SAME XCD, so the gradient
 // tile they all re-read comes from that XCD's L2.  Shapes (MTW, NTW) are picked per layer to minimise the padded columns
 // (38 ch: 3x6 -> 4 groups of 96 for 343 columns; 46 ch: 3x7 -> 4 groups of 112 for 415), within the 256-VGPR budget.
-// GM2: 0 = g as is, 2 = tanh-grad (g, gaux)
+// GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient (two float4 per cout PAIR), 2 = tanh-grad (g, gaux)
 template <int IN, int GM2, int MTW, int NTW>
 __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kernel(const WArgs wa, const int slots, const SidePack side) {
     using G = Geo<3>;
     constexpr int NPL = wgrad_npl<3, NTW>();
     constexpr int NXSLOT = NPL * G::ROWS * G::SEGS;
     constexpr int NXS = (NXSLOT + 255) / 256;
-    constexpr int NGS = MTW * 4;                                             // g slot k of wave w: cout row w + 4 k (wave-uniform)
-    constexpr bool GTWO = (GM2 == 2);
+    constexpr int NGS = (GM2 == 1) ? MTW * 2 : MTW * 4;                      // g slot k of wave w: cout row (pair) w + 4 k (wave-uniform)
+    constexpr bool GTWO = (GM2 != 0);
     constexpr bool AFF = (IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE);
     constexpr int AFFN = 32;                                                 // >= NPL
     static_assert(NPL <= AFFN, "affine table too small");
@@ -780,7 +780,8 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
     const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
-    const int g_rows = min(MTW * 16, Cout);
+    const int co_base = (int)(((blockIdx.x >> 3) % (unsigned)(wa.n_ngroups * wa.n_mgroups)) / (unsigned)wa.n_ngroups) * MTW * 16;
+    const int g_rows = min(MTW * 16, Cout - co_base);
     float* s_g = smem;                                                       // g_rows rows of CSG (rows beyond Cout: see conv_wgrad_kernel)
     float* s_in = smem + g_rows * CSG;                                       // (NPL + 2) planes
     float* s_aff = s_in + (NPL + 2) * G::PLANE;                              // [2][AFFN]
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
     const int tiles_x = wa.tiles_x, tiles_y = wa.tiles_y;
 
     // block -> (xcd, slot, column group); the XCD owns a contiguous slice of the tile list, its slots take it round-robin
-    const int ngroups = wa.n_ngroups;
+    const int ngroups = wa.n_ngroups * wa.n_mgroups;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int slot = q / ngroups, grp = q - slot * ngroups;
     const int total = d.B * tiles_x * tiles_y;
@@ -812,7 +813,8 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
         while (a.ty >= tiles_y) { a.ty -= tiles_y; ++a.b; }
         return a;
     };
-    const int n_base = grp * NTW * 16;
+    const int mg = grp / wa.n_ngroups;
+    const int n_base = (grp - mg * wa.n_ngroups) * NTW * 16;
     const int ci_lo = min(n_base, nW - 1) / G::T;
     const int ci_hi = min(n_base + NTW * 16 - 1, nW - 1) / G::T;
     const int npl = ci_hi - ci_lo + 1;                                       // <= NPL
@@ -844,8 +846,8 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
     }
     // g slot k of this thread: cout row wave + 4 k, tile row (tid >> 3) & 7, segment tid & 7
     const int g_r = (tid >> 3) & 7, g_sg = tid & 7;
-    const unsigned voffg0 = (unsigned)((g_r * W + 4 * g_sg) * 4);
-    const int loffg0 = (wave * CSG + g_r * TW + 4 * g_sg) * 4;
+    const unsigned voffg0 = GM2 == 1 ? (unsigned)((2 * g_r * 2 * W + 8 * g_sg) * 4) : (unsigned)((g_r * W + 4 * g_sg) * 4);
+    const int loffg0 = ((GM2 == 1 ? 2 * wave : wave) * CSG + g_r * TW + 4 * g_sg) * 4;
     const unsigned hw4 = (unsigned)(H * W * 4);
     const unsigned shift = (unsigned)((G::PAD * W + G::XOFF) * 4);
     const unsigned x_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
@@ -872,7 +874,8 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
         Pre p;
         p.ty0 = a.ty * TH; p.tx0 = a.tx * TW;
         p.sbx = (unsigned)((((a.b * Cin + ci_lo) * H + p.ty0) * W + p.tx0) * 4);
-        p.sbg = (unsigned)((((a.b * Cout + wave) * H + p.ty0) * W + p.tx0) * 4);
+        if constexpr (GM2 == 1) p.sbg = (unsigned)(((a.b * (Cout >> 2) * 2 * H + 2 * p.ty0) * 2 * W + 2 * p.tx0) * 4);   // + the pair's plane / row parity
+        else p.sbg = (unsigned)((((a.b * Cout + co_base + wave) * H + p.ty0) * W + p.tx0) * 4);
         p.interior = p.ty0 >= G::PAD && p.ty0 + TH + G::PAD <= H && p.tx0 >= G::XOFF && p.tx0 + TW + G::XOFF <= W;
         p.vog = (p.ty0 + g_r < H && p.tx0 + 4 * g_sg < W) ? voffg0 : OOB;
         return p;
@@ -880,7 +883,14 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
     auto issue_part = [&](const Pre& p, int part) {        // `part` is a compile-time constant at every call site
         if (part < NGS) {
             const int k = part;
-            if (wave + 4 * k < g_rows) {                   // wave-uniform
+            if constexpr (GM2 == 1) {
+                if (2 * (wave + 4 * k) < g_rows) {         // wave-uniform: cout pair co, co + 1 = (cf, i, j = 0 / 1)
+                    const int co = co_base + 2 * (wave + 4 * k), cf = co >> 2, i = (co >> 1) & 1;
+                    const unsigned so = p.sbg + (unsigned)(((cf * 2 * H + i) * 2 * W) * 4);
+                    ga[k] = bload(rg, p.vog, so);
+                    gb[k] = bload(rg, p.vog == OOB ? OOB : p.vog + 16u, so);
+                }
+            } else if (wave + 4 * k < g_rows) {            // wave-uniform
                 ga[k] = bload(rg, p.vog, p.sbg + (unsigned)(4 * k) * hw4);
                 if constexpr (GM2 == 2) gb[k] = bload(rg2, p.vog, p.sbg + (unsigned)(4 * k) * hw4);
             }
@@ -896,7 +906,16 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
         const bool interior = ty0 >= G::PAD && ty0 + TH + G::PAD <= H && tx0 >= G::XOFF && tx0 + TW + G::XOFF <= W;
 #pragma unroll
         for (int k = 0; k < NGS; ++k) {
-            if (wave + 4 * k < g_rows) {
+            if constexpr (GM2 == 1) {
+                if (2 * (wave + 4 * k) < g_rows) {
+                    const f32x4 a0 = ga[k], a1 = gb[k];
+                    char* dst = reinterpret_cast<char*>(s_g) + loffg0 + k * (8 * CSG * 4);
+                    *reinterpret_cast<float2*>(dst) = float2{a0[0], a0[2]};
+                    *reinterpret_cast<float2*>(dst + 8) = float2{a1[0], a1[2]};
+                    *reinterpret_cast<float2*>(dst + CSG * 4) = float2{a0[1], a0[3]};
+                    *reinterpret_cast<float2*>(dst + CSG * 4 + 8) = float2{a1[1], a1[3]};
+                }
+            } else if (wave + 4 * k < g_rows) {
                 f32x4 v = ga[k];
                 if constexpr (GM2 == 2) {
 #pragma unroll
@@ -1018,26 +1037,26 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
     for (int idx = tid; idx < RSZ; idx += 256) {
         const int row = idx / RW, colq = idx - row * RW;
         const int col = n_base + colq;
-        if (row < Cout && col < wa.ncols) slab[(size_t)row * wa.ncols + col] = s_red[idx];
+        if (co_base + row < Cout && col < wa.ncols) slab[(size_t)(co_base + row) * wa.ncols + col] = s_red[idx];
     }
     side_run_hosted(side, smem);
 }
 
-struct WidePlan { int mtw, ntw, ngroups, slots; };
+struct WidePlan { int mtw, ntw, ngroups, mgroups, slots; };
 
 static WidePlan wide_plan(const bnerv_wgrad_desc& d) {
-    WidePlan p{0, 0, 0, 0};
+    WidePlan p{0, 0, 0, 1, 0};
     const int ncols = d.Cin * 9 + 1, nt = cdiv(ncols, 16), mt = cdiv(d.Cout, 16);
     auto best = [&](int a, int b) { return cdiv(nt, a) * a < cdiv(nt, b) * b ? a : b; };   // fewer padded columns; ties -> b
     if (mt == 1) { p.mtw = 1; p.ntw = 8; }
     else if (mt == 2) { p.mtw = 2; p.ntw = best(7, 9); }
     else if (mt == 3) { p.mtw = 3; p.ntw = best(6, 7); }
     else if (mt == 4) { p.mtw = 4; p.ntw = 4; }
-    else return p;
+    else { p.mtw = 3; p.ntw = best(6, 7); p.mgroups = cdiv(mt, 3); }      // (64 full gradient rows would leave one block per CU)
     p.ngroups = cdiv(nt, p.ntw);
     const int per_cu = p.mtw * p.ntw <= 8 ? 3 : 2;
     const int total_tiles = d.B * cdiv(d.H, TH) * cdiv(d.W, TW);
-    int s = (256 * per_cu) / (8 * p.ngroups);              // slots per XCD with every block resident
+    int s = (256 * per_cu) / (8 * p.ngroups * p.mgroups);  // slots per XCD with every block resident
     const int want = cdiv(total_tiles, 8);
     if (s > want) s = want;
     if (s < 1) s = 1;
@@ -1048,7 +1067,8 @@ static WidePlan wide_plan(const bnerv_wgrad_desc& d) {
 static bool wide_ok(const WArgs& wa) {
     const bnerv_wgrad_desc& d = wa.d;
     static const bool off = getenv("BNERV_NO_WIDE") != nullptr;            // A/B switch for tools/kwide.py
-    if (off || !wa.vec || d.k != 3 || d.Cout > 64 || d.g_s != 1) return false;
+    if (off || !wa.vec || d.k != 3 || d.g_s > 2) return false;
+    if (d.g_s == 2 && (d.g_mode != BNERV_IN_UNSHUFFLE || d.in_mode != BNERV_IN_PLAIN || d.Cout % 4 != 0 || d.Cout <= 16)) return false;
     if (d.in_mode != BNERV_IN_PLAIN && d.in_mode != BNERV_IN_AFFINE) return false;
     if (d.g_mode == BNERV_IN_TANHGRAD && (d.in_mode != BNERV_IN_PLAIN || d.Cout > 16)) return false;
     const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
@@ -1069,7 +1089,7 @@ int launch_wide(hipStream_t st, const WArgs& wa, const WidePlan& p) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_kernel<IN, GM2, MTW, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
-    const int grid = 8 * p.slots * p.ngroups;
+    const int grid = 8 * p.slots * p.ngroups * p.mgroups;
     SidePack side;
     bnerv_side_take(&side, 2 * grid);
     hipLaunchKernelGGL((wgrad_wide_kernel<IN, GM2, MTW, NTW>), dim3(grid), dim3(256), lds, st, wa, p.slots, side);
@@ -1079,6 +1099,12 @@ int launch_wide(hipStream_t st, const WArgs& wa, const WidePlan& p) {
 
 template <int IN, int GM2>
 int launch_wide_shape(hipStream_t st, const WArgs& wa, const WidePlan& p) {
+    if constexpr (GM2 == 1) {                              // up-convs feeding PixelShuffle(2): Cout = 4 * channels, 32 and up here
+        if (p.mtw == 2) return p.ntw == 9 ? launch_wide<IN, GM2, 2, 9>(st, wa, p) : launch_wide<IN, GM2, 2, 7>(st, wa, p);
+        if (p.mtw == 3) return p.ntw == 7 ? launch_wide<IN, GM2, 3, 7>(st, wa, p) : launch_wide<IN, GM2, 3, 6>(st, wa, p);
+        if (p.mtw == 4) return launch_wide<IN, GM2, 4, 4>(st, wa, p);
+        return -1;
+    }
     if (p.mtw == 1) return launch_wide<IN, GM2, 1, 8>(st, wa, p);
     if constexpr (GM2 == 0) {
         if (p.mtw == 2) return p.ntw == 9 ? launch_wide<IN, GM2, 2, 9>(st, wa, p) : launch_wide<IN, GM2, 2, 7>(st, wa, p);
@@ -1090,6 +1116,7 @@ int launch_wide_shape(hipStream_t st, const WArgs& wa, const WidePlan& p) {
 
 static int launch_wide_modes(hipStream_t st, const WArgs& wa, const WidePlan& p) {
     if (wa.d.g_mode == BNERV_IN_TANHGRAD) return launch_wide_shape<BNERV_IN_PLAIN, 2>(st, wa, p);
+    if (wa.d.g_s == 2) return launch_wide_shape<BNERV_IN_PLAIN, 1>(st, wa, p);
     if (wa.d.in_mode == BNERV_IN_PLAIN) return launch_wide_shape<BNERV_IN_PLAIN, 0>(st, wa, p);
     return launch_wide_shape<BNERV_IN_AFFINE, 0>(st, wa, p);
 }
@@ -1178,7 +1205,7 @@ extern "C" size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int
     bnerv_wgrad_desc t{};
     t.B = B; t.H = H; t.W = W; t.k = k;
     int nb = wlean_blocks(t) > p.nsplit ? wlean_blocks(t) : p.nsplit;           // covers whichever kernel the launcher picks
-    if (k == 3 && Cout <= 64) {
+    if (k == 3) {
         t.Cin = Cin; t.Cout = Cout;
         const WidePlan wp = wide_plan(t);
         if (8 * wp.slots > nb) nb = 8 * wp.slots;
@@ -1218,7 +1245,7 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
         const WidePlan wp = wide_plan(d);
         if (wp.mtw) {
             wa.n_ngroups = wp.ngroups;
-            wa.n_mgroups = 1;
+            wa.n_mgroups = wp.mgroups;
             rc = launch_wide_modes(st, wa, wp);
             if (rc == BNERV_OK) n_slabs = 8 * wp.slots;
             else { wa.n_ngroups = p.n_ngroups; wa.n_mgroups = p.n_mgroups; }
