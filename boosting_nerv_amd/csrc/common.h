@@ -35,9 +35,11 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // |error| <= 1.5e-7 on erf, i.e. 7.5e-8 on the normal cdf: at the level of one fp32 ulp of the results.  Used where both values
 // are produced at once (the TAT conv0 epilogue); ~29 VALU per element instead of ~54 for gelu_f + gelu_grad_f.
 __device__ __forceinline__ void gelu_pair_f(float x, float* h, float* g) {
-    const float e = expf(-0.5f * x * x);
+    // e = exp(-x^2/2) <= 1 as one v_exp_f32 (1 ulp): the argument's rounding error |arg| * 2^-24 is relative to e itself, i.e.
+    // below 2e-10 absolute everywhere -- far inside the A-S bound; expf() spends ~10 VALU on ranges that cannot occur here
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
     const float az = fabsf(x) * 0.70710678118654752440f;
-    const float t = 1.0f / (1.0f + 0.3275911f * az);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);   // v_rcp_f32 (1 ulp) -- the IEEE division sequence costs ~10 VALU
     float poly = 1.061405429f;
     poly = fmaf(poly, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);

@@ -366,6 +366,28 @@ def test_sincos_epilogue_accuracy(ops):
         assert es < 3e-7 and ec < 3e-7, (span, es, ec)
 
 
+def test_gelu_pair_epilogue_accuracy(ops):
+    """gelu(v) and gelu'(v) of the TAT conv0 epilogue (common.h gelu_pair_f: one v_exp_f32, one v_rcp_f32, A-S 7.1.26 erf), read
+    back through an identity 3x3 conv with a unit affine prologue: against float64 on small, moderate and tail arguments."""
+    from boosting_nerv_amd import _lib as L
+    C, H, W = 12, 64, 128
+    g = torch.Generator().manual_seed(3)
+    w = torch.zeros(C, C, 3, 3)
+    w[torch.arange(C), torch.arange(C), 1, 1] = 1.0
+    w = w.to(DEV)
+    zero = torch.zeros(1, C, device=DEV)
+    for span in (0.5, 4.0, 12.0, 40.0):
+        x = ((torch.rand(1, C, H, W, generator=g) * 2 - 1) * span).to(DEV)
+        h, gp = torch.empty_like(x), torch.empty_like(x)
+        ops._conv(x, w, None, h, B=1, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=zero, shift=zero, out2=gp)
+        xd = x.double().cpu()
+        cdf = 0.5 * (1 + torch.erf(xd / math.sqrt(2.0)))
+        pdf = torch.exp(-0.5 * xd * xd) / math.sqrt(2 * math.pi)
+        eh = ((h.double().cpu() - xd * cdf).abs() / (1 + xd.abs())).max().item()
+        eg = (gp.double().cpu() - (cdf + xd * pdf)).abs().max().item()
+        assert eh < 3e-7 and eg < 6e-7, (span, eh, eg)
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_cem_fused_quantise_rate_vs_oracle(ops, training):
     """bnerv_cem_scale_fwd / _bwd against the CPU restatement (oracle/cem_ref.py, itself pinned to the reference): bits, mean, std,
