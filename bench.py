@@ -104,7 +104,7 @@ def dominant_kernel_roofline(dev, reps=30):
     traffic, traffic_src = None, None
     try:
         import json as _json
-        tj = _json.load(open(os.path.join(ROOT, "profiles", "r01_d_traffic.json")))
+        tj = _json.load(open(os.path.join(ROOT, "profiles", "r01_f_traffic.json")))
         traffic, traffic_src = float(tj["hbm_bytes_per_launch"]), tj["source"]
     except (OSError, KeyError, ValueError):
         pass

@@ -1144,9 +1144,12 @@ template <int KS, int IN, int EP, int NTB>
 __global__ __launch_bounds__(256, (NTB == 1 ? 3 : 2)) void conv_lean2_kernel(const KArgs ka, const SidePack side) {
     using G = Geo<KS>;
     constexpr int NQ1 = 4, NCH = 16;
-    constexpr int NSLOT = NCH * G::ROWS * G::SEGS;
+    // IN_UNSHUFFLE (in_s == 2, the data gradient of an up-conv feeding PixelShuffle(2)): conv channel 4c + 2i + j at (y, x) is
+    // du[c][2y + i][2x + j]; a slot is (c, i, row, 4-px segment) = 8 consecutive floats of one du row, split into the j = 0 / 1 planes
+    constexpr bool UNSH = (IN == BNERV_IN_UNSHUFFLE);
+    constexpr int NSLOT = (UNSH ? NCH / 2 : NCH) * G::ROWS * G::SEGS;
     constexpr int NPRE = (NSLOT + 255) / 256;
-    constexpr int S_IN = NCH * G::PLANE + (NPRE * 256 - NSLOT) * 4;
+    constexpr int S_IN = NCH * G::PLANE + (UNSH ? 0 : (NPRE * 256 - NSLOT) * 4);
     constexpr bool TWO = (IN == BNERV_IN_TANHGRAD);
     constexpr bool AFF = (IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE);
     constexpr bool RED = (EP == BNERV_EP_DGELU || EP == BNERV_EP_DSIN || EP == BNERV_EP_DGELU_SAVED);
@@ -1187,9 +1190,10 @@ __global__ __launch_bounds__(256, (NTB == 1 ? 3 : 2)) void conv_lean2_kernel(con
     };
     auto loff = [&](int k) {
         const int sidx = tid + k * 256;
-        if constexpr (G::PLANE == G::PLANE_RAW) return sidx * 16;
         int c, r, sg;
         slot_geom(k, c, r, sg);
+        if constexpr (UNSH) return ((4 * (c >> 1) + 2 * (c & 1)) * G::PLANE + r * G::RS + 4 * sg) * 4;   // the j = 0 plane; j = 1 follows
+        if constexpr (G::PLANE == G::PLANE_RAW) return sidx * 16;
         return sidx < NSLOT ? (c * G::PLANE + r * G::RS + 4 * sg) * 4 : (NCH * G::PLANE + (sidx - NSLOT) * 4) * 4;
     };
     unsigned voff[NPRE];                                   // chunk-local: channel c of the chunk
@@ -1197,9 +1201,10 @@ __global__ __launch_bounds__(256, (NTB == 1 ? 3 : 2)) void conv_lean2_kernel(con
     for (int k = 0; k < NPRE; ++k) {
         int c, r, sg;
         slot_geom(k, c, r, sg);
-        voff[k] = (tid + k * 256 < NSLOT) ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB;
+        if constexpr (UNSH) voff[k] = (tid + k * 256 < NSLOT) ? (unsigned)(((((c >> 1) * 2 * H) + 2 * r + (c & 1)) * (2 * W) + 8 * sg) * 4) : OOB;
+        else voff[k] = (tid + k * 256 < NSLOT) ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB;
     }
-    const unsigned shift = (unsigned)((G::PAD * W + G::XOFF) * 4);
+    const unsigned shift = UNSH ? (unsigned)((2 * G::PAD * 2 * W + 2 * G::XOFF) * 4) : (unsigned)((G::PAD * W + G::XOFF) * 4);
     const unsigned in_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
     const unsigned out_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, in_bytes);
@@ -1221,10 +1226,11 @@ __global__ __launch_bounds__(256, (NTB == 1 ? 3 : 2)) void conv_lean2_kernel(con
         lds_barrier();
     };
 
-    f32x4 ra[NPRE], rb[TWO ? NPRE : 1];
+    f32x4 ra[NPRE], rb[(TWO || UNSH) ? NPRE : 1];
     // stage = (item, chunk); issue its loads / commit them to s_in
     auto issue = [&](const Item& a, int c0) {
-        const unsigned sb = (unsigned)((((a.b * Cin + c0) * H + a.ty0) * W + a.tx0) * 4);
+        const unsigned sb = UNSH ? (unsigned)((((a.b * (Cin >> 2) + (c0 >> 2)) * 2 * H + 2 * a.ty0) * (2 * W) + 2 * a.tx0) * 4)
+                                 : (unsigned)((((a.b * Cin + c0) * H + a.ty0) * W + a.tx0) * 4);
         const bool interior = a.ty0 >= G::PAD && a.ty0 + TH + G::PAD <= H && a.tx0 >= G::XOFF && a.tx0 + TW + G::XOFF <= W;
         const int nch = min(NCH, Cin - c0);
         const bool plain = interior && nch == NCH;
@@ -1234,16 +1240,25 @@ __global__ __launch_bounds__(256, (NTB == 1 ? 3 : 2)) void conv_lean2_kernel(con
             if (!plain) {
                 int c, r, sg;
                 slot_geom(k, c, r, sg);
-                if (c >= nch || (!interior && !slot_inside(k, a.ty0, a.tx0))) vo = OOB;
+                if ((UNSH ? 2 * c : c) >= nch || (!interior && !slot_inside(k, a.ty0, a.tx0))) vo = OOB;
             }
             ra[k] = bload(rx, vo, sb);
             if constexpr (TWO) rb[k] = bload(rx2, vo, sb);
+            if constexpr (UNSH) rb[k] = bload(rx, vo == OOB ? OOB : vo + 16u, sb);
         }
     };
     auto commit = [&](const Item& a, int c0) {
         const bool interior = a.ty0 >= G::PAD && a.ty0 + TH + G::PAD <= H && a.tx0 >= G::XOFF && a.tx0 + TW + G::XOFF <= W;
 #pragma unroll
         for (int k = 0; k < NPRE; ++k) {
+            if constexpr (UNSH) {
+                if (k == NPRE - 1 && tid + k * 256 >= NSLOT) continue;                 // idle slots of the last round
+                const f32x4 a0 = ra[k], a1 = rb[k];
+                char* dst = reinterpret_cast<char*>(s_in) + loff(k);
+                *reinterpret_cast<f32x4*>(dst) = f32x4{a0[0], a0[2], a1[0], a1[2]};
+                *reinterpret_cast<f32x4*>(dst + G::PLANE * 4) = f32x4{a0[1], a0[3], a1[1], a1[3]};
+                continue;
+            }
             f32x4 v = ra[k];
             if constexpr (IN != BNERV_IN_PLAIN) {
                 float sc_ = 0.f, sh_ = 0.f;
@@ -1509,7 +1524,7 @@ int launch_lean2(hipStream_t st, KArgs& ka) {
     ka.w_resident = wres <= (size_t)W_RESIDENT_MAX ? 1 : 0;
     if ((IN == BNERV_IN_TANHGRAD || NTB == 1) && !ka.w_resident) return -1;       // caller falls back to the generic kernel
     const size_t wfl = ka.w_resident ? wres : (size_t)G::T * 4 * NTB * 64;
-    const size_t lds = ((size_t)16 * G::PLANE + (size_t)(NPRE * 256 - NSLOT) * 4 + (size_t)4 * 2 * NTB * 16 + 2 * 128 + wfl) * sizeof(float);
+    const size_t lds = ((size_t)16 * G::PLANE + (size_t)(NPRE * 256 - NSLOT) * 4 + (size_t)4 * 2 * NTB * 16 + 2 * 128 + wfl) * sizeof(float);   // (dump area unused by the unshuffle path)
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean2_kernel<KS, IN, EP, NTB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1531,7 +1546,9 @@ static bool lean2_ok(const KArgs& ka) {
     const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
     static const bool off = getenv("BNERV_NO_LEAN2") != nullptr;          // A/B switch for tools/kbench.py
     if (off) return false;
-    return ka.vec && d.out_s == 1 && d.k == 3 && (d.Cin > 16 || d.Cout > 16) && d.Cin <= 128 && ka.ksplit == 1 &&
+    if (d.in_mode == BNERV_IN_UNSHUFFLE && (d.in_s != 2 || d.Cin % 4 != 0)) return false;
+    const bool affine = d.in_mode == BNERV_IN_AFFINE || d.in_mode == BNERV_IN_GELU_AFFINE;   // (the LDS table of scale/shift holds 128 channels)
+    return ka.vec && d.out_s == 1 && d.k == 3 && (d.Cin > 16 || d.Cout > 16) && (d.Cin <= 128 || !affine) && ka.ksplit == 1 &&
            (size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 < LEAN_MAX_BYTES;
 }
 
@@ -1544,7 +1561,7 @@ static bool lean_ok(const KArgs& ka) {
 
 template <int KS, int IN, int EP, int NTB>
 int launch_one(hipStream_t st, KArgs& ka) {
-    if constexpr (KS == 3 && IN != BNERV_IN_UNSHUFFLE && NTB <= 3 &&
+    if constexpr (KS == 3 && NTB <= 3 && (IN != BNERV_IN_UNSHUFFLE || EP == BNERV_EP_PLAIN) &&
                   (EP == BNERV_EP_BIAS || EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU || EP == BNERV_EP_BIAS_RES || EP == BNERV_EP_BIAS_TANH || EP == BNERV_EP_PLAIN ||
                    EP == BNERV_EP_DGELU_SAVED || EP == BNERV_EP_DSIN)) {
         if (lean2_ok(ka)) { const int rc = launch_lean2<KS, IN, EP, NTB>(st, ka); if (rc != -1) return rc; }

@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = [  # (B, Cin, Cout, H, W)
     (1, 30, 30, 45, 80), (2, 38, 38, 9, 40), (1, 38, 38, 1080, 1920), (1, 46, 46, 540, 960), (1, 55, 55, 270, 480),
     (1, 22, 22, 540, 960), (1, 44, 44, 270, 480), (1, 38, 3, 1080, 1920), (1, 3, 38, 1080, 1920), (1, 95, 95, 18, 32), (3, 17, 20, 24, 36),
+    (1, 12, 12, 360, 640), (1, 12, 15, 90, 160), (2, 5, 7, 19, 36),
 ]
 if os.environ.get("KLEAN2_SMALL"):
     SHAPES = [s for s in SHAPES if s[3] * s[4] < 100000]
@@ -32,6 +33,8 @@ def leg(path):
         sci, shi = rnd(B, Ci, sc=0.3), rnd(B, Ci, sc=0.3)
         sco = rnd(B, Co, sc=0.3)
         kw = dict(B=B, Cin=Ci, Cout=Co, H=H, W=W, k=3)
+        xu = rnd(B, Ci, 2 * H, 2 * W) if Ci <= 46 else None     # gradient of a PixelShuffle(2) output: conv-space Cin = 4 Ci
+        wu = rnd(4 * Ci, Co, 3, 3, sc=0.1) if Ci <= 46 else None
         modes = {
             "affine->gelu": lambda o, o2: ops._conv(x, w, b, o, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=sci, shift=shi, out2=o2, **kw),
             "affine->res": lambda o, o2: ops._conv(x, w, b, o, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_RES, scale=sci, shift=shi, aux0=a0, **kw),
@@ -39,9 +42,12 @@ def leg(path):
             "plain->tanh": lambda o, o2: ops._conv(x, w, b, o, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_TANH, **kw),
             "T plain->dgelu_saved": lambda o, o2: o2.__setitem__(slice(0, B * 2 * Co), ops._conv(x, wt, None, o, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU_SAVED, transposed=1, aux0=a0, aux1=a1, scale=sco, **kw).reshape(-1)),
             "T plain->dsin": lambda o, o2: o2.__setitem__(slice(0, B * 2 * Co), ops._conv(x, wt, None, o, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN, transposed=1, aux0=a0, aux1=a1, aux2=a2, scale=sco, **kw).reshape(-1)),
+            "T unshuffle2->plain": (lambda o, o2: ops._conv(xu, wu, None, o, B=B, Cin=4 * Ci, Cout=Co, H=H, W=W, k=3, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=2, transposed=1)) if Ci <= 46 else None,
             "T tanhgrad->plain": lambda o, o2: ops._conv(x, wt, None, o, in_mode=L.IN_TANHGRAD, ep_mode=L.EP_PLAIN, transposed=1, aux0=gx, **kw),
         }
         for name, fn in modes.items():
+            if fn is None:
+                continue
             o = torch.zeros(B, Co, H, W, device=dev)
             o2 = torch.zeros(B, Co, H, W, device=dev)
             key = f"{name} {B}x{Ci}->{Co}@{H}x{W}"

@@ -1,17 +1,18 @@
-"""Run ONE hot kernel a few times (for rocprofv3 --pmc runs).  usage: kone.py conv|wgrad [reps]"""
+"""Run ONE hot kernel a few times (for rocprofv3 --pmc runs).  usage: kone.py conv|wgrad|conv38|wgrad38 [reps]
+conv / wgrad: the 12->12 3x3 layer at 720x1280 (C1); conv38 / wgrad38: the 38->38 3x3 layer at 1080x1920 (C3)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from boosting_nerv_amd import _lib as L, ops
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "conv"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-B, C, H, W = 1, 12, 720, 1280
+B, C, H, W = (1, 38, 1080, 1920) if which.endswith("38") else (1, 12, 720, 1280)
 x, g = torch.randn(B, C, H, W, device=dev), torch.randn(B, C, H, W, device=dev)
 w, b = torch.randn(C, C, 3, 3, device=dev) / 10, torch.randn(C, device=dev)
 sc, sh = torch.randn(B, C, device=dev) * 0.1, torch.randn(B, C, device=dev) * 0.1
 out = torch.empty_like(x); dw, db = torch.empty_like(w), torch.empty_like(b)
 for _ in range(reps):
-    if which == "conv":
+    if which.startswith("conv"):
         ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS, scale=sc, shift=sh)
     else:
         ops._wgrad(x, g, dw, db, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE)
