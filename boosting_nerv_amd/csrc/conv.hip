@@ -1136,7 +1136,7 @@ int launch_lean(hipStream_t st, KArgs& ka) {
 
 // ---------------------------------------------------------------------------------------------------------------- lean2 kernel
 // The lean recipe for the layers the first lean kernel does not take: Cin > 16 (K walked in chunks of 16 channels, the next
-// (tile, chunk) stage prefetched into registers under the MFMA phase of the current one) and/or Cout > 16 (NTB <= 3 cout
+// (tile, chunk) stage prefetched into registers under the MFMA phase of the current one) and/or Cout > 16 (NTB <= 4 cout
 // tiles per block, the input tile staged once for all of them).  Stride-1 outputs only: the epilogue works straight from the
 // accumulators for every cout tile.  These are the TAT convolutions, heads and their data gradients of the 3M models
 // (22..55 channels) and of C1's 30-channel stage; the generic kernel keeps PixelShuffle outputs and the unshuffle prologue.
@@ -1561,7 +1561,7 @@ static bool lean_ok(const KArgs& ka) {
 
 template <int KS, int IN, int EP, int NTB>
 int launch_one(hipStream_t st, KArgs& ka) {
-    if constexpr (KS == 3 && NTB <= 3 && (IN != BNERV_IN_UNSHUFFLE || EP == BNERV_EP_PLAIN) &&
+    if constexpr (KS == 3 && (NTB <= 3 || (NTB == 4 && EP != BNERV_EP_BIAS_SIN)) && (IN != BNERV_IN_UNSHUFFLE || EP == BNERV_EP_PLAIN) &&   // (4 tiles + sincos spills)
                   (EP == BNERV_EP_BIAS || EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU || EP == BNERV_EP_BIAS_RES || EP == BNERV_EP_BIAS_TANH || EP == BNERV_EP_PLAIN ||
                    EP == BNERV_EP_DGELU_SAVED || EP == BNERV_EP_DSIN)) {
         if (lean2_ok(ka)) { const int rc = launch_lean2<KS, IN, EP, NTB>(st, ka); if (rc != -1) return rc; }

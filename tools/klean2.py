@@ -35,6 +35,9 @@ def leg(path):
         kw = dict(B=B, Cin=Ci, Cout=Co, H=H, W=W, k=3)
         xu = rnd(B, Ci, 2 * H, 2 * W) if Ci <= 46 else None     # gradient of a PixelShuffle(2) output: conv-space Cin = 4 Ci
         wu = rnd(4 * Ci, Co, 3, 3, sc=0.1) if Ci <= 46 else None
+        if Co <= 46 and Co > 3:
+            wps, bps = rnd(4 * Co, Ci, 3, 3, sc=0.1), rnd(4 * Co)
+            ps_o, ps_o2 = torch.zeros(B, Co, 2 * H, 2 * W, device=dev), torch.zeros(B, Co, 2 * H, 2 * W, device=dev)
         modes = {
             "affine->gelu": lambda o, o2: ops._conv(x, w, b, o, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=sci, shift=shi, out2=o2, **kw),
             "affine->res": lambda o, o2: ops._conv(x, w, b, o, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_RES, scale=sci, shift=shi, aux0=a0, **kw),
@@ -43,6 +46,8 @@ def leg(path):
             "T plain->dgelu_saved": lambda o, o2: o2.__setitem__(slice(0, B * 2 * Co), ops._conv(x, wt, None, o, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU_SAVED, transposed=1, aux0=a0, aux1=a1, scale=sco, **kw).reshape(-1)),
             "T plain->dsin": lambda o, o2: o2.__setitem__(slice(0, B * 2 * Co), ops._conv(x, wt, None, o, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN, transposed=1, aux0=a0, aux1=a1, aux2=a2, scale=sco, **kw).reshape(-1)),
             "T unshuffle2->plain": (lambda o, o2: ops._conv(xu, wu, None, o, B=B, Cin=4 * Ci, Cout=Co, H=H, W=W, k=3, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=2, transposed=1)) if Ci <= 46 else None,
+            "plain->sin PS2 (x4 cout)": (lambda o, o2: (ops._conv(x, wps, bps, ps_o, B=B, Cin=Ci, Cout=4 * Co, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_SIN, out_s=2, out2=ps_o2),
+                                                          o.copy_(ps_o[:, :, 0::2, 1::2]), o2.copy_(ps_o2[:, :, 1::2, 0::2]))) if Co <= 46 and Co > 3 else None,
             "T tanhgrad->plain": lambda o, o2: ops._conv(x, wt, None, o, in_mode=L.IN_TANHGRAD, ep_mode=L.EP_PLAIN, transposed=1, aux0=gx, **kw),
         }
         for name, fn in modes.items():
