@@ -115,6 +115,9 @@ SYMBOLS = {
     "bnerv_dwconv_fwd": (_I, [_V, _V, _V, _V, _V, _I, _I, _I, _I, _I, _I]),
     "bnerv_dwconv_wgrad_ws_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "bnerv_dwconv_wgrad": (_I, [_V, _V, _V, _V, _V, _Z, _I, _I, _I, _I, _I, _I]),
+    "bnerv_lncf_fwd": (_I, [_V, _V, _V, _V, _V, _I, _I, _I, _F]),
+    "bnerv_lncf_bwd_ws_bytes": (_Z, [_I, _I, _I]),
+    "bnerv_lncf_bwd": (_I, [_V, _V, _V, _V, _V, _V, _V, _Z, _I, _I, _I, _F]),
     "bnerv_loss_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bnerv_fft_prepare": (_I, [_I, _I]),
     "bnerv_loss_fwd_bwd": (_I, [_V, C.POINTER(LossDesc)]),

@@ -302,6 +302,8 @@ class LayerNorm(nn.Module):
     def forward(self, x):
         if self.data_format == "channels_last":
             return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+        if x.is_cuda and x.dim() == 4 and x.shape[1] <= ops.LN_CF_MAX_C:       # one HIP kernel instead of ~8 elementwise launches (row N3)
+            return ops.layernorm_cf(x, self.weight, self.bias, self.eps)
         u = x.mean(1, keepdim=True)
         s = (x - u).pow(2).mean(1, keepdim=True)
         x = (x - u) / torch.sqrt(s + self.eps)
@@ -323,6 +325,17 @@ class Block(nn.Module):
 
     def forward(self, x):
         inp = x
+        if x.is_cuda and x.shape[1] <= ops.LN_CF_MAX_C:
+            # Row N3: HIP depthwise conv and channel LayerNorm, everything kept NCHW -- the pointwise linears become 1x1 convs on
+            # the same weights (no permute copies in either direction; same arithmetic as the channels_last form)
+            dim = x.shape[1]
+            x = ops.dwconv(x, self.dwconv.weight, self.dwconv.bias)
+            x = ops.layernorm_cf(x, self.norm.weight, self.norm.bias, self.norm.eps)
+            x = F.conv2d(x, self.pwconv1.weight.view(4 * dim, dim, 1, 1), self.pwconv1.bias)
+            x = F.conv2d(self.act(x), self.pwconv2.weight.view(dim, 4 * dim, 1, 1), self.pwconv2.bias)
+            if self.gamma is not None:
+                x = self.gamma.view(1, dim, 1, 1) * x
+            return inp + x
         if x.is_cuda:        # HIP depthwise kernels (row N3); MIOpen only has its naive fp32 fallback for these shapes
             x = ops.dwconv(x, self.dwconv.weight, self.dwconv.bias).permute(0, 2, 3, 1)
         else:

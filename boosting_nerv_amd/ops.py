@@ -541,6 +541,41 @@ def dwconv(x, w, b):
     return _DWConv.apply(x, w, b)
 
 
+LN_CF_MAX_C = 64
+
+
+class _LayerNormCF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = L.f32c(L.require_device(x, "x")); w = L.f32c(w); b = L.f32c(b)
+        B, Cc = x.shape[:2]
+        HW = x[0, 0].numel()
+        y = torch.empty_like(x)
+        L.check(L.load().bnerv_lncf_fwd(L.stream(), L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, Cc, HW, float(eps)), "bnerv_lncf_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = L.f32c(g)
+        B, Cc = x.shape[:2]
+        HW = x[0, 0].numel()
+        lib = L.load()
+        nbytes = lib.bnerv_lncf_bwd_ws_bytes(B, Cc, HW)
+        ws = _ws(nbytes, x.device)
+        dx = torch.empty_like(x)
+        dwb = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
+        L.check(lib.bnerv_lncf_bwd(L.stream(), L.ptr(x), L.ptr(w), L.ptr(g), L.ptr(dx), L.ptr(dwb), L.ptr(ws), nbytes, B, Cc, HW, ctx.eps), "bnerv_lncf_bwd")
+        return dx, dwb[0], dwb[1], None
+
+
+def layernorm_cf(x, w, b, eps):
+    """LayerNorm over dim 1 of an NCHW tensor, C <= 64 (model_blocks.py:250-270 `LayerNorm`, data_format channels_first)."""
+    return _LayerNormCF.apply(x, w, b, eps)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # loss / metrics
 # ----------------------------------------------------------------------------------------------------------------------

@@ -94,6 +94,15 @@ int bnerv_dense_grouped_bwd(void* stream, const bnerv_dense_bwd_desc* groups, in
 int bnerv_sft_affine_fwd(void* stream, const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW);
 int bnerv_sft_affine_bwd(void* stream, const float* x, const float* scale, const float* g, float* dx, float* part, int B, int C, int HW);
 
+/* LayerNorm over the channel axis of an NCHW tensor (reference: model_blocks.py:250-270 `LayerNorm`, data_format
+ * "channels_first"; the "channels_last" form of the ConvNeXt block is the same arithmetic on the permuted tensor):
+ *   y[b,c,p] = w[c] * (x[b,c,p] - mean_c) / sqrt(var_c + eps) + b[c],  var = mean_c (x - mean_c)^2.   1 <= C <= 64.
+ * bwd: dx as autograd's; dwb = [2][C] = (dw, db), summed over b and p in a fixed order (ws: bnerv_lncf_bwd_ws_bytes). */
+int bnerv_lncf_fwd(void* stream, const float* x, const float* w, const float* b, float* y, int B, int C, int HW, float eps);
+size_t bnerv_lncf_bwd_ws_bytes(int B, int C, int HW);
+int bnerv_lncf_bwd(void* stream, const float* x, const float* w, const float* dy, float* dx, float* dwb, void* ws, size_t ws_bytes,
+                   int B, int C, int HW, float eps);
+
 /* out[i] = sum_{s<n_slabs} slabs[s*count + i]   (deterministic finish of every split reduction in this library) */
 int bnerv_reduce_slabs(void* stream, const float* slabs, int n_slabs, int count, float* out);
 

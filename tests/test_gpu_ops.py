@@ -349,6 +349,51 @@ def test_dwconv_fwd_bwd(ops, shape):
         close(a, r, msg=f"dwconv d{n}")
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 23, 70), (1, 64, 36, 64), (3, 16, 9, 16), (1, 1, 4, 300)])
+def test_layernorm_channels_first(ops, shape):
+    """Channel LayerNorm on NCHW (lnorm.hip) against the reference's channels_first arithmetic in float64: y, dx, dw, db."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(B, C, H, W, generator=g) * 2 + 0.5).requires_grad_(True)
+    w = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    b = torch.randn(C, generator=g).requires_grad_(True)
+    cot = torch.randn(B, C, H, W, generator=g)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    u = xd.mean(1, keepdim=True)
+    s = (xd - u).pow(2).mean(1, keepdim=True)
+    ref = wd[:, None, None] * ((xd - u) / torch.sqrt(s + 1e-6)) + bd[:, None, None]
+    rg = torch.autograd.grad(ref, [xd, wd, bd], cot.double())
+    xs = [gpu(t) for t in (x, w, b)]
+    out = ops.layernorm_cf(xs[0], xs[1], xs[2], 1e-6)
+    close(out, ref.float(), msg="ln fwd")
+    for n, a, r in zip(("x", "w", "b"), torch.autograd.grad(out, xs, cot.to(DEV)), rg):
+        close(a, r.float(), msg=f"ln d{n}")
+
+
+def test_convnext_block_matches_channels_last_form(ops):
+    """Block.forward on the GPU (NCHW: HIP dwconv + HIP LayerNorm + 1x1 convs) against the module's own CPU path, which is the
+    reference's channels_last sequence (model_blocks.py:223-247): output and every parameter gradient."""
+    from boosting_nerv_amd import model_blocks as mb
+    torch.manual_seed(5)
+    blk = mb.Block(dim=16, layer_scale_init_value=0.5)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.add_(torch.randn_like(p_) * 0.1)
+    x = torch.randn(2, 16, 18, 32)
+    cot = torch.randn(2, 16, 18, 32)
+    xr = x.clone().requires_grad_(True)
+    ref = blk(xr)
+    rg = torch.autograd.grad(ref, [xr] + list(blk.parameters()), cot)
+    import copy
+    gblk = copy.deepcopy(blk).to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out = gblk(xg)
+    close(out, ref, msg="block fwd")
+    names = ["x"] + [n for n, _ in blk.named_parameters()]
+    for n, a, r in zip(names, torch.autograd.grad(out, [xg] + list(gblk.parameters()), cot.to(DEV)), rg):
+        close(a, r, msg=f"block d{n}")
+
+
 def test_sincos_epilogue_accuracy(ops):
     """The sin/cos pair of the block activation (common.h sincos_f), read back exactly through an identity 1x1 conv (MFMA f32
     is exact, so the epilogue sees x itself): against float64 sin/cos on moderate and on large arguments."""
