@@ -61,34 +61,49 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const FwdArgs a) {
 // ---------------------------------------------------------------- grouped dense backward
 struct BwdArgs { bnerv_dense_bwd_desc g[BNERV_MAX_DENSE_GROUPS]; int B; };
 
-// phase 1: one wave per output row o: dpre[b][o], dw[o][:], db[o]
+// phase 1: one wave per (output row o, column chunk): dpre[b][o], dw[o][chunk], db[o].  Rows with many inputs (E-NeRV: I ~ 9000) are
+// split over blockIdx.z in chunks of DW_CHUNK columns -- a single wave walking the whole row is a serial chain of ~140 dependent
+// load/store rounds (70 us per launch at C4); 4 independent columns per lane and round keep the loads in flight.
+constexpr int DW_CHUNK = 1024;
 __global__ __launch_bounds__(256) void dense_bwd_w_kernel(const BwdArgs a) {
     const BwdArgs* ap = &a;
     const bnerv_dense_bwd_desc g = a.g[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int o = blockIdx.x * 4 + wave;
-    if (o >= g.O) return;
+    const int i0 = blockIdx.z * DW_CHUNK;
+    if (o >= g.O || (i0 >= g.I && blockIdx.z != 0)) return;
     const int B = ap->B;
-    float dbsum = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const size_t k = (size_t)b * g.O + o;
-        float dp = g.dy[k];
-        if (g.act == BNERV_ACT_RELU) dp = g.y[k] > 0.f ? dp : 0.f;
-        else if (g.act == BNERV_ACT_SIN) dp *= g.aux[k];
-        if (lane == 0) g.dpre[k] = dp;
-        dbsum += dp;
-    }
-    if (lane == 0 && g.db) g.db[o] = dbsum;
-    for (int i = lane; i < g.I; i += 64) {
-        float s = 0.f;
+    if (blockIdx.z == 0) {
+        float dbsum = 0.f;
         for (int b = 0; b < B; ++b) {
             const size_t k = (size_t)b * g.O + o;
             float dp = g.dy[k];
             if (g.act == BNERV_ACT_RELU) dp = g.y[k] > 0.f ? dp : 0.f;
             else if (g.act == BNERV_ACT_SIN) dp *= g.aux[k];
-            s = fmaf(dp, g.x[(size_t)b * g.I + i], s);
+            if (lane == 0) g.dpre[k] = dp;
+            dbsum += dp;
         }
-        g.dw[(size_t)o * g.I + i] = s;
+        if (lane == 0 && g.db) g.db[o] = dbsum;
+    }
+    const int i1 = min(i0 + DW_CHUNK, g.I);
+    for (int ib = i0 + lane; ib < i1; ib += 256) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) {
+            const size_t k = (size_t)b * g.O + o;
+            float dp = g.dy[k];
+            if (g.act == BNERV_ACT_RELU) dp = g.y[k] > 0.f ? dp : 0.f;
+            else if (g.act == BNERV_ACT_SIN) dp *= g.aux[k];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = ib + 64 * u;
+                if (i < i1) s[u] = fmaf(dp, g.x[(size_t)b * g.I + i], s[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = ib + 64 * u;
+            if (i < i1) g.dw[(size_t)o * g.I + i] = s[u];
+        }
     }
 }
 
@@ -215,7 +230,7 @@ extern "C" int bnerv_dense_grouped_bwd(void* stream, const bnerv_dense_bwd_desc*
     BNERV_REQUIRE(groups && n_groups > 0 && n_groups <= BNERV_MAX_DENSE_GROUPS && B > 0 && B <= 65535, "dense_grouped_bwd: bad args (n_groups=%d)", n_groups);
     BwdArgs a;
     a.B = B;
-    int maxO = 0;
+    int maxO = 0, maxI = 0;
     bool any_dx = false;
     for (int i = 0; i < n_groups; ++i) {
         const bnerv_dense_bwd_desc& g = groups[i];
@@ -224,10 +239,11 @@ extern "C" int bnerv_dense_grouped_bwd(void* stream, const bnerv_dense_bwd_desc*
         if (g.act == BNERV_ACT_SIN) BNERV_REQUIRE(g.aux, "dense_grouped_bwd: sin group %d needs aux", i);
         a.g[i] = g;
         if (g.O > maxO) maxO = g.O;
+        if (g.I > maxI) maxI = g.I;
         any_dx |= g.dx_part != nullptr;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dense_bwd_w_kernel, dim3(cdiv(maxO, 4), n_groups), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(dense_bwd_w_kernel, dim3(cdiv(maxO, 4), n_groups, cdiv(maxI, DW_CHUNK)), dim3(256), 0, st, a);
     BNERV_LAUNCH_CHECK("dense_bwd_w");
     if (any_dx) {
         hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(cdiv(maxO, BNERV_DENSE_DX_CHUNK), B, n_groups), dim3(256), 0, st, a);

@@ -102,3 +102,47 @@ class TrainStep:
                 self.graph_b.replay()
         self.n_calls += 1
         return self.loss_out, self.psnr_out
+
+
+class DecodeGraph:
+    """Forward-only decode of one batch as a captured hipGraph (row N4: the rate evaluate() logs as "FPS" under --eval_fps,
+    train_nerv_all.py:492-496 of the reference, is ~35 Python-driven launches per frame when run eagerly).  The graph replays
+    `model(cur_input, embed, norm_idx=norm_idx)` on static copies of its inputs; `__call__` refreshes them, replays, and returns
+    (img_out, seconds) with the same synchronised-timer definition the model's own `dec_time` uses."""
+
+    def __init__(self, model, cur_input, embed, norm_idx):
+        import time as _time
+        self._time = _time
+        self.inp = cur_input.clone()
+        self.embed = None if embed is None else embed.clone()
+        self.norm = norm_idx.clone()
+        td = getattr(model, "time_decode", False)
+        model.time_decode = False                           # no host synchronisation inside the capture
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        try:
+            with torch.no_grad(), torch.cuda.stream(side):
+                for _ in range(2):                          # warm-up: workspaces and lazily built tables exist before capture
+                    model(self.inp, self.embed, norm_idx=self.norm)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=side):
+                    self.out = model(self.inp, self.embed, norm_idx=self.norm)[0]
+        finally:
+            model.time_decode = td
+            cur.wait_stream(side)
+
+    def matches(self, cur_input, embed, norm_idx):
+        return (cur_input.shape == self.inp.shape and norm_idx.shape == self.norm.shape and
+                (embed is None) == (self.embed is None) and (embed is None or embed.shape == self.embed.shape))
+
+    def __call__(self, cur_input, embed, norm_idx):
+        self.inp.copy_(cur_input)
+        self.norm.copy_(norm_idx)
+        if self.embed is not None:
+            self.embed.copy_(embed)
+        torch.cuda.synchronize()
+        t0 = self._time.time()
+        self.graph.replay()
+        torch.cuda.synchronize()
+        return self.out, self._time.time() - t0

@@ -478,6 +478,7 @@ def evaluate(model, full_dataloader, local_rank, args, dump_vis=False, huffman_c
     fps, hw = 0.0, (0, 0)
     for model_ind, cur_model in enumerate(model_list):
         time_list = []
+        decode_graph = None
         cur_model.eval()
         cur_model.time_decode = True
         device = next(cur_model.parameters()).device
@@ -503,9 +504,18 @@ def evaluate(model, full_dataloader, local_rank, args, dump_vis=False, huffman_c
             time_list.append(dec_time)
             if args.eval_fps:
                 time_list.pop()
-                for _ in range(100):
-                    _, _, dec_time = cur_model(cur_input, embed_list[0], norm_idx=norm_idx)
-                    time_list.append(dec_time)
+                # row N4: the 100 timing decodes replay a captured hipGraph of the same forward (BNERV_EVAL_GRAPH=0: eager, as the reference)
+                if img_out.is_cuda and os.environ.get('BNERV_EVAL_GRAPH', '1') != '0':
+                    from .engine import DecodeGraph
+                    if decode_graph is None or not decode_graph.matches(cur_input, embed_list[0], norm_idx):
+                        decode_graph = DecodeGraph(cur_model, cur_input, embed_list[0], norm_idx)
+                    for _ in range(100):
+                        _, dec_time = decode_graph(cur_input, embed_list[0], norm_idx)
+                        time_list.append(dec_time)
+                else:
+                    for _ in range(100):
+                        _, _, dec_time = cur_model(cur_input, embed_list[0], norm_idx=norm_idx)
+                        time_list.append(dec_time)
             # metrics stay on the device (row N4): no per-frame .cpu(); they are read when a line is printed and at the end
             pred_psnr, pred_ssim = ops.psnr(img_out, img_gt)[None], ops.msssim(img_out.float(), img_gt)[None]
             for metric_idx, cur_v in enumerate([pred_psnr, pred_ssim]):

@@ -99,6 +99,31 @@ def test_c1_full_size_against_reference_golden():
         assert abs(got - gn) <= 5e-3 * gn + 1e-6, (k, got, gn)
 
 
+@pytest.mark.parametrize("name,cfg", [("tiny_nerv", configs.tiny_nerv), ("tiny_enerv", configs.tiny_enerv), ("tiny_hnerv", configs.tiny_hnerv)])
+def test_decode_graph_equals_eager_decode(name, cfg):
+    """engine.DecodeGraph (the captured forward evaluate() replays under --eval_fps) returns bit-identical images to the eager
+    no_grad forward, for fresh inputs copied into its static buffers; HNeRV decodes from the embedding as evaluate() does."""
+    from boosting_nerv_amd.engine import DecodeGraph
+    args = cfg()
+    torch.manual_seed(3)
+    model = _build(name, args).to(DEV).eval()
+    h, w = 180, 320                                       # every tiny config decodes 9x16 -> 180x320
+    g = torch.Generator().manual_seed(9)
+    frames = torch.rand(3, 1, 3, h, w, generator=g).to(DEV)
+    norms = [torch.tensor([(i + 1) / 7], dtype=torch.float64, device=DEV) for i in range(3)]
+    takes_image = args.model == "HNeRV_Boost"
+    with torch.no_grad():
+        ins = [frames[i] if takes_image else norms[i] for i in range(3)]
+        first = model(ins[0], norm_idx=norms[0])
+        embeds = [model(ins[i], norm_idx=norms[i])[1][0] for i in range(3)]
+        dg = DecodeGraph(model, ins[0], embeds[0], norms[0])
+        for i in (1, 2, 0):
+            ref = model(ins[i], embeds[i], norm_idx=norms[i])[0]
+            out, dt = dg(ins[i], embeds[i], norms[i])
+            assert dt > 0 and torch.equal(out, ref), (name, i, float((out - ref).abs().max()))
+    assert torch.equal(first[0], model(ins[0], embeds[0], norm_idx=norms[0])[0]) or takes_image
+
+
 @pytest.mark.parametrize("name,cfg", [("c3", configs.c3), ("c4", configs.c4)])
 def test_big_models_init_and_step_run(name, cfg):
     """C3 (HNeRV-boost 3M) and C4 (E-NeRV-boost 3M) at 1080x1920: seeded init hash equals the reference's; one full train
