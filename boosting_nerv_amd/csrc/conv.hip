@@ -1679,6 +1679,47 @@ extern "C" int bnerv_conv_partial_rows(const bnerv_conv_desc* dp) {
     return cdiv(d.H, TH) * cdiv(d.W, TW);     // every kernel of this build uses 8x32 tiles; callers must still ask (it may change)
 }
 
+// Data gradient of a 1x1 head (reference: head_layer 1x1 C->3 + OutImg tanh, model_nerv.py:41,56-57): 3 -> C channels with the
+// tanh-grad prologue is 9*C FMAs per pixel against 6 loaded and C stored floats -- a streaming kernel, not a GEMM (the MFMA
+// path spends 29 us on it at 720x1280 where the 66 MB of traffic need ~13).  One thread = 4 consecutive pixels.
+namespace {
+constexpr int HEAD_KMAX = 4, HEAD_CMAX = 16;
+__global__ __launch_bounds__(256) void head1x1_dgrad_kernel(const bnerv_conv_desc d, const int hw4) {
+    __shared__ float s_w[HEAD_KMAX * HEAD_CMAX];
+    const int K = d.Cin, C = d.Cout;
+    if ((int)threadIdx.x < K * C) {                        // W(k, c): transposed weights are stored [k][c], direct ones [c][k]
+        const int k = threadIdx.x / C, c = threadIdx.x - k * C;
+        s_w[k * HEAD_CMAX + c] = d.transposed ? d.w[k * C + c] : d.w[c * K + k];
+    }
+    __syncthreads();
+    const int q = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (q >= hw4) return;
+    const size_t HW = (size_t)d.H * d.W;
+    f32x4 g[HEAD_KMAX];
+#pragma unroll
+    for (int k = 0; k < HEAD_KMAX; ++k) {
+        g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k < K) {
+            const size_t o = ((size_t)b * K + k) * HW + (size_t)q * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(d.x + o), a = *reinterpret_cast<const f32x4*>(d.aux0 + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[k][e] = xform1<BNERV_IN_TANHGRAD>(v[e], 0.f, 0.f, a[e]);
+        }
+    }
+    for (int c = 0; c < C; ++c) {
+        f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < HEAD_KMAX; ++k)
+            if (k < K) {
+                const float wv = s_w[k * HEAD_CMAX + c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = fmaf(g[k][e], wv, r[e]);
+            }
+        *reinterpret_cast<f32x4*>(d.out + ((size_t)b * C + c) * HW + (size_t)q * 4) = r;
+    }
+}
+}  // namespace
+
 extern "C" size_t bnerv_conv_splitk_ws_bytes(const bnerv_conv_desc* dp) {
     if (!dp || dp->B <= 0 || dp->Cin <= 0 || dp->Cout <= 0 || dp->H <= 0 || dp->W <= 0) return 0;
     const SplitPlan p = plan_split(*dp);
@@ -1718,6 +1759,13 @@ extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
         const SplitPlan p = plan_split(d);
         ka.ksplit = p.ksplit;
         ka.chunks_per_split = p.chunks_per_split;
+    }
+    if (d.k == 1 && d.in_mode == BNERV_IN_TANHGRAD && d.ep_mode == BNERV_EP_PLAIN && d.out_s == 1 && ka.vec && ka.ksplit == 1 &&
+        d.Cin <= HEAD_KMAX && d.Cout <= HEAD_CMAX && ((size_t)d.H * d.W) % 4 == 0 && d.B <= 65535) {
+        const int hw4 = (int)(((size_t)d.H * d.W) / 4);
+        hipLaunchKernelGGL(head1x1_dgrad_kernel, dim3(cdiv(hw4, 256), d.B), dim3(256), 0, st, d, hw4);
+        BNERV_LAUNCH_CHECK("head1x1_dgrad");
+        return BNERV_OK;
     }
     const int rc = d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);
     if (rc != BNERV_OK || ka.ksplit == 1) return rc;

@@ -178,9 +178,10 @@ def test_snerv_block(ops, case):
 
 
 @pytest.mark.parametrize("k", [1, 3])
-def test_head_tanh(ops, k):
+@pytest.mark.parametrize("hw", [(21, 45), (16, 64)])      # (16, 64): aligned rows -> the streaming 1x1 head data-gradient kernel
+def test_head_tanh(ops, k, hw):
     g = torch.Generator().manual_seed(13)
-    x = torch.randn(2, 12, 21, 45, generator=g).requires_grad_(True)
+    x = torch.randn(2, 12, hw[0], hw[1], generator=g).requires_grad_(True)
     w = (torch.randn(3, 12, k, k, generator=g) / math.sqrt(12 * k * k)).requires_grad_(True)
     b = torch.randn(3, generator=g).requires_grad_(True)
     ref = cpu_ref.out_img(F.conv2d(x, w, b, padding=(k - 1) // 2))
