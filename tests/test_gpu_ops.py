@@ -52,7 +52,7 @@ def test_pe_against_reference_golden(ops):
 
 
 # --------------------------------------------------------------------------------------------------------------- dense
-@pytest.mark.parametrize("B", [1, 3])
+@pytest.mark.parametrize("B", [1, 3, 144])      # 144: the token MLPs of E-NeRV take the library-GEMM route
 def test_dense_grouped_fwd_bwd(ops, B):
     g = torch.Generator().manual_seed(3)
     specs = [(160, 256, "sin"), (160, 64, "sin"), (32, 32, "relu"), (32, 12, "none"), (256, 1152, "sin"), (32, 95, "none")]
