@@ -762,7 +762,8 @@ int launch_wlean_modes(hipStream_t st, const WArgs& wa) {
 // the MFMA phase of the current one.  The column groups of one tile slot sit next to each other in the SAME XCD, so the gradient
 // tile they all re-read comes from that XCD's L2.  Shapes (MTW, NTW) are picked per layer to minimise the padded columns
 // (38 ch: 3x6 -> 4 groups of 96 for 343 columns; 46 ch: 3x7 -> 4 groups of 112 for 415), within the 256-VGPR budget.
-// GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient (two float4 per cout PAIR), 2 = tanh-grad (g, gaux)
+// GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient (two float4 per cout PAIR), 2 = tanh-grad (g, gaux),
+//      3 = pixel-shuffled by g_s (3, 5): one dword per pixel, g_s apart
 template <int IN, int GM2, int MTW, int NTW>
 __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kernel(const WArgs wa, const int slots, const SidePack side) {
     using G = Geo<3>;
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
     constexpr int NXSLOT = NPL * G::ROWS * G::SEGS;
     constexpr int NXS = (NXSLOT + 255) / 256;
     constexpr int NGS = (GM2 == 1) ? MTW * 2 : MTW * 4;                      // g slot k of wave w: cout row (pair) w + 4 k (wave-uniform)
-    constexpr bool GTWO = (GM2 != 0);
+    constexpr bool GTWO = (GM2 == 1 || GM2 == 2);
     constexpr bool AFF = (IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE);
     constexpr int AFFN = 32;                                                 // >= NPL
     static_assert(NPL <= AFFN, "affine table too small");
@@ -846,7 +847,9 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
     }
     // g slot k of this thread: cout row wave + 4 k, tile row (tid >> 3) & 7, segment tid & 7
     const int g_r = (tid >> 3) & 7, g_sg = tid & 7;
-    const unsigned voffg0 = GM2 == 1 ? (unsigned)((2 * g_r * 2 * W + 8 * g_sg) * 4) : (unsigned)((g_r * W + 4 * g_sg) * 4);
+    const int gs = d.g_s;                                                    // GM2 == 3: du[c][y*s + i][x*s + j], a stride-s gather along x
+    const unsigned voffg0 = GM2 == 1 ? (unsigned)((2 * g_r * 2 * W + 8 * g_sg) * 4)
+                          : GM2 == 3 ? (unsigned)((g_r * gs * W * gs + 4 * g_sg * gs) * 4) : (unsigned)((g_r * W + 4 * g_sg) * 4);
     const int loffg0 = ((GM2 == 1 ? 2 * wave : wave) * CSG + g_r * TW + 4 * g_sg) * 4;
     const unsigned hw4 = (unsigned)(H * W * 4);
     const unsigned shift = (unsigned)((G::PAD * W + G::XOFF) * 4);
@@ -867,6 +870,15 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
         lds_barrier();
     };
 
+    unsigned goff[GM2 == 3 ? NGS : 1];                                       // block constants: the (plane, i, j) part of each cout row's offset
+    if constexpr (GM2 == 3) {
+#pragma unroll
+        for (int k = 0; k < NGS; ++k) {
+            const int co = co_base + wave + 4 * k, s2 = gs * gs;
+            const int cf = co / s2, rem = co - cf * s2, i = rem / gs, j = rem - i * gs;
+            goff[k] = (unsigned)((((cf * gs * H) + i) * (gs * W) + j) * 4);
+        }
+    }
     f32x4 xa[NXS], ga[NGS], gb[GTWO ? NGS : 1];
     constexpr int NPART = NGS + NXS;
     struct Pre { unsigned sbx, sbg, vog; int ty0, tx0; bool interior; };
@@ -875,6 +887,7 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
         p.ty0 = a.ty * TH; p.tx0 = a.tx * TW;
         p.sbx = (unsigned)((((a.b * Cin + ci_lo) * H + p.ty0) * W + p.tx0) * 4);
         if constexpr (GM2 == 1) p.sbg = (unsigned)(((a.b * (Cout >> 2) * 2 * H + 2 * p.ty0) * 2 * W + 2 * p.tx0) * 4);   // + the pair's plane / row parity
+        else if constexpr (GM2 == 3) p.sbg = (unsigned)(((a.b * (Cout / (gs * gs)) * gs * H + gs * p.ty0) * gs * W + gs * p.tx0) * 4);   // + plane / (i, j)
         else p.sbg = (unsigned)((((a.b * Cout + co_base + wave) * H + p.ty0) * W + p.tx0) * 4);
         p.interior = p.ty0 >= G::PAD && p.ty0 + TH + G::PAD <= H && p.tx0 >= G::XOFF && p.tx0 + TW + G::XOFF <= W;
         p.vog = (p.ty0 + g_r < H && p.tx0 + 4 * g_sg < W) ? voffg0 : OOB;
@@ -889,6 +902,13 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
                     const unsigned so = p.sbg + (unsigned)(((cf * 2 * H + i) * 2 * W) * 4);
                     ga[k] = bload(rg, p.vog, so);
                     gb[k] = bload(rg, p.vog == OOB ? OOB : p.vog + 16u, so);
+                }
+            } else if constexpr (GM2 == 3) {
+                if (wave + 4 * k < g_rows) {               // wave-uniform: co = cf*s*s + i*s + j; 4 pixels = 4 dwords s apart
+                    const unsigned so = p.sbg + goff[k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        ga[k][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)(p.vog == OOB ? OOB : p.vog + (unsigned)(e * gs * 4)), (int)so, 0));
                 }
             } else if (wave + 4 * k < g_rows) {            // wave-uniform
                 ga[k] = bload(rg, p.vog, p.sbg + (unsigned)(4 * k) * hw4);
@@ -1067,7 +1087,8 @@ static WidePlan wide_plan(const bnerv_wgrad_desc& d) {
 static bool wide_ok(const WArgs& wa) {
     const bnerv_wgrad_desc& d = wa.d;
     static const bool off = getenv("BNERV_NO_WIDE") != nullptr;            // A/B switch for tools/kwide.py
-    if (off || !wa.vec || d.k != 3 || d.g_s > 2) return false;
+    if (off || !wa.vec || d.k != 3) return false;
+    if (d.g_s > 2 && (d.g_mode != BNERV_IN_UNSHUFFLE || d.in_mode != BNERV_IN_PLAIN || d.Cout % (d.g_s * d.g_s) != 0 || d.Cout <= 16)) return false;
     if (d.g_s == 2 && (d.g_mode != BNERV_IN_UNSHUFFLE || d.in_mode != BNERV_IN_PLAIN || d.Cout % 4 != 0 || d.Cout <= 16)) return false;
     if (d.in_mode != BNERV_IN_PLAIN && d.in_mode != BNERV_IN_AFFINE) return false;
     if (d.g_mode == BNERV_IN_TANHGRAD && (d.in_mode != BNERV_IN_PLAIN || d.Cout > 16)) return false;
@@ -1099,7 +1120,7 @@ int launch_wide(hipStream_t st, const WArgs& wa, const WidePlan& p) {
 
 template <int IN, int GM2>
 int launch_wide_shape(hipStream_t st, const WArgs& wa, const WidePlan& p) {
-    if constexpr (GM2 == 1) {                              // up-convs feeding PixelShuffle(2): Cout = 4 * channels, 32 and up here
+    if constexpr (GM2 == 1 || GM2 == 3) {                  // up-convs feeding PixelShuffle(2 / 3 / 5): Cout = s^2 * channels, 32 and up here
         if (p.mtw == 2) return p.ntw == 9 ? launch_wide<IN, GM2, 2, 9>(st, wa, p) : launch_wide<IN, GM2, 2, 7>(st, wa, p);
         if (p.mtw == 3) return p.ntw == 7 ? launch_wide<IN, GM2, 3, 7>(st, wa, p) : launch_wide<IN, GM2, 3, 6>(st, wa, p);
         if (p.mtw == 4) return launch_wide<IN, GM2, 4, 4>(st, wa, p);
@@ -1117,6 +1138,7 @@ int launch_wide_shape(hipStream_t st, const WArgs& wa, const WidePlan& p) {
 static int launch_wide_modes(hipStream_t st, const WArgs& wa, const WidePlan& p) {
     if (wa.d.g_mode == BNERV_IN_TANHGRAD) return launch_wide_shape<BNERV_IN_PLAIN, 2>(st, wa, p);
     if (wa.d.g_s == 2) return launch_wide_shape<BNERV_IN_PLAIN, 1>(st, wa, p);
+    if (wa.d.g_s > 2) return launch_wide_shape<BNERV_IN_PLAIN, 3>(st, wa, p);
     if (wa.d.in_mode == BNERV_IN_PLAIN) return launch_wide_shape<BNERV_IN_PLAIN, 0>(st, wa, p);
     return launch_wide_shape<BNERV_IN_AFFINE, 0>(st, wa, p);
 }

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = [  # (B, Cin, Cout, H, W)
     (1, 30, 30, 45, 80), (2, 38, 38, 9, 40), (3, 17, 20, 24, 36), (1, 95, 64, 18, 32), (2, 13, 5, 19, 44),
     (2, 20, 32, 24, 36), (1, 20, 80, 24, 36), (1, 46, 152, 540, 960), (1, 55, 184, 270, 480), (1, 12, 48, 360, 640),
+    (2, 20, 36, 24, 36), (1, 30, 75, 9, 16), (1, 177, 792, 45, 80), (1, 30, 750, 9, 16), (1, 79, 594, 45, 80),
     (1, 38, 38, 1080, 1920), (1, 46, 46, 540, 960), (1, 55, 55, 270, 480), (1, 22, 22, 540, 960), (1, 44, 44, 270, 480), (1, 38, 3, 1080, 1920),
 ]
 
@@ -33,6 +34,11 @@ def leg(path):
             g2 = rnd(B, Co // 4, 2 * H, 2 * W)
             modes = dict(modes)
             modes["pair"] = lambda dw, db, g2=g2: ops._wgrad(x, g2, dw, db, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=2, **kw)
+        for sf in (3, 5):
+            if Co % (sf * sf) == 0 and Co > 16:
+                gs_ = rnd(B, Co // (sf * sf), sf * H, sf * W)
+                modes = dict(modes)
+                modes[f"ps{sf}"] = lambda dw, db, gs_=gs_, sf=sf: ops._wgrad(x, gs_, dw, db, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=sf, **kw)
         if Co <= 16:
             modes["tanhgrad"] = lambda dw, db: ops._wgrad(x, gr, dw, db, in_mode=L.IN_PLAIN, g_mode=L.IN_TANHGRAD, gaux=gaux, **kw)
         for name, fn in modes.items():
