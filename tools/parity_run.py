@@ -2,7 +2,8 @@
 on the synthetic Bunny-shaped clip twice -- through the HIP path (TrainStep, hipGraph) and through the oracle restatement
 (oracle/cpu_ref.py, plain torch ops executed by stock PyTorch-ROCm on the same GPU) -- with the same initial weights, frame
 order and learning rates, then evaluate every frame with both models.  Prints the end PSNR of both and their difference.
-usage: python tools/parity_run.py [epochs] [n_frames]          (checker tool: imports the oracle, not part of the product)"""
+usage: python tools/parity_run.py [epochs] [n_frames] [seed] [c1|c3|c4]     (checker tool: imports the oracle, not part of the product)
+For c3 / c4 (1080x1920, 600-frame recipes) pass a small n_frames: the oracle on stock ops runs at 1-3 frames/s there."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -13,15 +14,19 @@ from boosting_nerv_amd.optimizer import Adan
 from boosting_nerv_amd.synth import SyntheticVideo
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 132
+CFG = sys.argv[4] if len(sys.argv) > 4 else "c1"
+RC = bench.RECIPES[CFG]
+NT, FH, FW = RC["n"], RC["h"], RC["w"]
+N = int(sys.argv[2]) if len(sys.argv) > 2 else NT
 dev = torch.device("cuda:0")
 torch.backends.cudnn.benchmark = False
-args, model = bench.build("c1")
+args, model = bench.build(CFG)
 torch.backends.cudnn.benchmark = False
 sd0 = {k: v.clone() for k, v in model.state_dict().items()}
-vid = SyntheticVideo(132, 720, 1280)
+vid = SyntheticVideo(NT, FH, FW)
 frames = torch.stack([vid.frame(i, device=dev) for i in range(N)])
-norm = torch.tensor([(i + 1) / 132 for i in range(N)], dtype=torch.float64, device=dev)
+norm = torch.tensor([(i + 1) / NT for i in range(N)], dtype=torch.float64, device=dev)
+TAKES_IMG = args.model == "HNeRV_Boost"
 g = torch.Generator().manual_seed(int(sys.argv[3]) if len(sys.argv) > 3 else 123)
 order = [int(i) for e in range(E) for i in torch.randperm(N, generator=g)]
 lrs = [args.lr * cpu_ref.lr_mult(((s // N) + (s % N) / N) / E) for s in range(len(order))]
@@ -29,7 +34,7 @@ lrs = [args.lr * cpu_ref.lr_mult(((s // N) + (s % N) / N) / E) for s in range(le
 # ---- HIP path
 model = model.to(dev)
 opt = Adan(model.parameters(), lr=lrs[0])
-step = TrainStep(model, opt, args.loss, False, (1, 3, 720, 1280), dev, use_graph=True, warmup_eager=3)
+step = TrainStep(model, opt, args.loss, TAKES_IMG, (1, 3, FH, FW), dev, use_graph=True, warmup_eager=3)
 t0 = time.time()
 tr_hip = []
 for s, fi in enumerate(order):
@@ -41,7 +46,7 @@ torch.cuda.synchronize()
 t_hip = time.time() - t0
 model.eval()
 with torch.no_grad():
-    p_hip = torch.stack([hu.psnr_fn_device(model(norm[i:i + 1], norm_idx=norm[i:i + 1])[0], frames[i:i + 1]) for i in range(N)]).mean().item()
+    p_hip = torch.stack([hu.psnr_fn_device(model(frames[i:i + 1] if TAKES_IMG else norm[i:i + 1], norm_idx=norm[i:i + 1])[0], frames[i:i + 1]) for i in range(N)]).mean().item()
 
 # ---- oracle restatement on stock PyTorch-ROCm ops
 sd = {k: v.clone().float().to(dev).requires_grad_(True) for k, v in sd0.items()}
@@ -50,13 +55,15 @@ t0 = time.time()
 tr_ref = []
 for s, fi in enumerate(order):
     adan.lr = lrs[s]
-    _, ps, _ = cpu_ref.train_step("NeRV_Boost", sd, adan, frames[fi:fi + 1], norm[fi:fi + 1], args.loss)
+    _, ps, _ = cpu_ref.train_step(args.model, sd, adan, frames[fi:fi + 1], norm[fi:fi + 1], args.loss)
     tr_ref.append(ps.clone())
 torch.cuda.synchronize()
 t_ref = time.time() - t0
 with torch.no_grad():
-    p_ref = torch.stack([cpu_ref.psnr_fn_single(cpu_ref.nerv_boost_forward(sd, norm[i:i + 1]), frames[i:i + 1]) for i in range(N)]).mean().item()
-print(f"epochs {E}, frames {N}, steps {len(order)}")
+    FWD = {"NeRV_Boost": lambda i: cpu_ref.nerv_boost_forward(sd, norm[i:i + 1]), "ENeRV_Boost": lambda i: cpu_ref.enerv_boost_forward(sd, norm[i:i + 1]),
+           "HNeRV_Boost": lambda i: cpu_ref.hnerv_boost_forward(sd, frames[i:i + 1], norm[i:i + 1])}[args.model]
+    p_ref = torch.stack([cpu_ref.psnr_fn_single(FWD(i), frames[i:i + 1]) for i in range(N)]).mean().item()
+print(f"config {CFG}: epochs {E}, frames {N}, steps {len(order)}")
 print(f"HIP path      : end PSNR {p_hip:.4f} dB   train {t_hip:.1f} s ({len(order) / t_hip:.1f} frames/s)")
 print(f"oracle on GPU : end PSNR {p_ref:.4f} dB   train {t_ref:.1f} s ({len(order) / t_ref:.1f} frames/s)")
 print(f"difference    : {p_hip - p_ref:+.4f} dB")
