@@ -412,6 +412,41 @@ def test_sincos_epilogue_accuracy(ops):
         assert es < 3e-7 and ec < 3e-7, (span, es, ec)
 
 
+def test_direct_epilogue_stores_are_stable_under_load(ops):
+    """The kernels that store straight from the accumulators (conv_lean / conv_lean2) follow every 128-bit buffer store with wait
+    states (store-data hazard on gfx950).  Timing-dependent corruption would show up as launch-to-launch differences:
+    every epilogue family is launched repeatedly, back to back with a bandwidth-heavy copy on a second stream, and each result
+    must equal the first bit for bit and agree with the float64 reference."""
+    from boosting_nerv_amd import _lib as L
+    g = torch.Generator().manual_seed(21)
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, device=DEV)
+    for (C, H, W) in ((12, 180, 320), (38, 72, 128)):
+        x = torch.randn(1, C, H, W, generator=g).to(DEV)
+        w = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).to(DEV)
+        b = torch.randn(C, generator=g).to(DEV)
+        sc, sh = (torch.randn(1, C, generator=g) * 0.3).to(DEV), (torch.randn(1, C, generator=g) * 0.3).to(DEV)
+        a0 = torch.randn(1, C, H, W, generator=g).to(DEV)
+        pre = F.conv2d((x * (1 + sc[:, :, None, None]) + sh[:, :, None, None]).double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+        pre_plain = F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+        refs = {"gelu": (F.gelu(pre), None), "res": (pre + a0.double().cpu(), None), "sin": (torch.sin(pre_plain), torch.cos(pre_plain))}
+        kw = dict(B=1, Cin=C, Cout=C, H=H, W=W, k=3)
+        aff = dict(in_mode=L.IN_AFFINE, scale=sc, shift=sh)
+        for name, ep, extra in (("gelu", L.EP_BIAS_GELU, aff), ("res", L.EP_BIAS_RES, dict(aux0=a0, **aff)), ("sin", L.EP_BIAS_SIN, dict(in_mode=L.IN_PLAIN))):
+            first = None
+            for it in range(40):
+                o, o2 = torch.empty_like(x), torch.empty_like(x)
+                with torch.cuda.stream(side):
+                    big.add_(1.0)
+                ops._conv(x, w, b, o, ep_mode=ep, out2=None if name == "res" else o2, **extra, **kw)
+                if first is None:
+                    first = (o.clone(), o2.clone())
+                    close(o, refs[name][0].float(), msg=f"{name} C={C}")
+                else:
+                    assert torch.equal(o, first[0]) and (name == "res" or torch.equal(o2, first[1])), (name, C, it)
+    torch.cuda.synchronize()
+
+
 def test_gelu_pair_epilogue_accuracy(ops):
     """gelu(v) and gelu'(v) of the TAT conv0 epilogue (common.h gelu_pair_f: one v_exp_f32, one v_rcp_f32, A-S 7.1.26 erf), read
     back through an identity 3x3 conv with a unit affine prologue: against float64 on small, moderate and tail arguments."""
