@@ -206,7 +206,7 @@ def main():
     args.epochs = 300
     n_iter = len(keep)
 
-    if a.config == "c5":                                       # compression step (train_nerv_compression.py:354-367), eager
+    if a.config == "c5":                                       # compression step (train_nerv_compression.py:354-367)
         from boosting_nerv_amd import ops
         from boosting_nerv_amd.hnerv_utils import loss_fn
         from boosting_nerv_amd.lib.entropy_model import DiffEntropyModel
@@ -216,20 +216,9 @@ def main():
         final_size, n_full = r["h"] * r["w"], r["n"]
         target_bpp = args.target_bit * (sum(p.numel() for p in model.parameters()) / 1e6) * 1e6 / final_size / n_full
 
-        class _CemStep:
-            loss_out = psnr_out = None
-
-            def __call__(self, img, nidx):
-                model.cal_params(em)
-                img_out, _, _ = model(img, entropy_model=em, norm_idx=nidx)
-                bpp = (model.get_bitrate_sum(name="bitrate") + model.bitrate_e_dict["bitrate"] * n_full) / final_size
-                out_loss = loss_fn(img_out, img, args.loss)
-                final = out_loss + (bpp.detach() / n_full > target_bpp).to(out_loss.dtype) * args.lambda_rate * bpp
-                opt.zero_grad()
-                final.backward()
-                opt.step()
-                self.loss_out, self.psnr_out = final.detach(), ops.psnr(img_out.detach(), img)
-        step = _CemStep()
+        from boosting_nerv_amd.engine import CompressionStep
+        args.final_size, args.full_data_length, args.target_bpp = final_size, n_full, target_bpp
+        step = CompressionStep(model, opt, em, args, (per_gpu_batch, 3, r["h"], r["w"]), dev, use_graph=not a.no_graph, warmup_eager=3)
 
     def run(k0, k):
         for s in range(k0, k0 + k):
@@ -262,7 +251,7 @@ def main():
                                       f"{'quantise + rate term (CEM) + ' if a.config == 'c5' else ''}decoder fwd + {args.loss} + bwd + "
                                       f"{'flat-bucket RCCL all-reduce + ' if world > 1 else ''}fused Adan; frames resident in HBM",
                           "baseline_config": {"c1": "configs[1]", "c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]"}[a.config], "global_batch": per_gpu_batch * world,
-                          "per_gpu_batch": per_gpu_batch, "parallelism": f"dp{world}", "hipgraph": (not a.no_graph) and a.config != "c5",
+                          "per_gpu_batch": per_gpu_batch, "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
                           "last_loss": round(loss, 4), "last_train_psnr_db": round(psnr, 3)}}
         out["roofline"] = dominant_kernel_roofline(dev) if a.config == "c1" else None
         if world == 1 and not a.no_cpu_baseline:

@@ -104,6 +104,52 @@ class TrainStep:
         return self.loss_out, self.psnr_out
 
 
+class CompressionStep(TrainStep):
+    """The rate-distortion step of train_nerv_compression.py:354-367 (quantise + rate term over all tensors -> forward with the
+    embedding's rate -> loss + lambda * bpp while bpp / N exceeds the target -> backward -> Adan) as ONE captured graph.  The
+    `bpp > target` decision is a device-side gate and the training noise comes from the capture-aware default generator, so
+    nothing in the step needs the host.  Single GPU; returns (final_loss, psnr[B]); `bpp_out` holds bits per pixel (x N)."""
+
+    def __init__(self, model, optimizer, entropy_model, args, batch_shape, device, use_graph=True, warmup_eager=3):
+        super().__init__(model, optimizer, args.loss, "HNeRV_Boost" in args.model or 'pe' not in args.embed, batch_shape, device,
+                         use_graph=use_graph, warmup_eager=warmup_eager, clip_max_norm=getattr(args, "clip_max_norm", 0.0))
+        self.entropy_model, self.cargs = entropy_model, args
+        self.bpp_out = None
+
+    def _fwd_bwd(self):
+        a, m = self.cargs, self.model
+        self.opt.zero_grad(set_to_none=True)
+        m.cal_params(self.entropy_model)
+        inp = self.static_img if self.takes_image else self.static_idx
+        if a.embed_entropy:
+            img_out, _, _ = m(inp, entropy_model=self.entropy_model, norm_idx=self.static_idx)
+            bpp = (m.get_bitrate_sum(name="bitrate") + m.bitrate_e_dict["bitrate"] * a.full_data_length) / a.final_size
+        else:
+            img_out, _, _ = m(inp, norm_idx=self.static_idx)
+            bpp = m.get_bitrate_sum(name="bitrate") / a.final_size
+        out_loss = hu.loss_fn(img_out, self.static_img, self.loss_type)
+        gate = (bpp.detach() / a.full_data_length > a.target_bpp).to(out_loss.dtype)     # `if bpp / N > target_bpp` (:363) on the device
+        final_loss = out_loss + gate * a.lambda_rate * bpp
+        final_loss.backward()
+        self.loss_out = final_loss.detach()
+        self.bpp_out = bpp.detach()
+        self.psnr_out = ops.psnr(img_out.detach(), self.static_img)
+
+    def _capture(self):
+        # The model's rate dictionaries and dequantised tensors still reference the autograd graph of the last eager step; that
+        # keeps its AccumulateGrad nodes (created on the default stream) alive, the capture would reuse them and pull the
+        # default stream into the capture (hipStreamEndCapture crashes on it).  Detach every such reference first.
+        for mod in self.model.modules():
+            for k, v in list(vars(mod).items()):
+                if torch.is_tensor(v) and v.grad_fn is not None:
+                    setattr(mod, k, v.detach())
+                elif isinstance(v, dict) and not k.startswith("_"):
+                    for kk, vv in list(v.items()):
+                        if torch.is_tensor(vv) and vv.grad_fn is not None:
+                            v[kk] = vv.detach()
+        super()._capture()
+
+
 class DecodeGraph:
     """Forward-only decode of one batch as a captured hipGraph (row N4: the rate evaluate() logs as "FPS" under --eval_fps,
     train_nerv_all.py:492-496 of the reference, is ~35 Python-driven launches per frame when run eagerly).  The graph replays

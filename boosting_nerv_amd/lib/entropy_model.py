@@ -61,7 +61,9 @@ class DiffEntropyModel:
 
     def get_bits(self, x, mu, sigma):
         sigma = sigma.clamp(1e-5, 1e10)
-        gaussian = torch.distributions.normal.Normal(mu, sigma)
+        # validate_args=False: the default argument check reads a device flag on the host every call (a sync per step, and not
+        # capturable in a graph); sigma is clamped positive just above, so the check cannot fail
+        gaussian = torch.distributions.normal.Normal(mu, sigma, validate_args=False)
         probs = gaussian.cdf(x + 0.5) - gaussian.cdf(x - 0.5)
         bits = -1.0 * torch.log(probs + 1e-5) / math.log(2.0)
         return LowerBound.apply(bits, 0)

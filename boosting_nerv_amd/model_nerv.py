@@ -46,6 +46,7 @@ class _CEMHooks:
                     noises[i] = flat[off:off + t.numel()]
                     off += t.numel()
         bits, stats, deqs = ops.cem_scale_rate([t for _, _, t, _ in items], [q.scale for _, _, _, q in items], noises, training)
+        self._fused_bits_total = bits.sum()                    # get_bitrate_sum("bitrate") of this step as ONE reduction (not ~400 adds)
         for i, (m, is_bias, t, _) in enumerate(items):
             d = {"bitrate": bits[i], "mean": stats[i, 1], "std": stats[i, 2], "real_bitrate": 0}
             if is_bias:
@@ -57,6 +58,7 @@ class _CEMHooks:
         return True
 
     def cal_params(self, entropy_model=None):
+        self._fused_bits_total = None
         if self.training and getattr(self, "cem_fused", True) and self._cal_params_fused(entropy_model):
             return
         for m in self._quant_modules():
@@ -71,6 +73,8 @@ class _CEMHooks:
                     m.bitrate_b_dict.update(entropy_model.cal_bitrate(code_b, quant_b, self.training))
 
     def get_bitrate_sum(self, name="bitrate"):
+        if name == "bitrate" and getattr(self, "_fused_bits_total", None) is not None:
+            return self._fused_bits_total
         total = 0
         for m in self._quant_modules():
             total = total + m.bitrate_w_dict[name]

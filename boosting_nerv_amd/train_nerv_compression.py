@@ -167,6 +167,11 @@ def train(local_rank, args):
     psnr_list, time_list = [], []
     results_list = [torch.zeros(1) for _ in args.metric_names]
     model.init_data()                                                  # :338
+    cstep = None
+    if device.type == 'cuda' and not getattr(args, 'no_graph', False) and args.clip_max_norm <= 0 and hasattr(optimizer, 'prepare_step'):
+        from .engine import CompressionStep
+        h_, w_ = [int(v) for v in args.crop_list.split('_')[:2]]
+        cstep = CompressionStep(model, optimizer, entropy_model, args, (args.batchSize, 3, h_, w_), device)
     for epoch in range(args.start_epoch, args.epochs):
         model.train()
         epoch_start_time = datetime.now()
@@ -181,6 +186,21 @@ def train(local_rank, args):
             cur_input = img_data if takes_image else norm_idx
             cur_epoch = (epoch + float(i) / n_iter) / args.epochs
             lr = adjust_lr(optimizer, cur_epoch, i, args)
+            if cstep is not None and inpaint_mask is None and img_gt is img_data:
+                # the whole step as one captured graph (engine.CompressionStep; --no_graph keeps the eager sequence below)
+                final_loss, psnr_b = cstep(img_data, norm_idx)
+                bpp = cstep.bpp_out
+                psnr_sum += psnr_b.sum()
+                psnr_cnt += psnr_b.numel()
+                if i % args.print_freq == 0 or i == n_iter - 1:
+                    print_str = '[{}] Rank:{}, Epoch[{}/{}], Step [{}/{}], lr:{:.2e} pred_PSNR: {}, loss:{}, bpp:{}'.format(
+                        datetime.now().strftime("%Y/%m/%d %H:%M:%S"), local_rank, epoch + 1, args.epochs, i + 1, n_iter, lr,
+                        RoundTensor((psnr_sum / psnr_cnt).cpu(), 2), RoundTensor(final_loss.detach().cpu(), 4),
+                        RoundTensor((bpp.detach() / args.full_data_length).cpu(), 6))
+                    print(print_str, flush=True)
+                    with open('{}/rank0.txt'.format(args.outf), 'a') as f:
+                        f.write(print_str + '\n')
+                continue
             model.cal_params(entropy_model)
             if args.embed_entropy:
                 img_out, _, _ = model(cur_input, entropy_model=entropy_model, norm_idx=norm_idx)
