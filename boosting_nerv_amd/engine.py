@@ -28,6 +28,7 @@ class TrainStep:
         self.warmup_eager = warmup_eager
         self.n_calls = 0
         self.graph_a = self.graph_b = None
+        self._opt_epoch = getattr(optimizer, "state_epoch", 0)
         self.loss_out = self.psnr_out = None
         self.world = world_size
         # force_bucket: run the multi-GPU code path (bucket gather -> RCCL all-reduce -> scatter, two graphs) on a 1-rank
@@ -58,6 +59,7 @@ class TrainStep:
 
     def _capture(self):
         torch.cuda.synchronize()
+        self._opt_epoch = getattr(self.opt, "state_epoch", 0)
         pool = torch.cuda.graph_pool_handle()
         self.graph_a = torch.cuda.CUDAGraph()
         if self.bucket is None:
@@ -87,6 +89,8 @@ class TrainStep:
         overwritten by the next call."""
         self.static_img.copy_(img, non_blocking=True)
         self.static_idx.copy_(norm_idx, non_blocking=True)
+        if self.graph_a is not None and getattr(self.opt, "state_epoch", 0) != self._opt_epoch:
+            self.graph_a = self.graph_b = None      # optimizer state tensors were replaced (restart_opt / load_state_dict): re-capture
         if not self.use_graph or self.n_calls < self.warmup_eager:
             self._eager()
         else:

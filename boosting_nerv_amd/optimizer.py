@@ -34,12 +34,25 @@ class Adan(Optimizer):
                         foreach=foreach, fused=fused)
         super().__init__(params, defaults)
         self._sched = {}          # group index -> (pinned host [5], device [5])
-        self._chunk_cache = {}    # group index -> (key, [AdanChunk])
+        self._chunk_cache = {}    # group index -> (key, [AdanChunk], tensors the chunks point into)
+        self.state_epoch = 0      # bumped whenever state tensors are replaced: a captured step (engine.TrainStep) re-captures
+
+    def _invalidate(self):
+        """The descriptors of launch_step() hold raw device pointers into the state tensors; whoever replaces those tensors
+        (restart_opt, load_state_dict, unpickling) must drop the descriptors, and a captured graph of the step with them."""
+        self._chunk_cache = {}
+        self.state_epoch = getattr(self, "state_epoch", 0) + 1
 
     def __setstate__(self, state):
         super().__setstate__(state)
         for group in self.param_groups:
             group.setdefault("no_prox", False)
+        self.__dict__.setdefault("_sched", {})
+        self._invalidate()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._invalidate()
 
     @torch.no_grad()
     def restart_opt(self):
@@ -51,6 +64,7 @@ class Adan(Optimizer):
                     state["exp_avg"] = torch.zeros_like(p)
                     state["exp_avg_sq"] = torch.zeros_like(p)
                     state["exp_avg_diff"] = torch.zeros_like(p)
+        self._invalidate()
 
     # ------------------------------------------------------------------------------------------------------------------
     def _clip_coef(self):
@@ -115,24 +129,30 @@ class Adan(Optimizer):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
-            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+            # the key covers every pointer a descriptor holds (parameter, gradient and the four state tensors), and the cache
+            # entry keeps the state tensors alive, so a descriptor can never point at freed memory
+            sts = [self._ensure_state(p, group.get("step", 1), clip) for p in ps]
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                         st["exp_avg_diff"].data_ptr(), st["neg_pre_grad"].data_ptr()) for p, st in zip(ps, sts))
             cached = self._chunk_cache.get(gi)
             if cached is None or cached[0] != key:
                 chunks = []
+                # (not p.grad: it is alive whenever the step launches, and pinning it would move the next eager gradient elsewhere)
+                keep = [(p, st["exp_avg"], st["exp_avg_sq"], st["exp_avg_diff"], st["neg_pre_grad"]) for p, st in zip(ps, sts)]
                 for i0 in range(0, len(ps), L.ADAN_MAX_TENSORS):
                     ck = L.AdanChunk()
                     sub = ps[i0:i0 + L.ADAN_MAX_TENSORS]
                     for j, p in enumerate(sub):
                         if not (p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32 and p.grad.dtype == torch.float32):
                             raise L.BnervError("fused Adan needs contiguous fp32 parameters and gradients")
-                        st = self._ensure_state(p, group.get("step", 1), clip)
+                        st = sts[i0 + j]
                         ck.p[j], ck.g[j] = p.data_ptr(), p.grad.data_ptr()
                         ck.exp_avg[j], ck.exp_avg_sq[j] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                         ck.exp_avg_diff[j], ck.neg_pre_grad[j] = st["exp_avg_diff"].data_ptr(), st["neg_pre_grad"].data_ptr()
                         ck.n[j] = p.numel()
                     ck.n_tensors = len(sub)
                     chunks.append(ck)
-                self._chunk_cache[gi] = (key, chunks)
+                self._chunk_cache[gi] = (key, chunks, keep)
             else:
                 chunks = cached[1]
             beta1, beta2, beta3 = group["betas"]

@@ -125,35 +125,67 @@ def test_decode_graph_equals_eager_decode(name, cfg):
 
 
 @pytest.mark.parametrize("name,cfg", [("c3", configs.c3), ("c4", configs.c4)])
-def test_big_models_init_and_step_run(name, cfg):
-    """C3 (HNeRV-boost 3M) and C4 (E-NeRV-boost 3M) at 1080x1920: seeded init hash equals the reference's; one full train
-    step runs and produces finite values (the per-block arithmetic is covered by the block/tiny-model parity tests)."""
+def test_big_models_full_size_against_reference_golden(name, cfg):
+    """BASELINE configs C3 (HNeRV-boost 3M incl. its ConvNeXt encoder, model_hnerv.py:224-251) and C4 (E-NeRV-boost 3M,
+    model_enerv.py:279-317) at 1080x1920 against the reference's own CPU run (oracle/make_goldens.py gen_full_1080): seeded init
+    identical (SHA-256), image and every returned stage output on 2048 / 256 sampled positions + means, L1_freq loss, PSNR
+    inside the +-0.02 dB bar, and the gradient norm of EVERY parameter -- then one Fusion10_freq Adan step stays finite."""
     import hashlib
     from boosting_nerv_amd import hnerv_utils as hu
     from boosting_nerv_amd.optimizer import Adan
-    npz = load_golden("full_models.npz")
+    shapes = load_golden("full_models.npz")
+    npz = load_golden(f"full_{name}.npz")
     args = cfg()
     torch.manual_seed(1)
     model = _build(name, args)
     sd = model.state_dict()
-    assert list(sd.keys()) == list(npz[f"{name}/keys"]) and [",".join(map(str, v.shape)) for v in sd.values()] == list(npz[f"{name}/shapes"])
-    assert sum(p.numel() for p in model.parameters()) == int(npz[f"{name}/n_params"])
-    if name != "c3":     # c3's ConvNeXt init (trunc_normal_/erfinv) is not bit-stable across host CPUs; c4 is
+    assert list(sd.keys()) == list(shapes[f"{name}/keys"]) and [",".join(map(str, v.shape)) for v in sd.values()] == list(shapes[f"{name}/shapes"])
+    assert sum(p.numel() for p in model.parameters()) == int(shapes[f"{name}/n_params"])
+
+    def sha(items):
         h = hashlib.sha256()
-        for k, v in sd.items():
+        for k, v in items:
             h.update(k.encode())
             h.update(v.numpy().tobytes())
-        assert h.hexdigest() == str(npz[f"{name}/sd_sha256"])
+        return h.hexdigest()
+    if name == "c3":
+        # the ConvNeXt encoder initialises through trunc_normal_ (erfinv): last bit depends on the host CPU's vector ISA, so
+        # the reference's seeded encoder values travel in the fixture; the decoder's seeded init is bit-identical
+        assert sha((k, v) for k, v in sd.items() if not k.startswith("encoder.")) == str(npz["dec_sha256"])
+        enc = group(npz, "enc_sd/")
+        for k, v in enc.items():
+            torch.testing.assert_close(sd[k], v, rtol=0, atol=1e-6, msg=k)
+        model.load_state_dict({**sd, **enc})
     else:
-        first = next(iter(sd.values())).flatten()[:8]
-        torch.testing.assert_close(first, torch.from_numpy(npz["c3/first_vals"]), rtol=0, atol=1e-6)
+        assert sha(sd.items()) == str(npz["sd_sha256"])
     model = model.to(DEV)
-    opt = Adan(model.parameters(), lr=1e-3)
-    frame = torch.rand(1, 3, 1080, 1920, generator=torch.Generator().manual_seed(5)).to(DEV)
-    norm_idx = torch.tensor([37 / 600], dtype=torch.float64, device=DEV)
+    frame = torch.rand(1, 3, 1080, 1920, generator=torch.Generator().manual_seed(int(npz["frame_seed"]))).to(DEV)
+    norm_idx = torch.from_numpy(npz["norm_idx"]).to(DEV)
     inp = frame if args.model == "HNeRV_Boost" else norm_idx
-    img, _, _ = model(inp, norm_idx=norm_idx)
+    img, lst, _ = model(inp, norm_idx=norm_idx)
     assert img.shape == (1, 3, 1080, 1920)
+    check_summary(img, npz, "img", 1e-3, 1e-5)
+    for i, t in enumerate(lst):
+        check_summary(t, npz, f"list{i}", 1e-3, 2e-5)
+    loss = hu.loss_fn(img, frame, "L1_freq")
+    gold = float(npz["loss_L1_freq"])
+    assert abs(loss.item() - gold) < 3e-4 * abs(gold), (loss.item(), gold)
+    assert abs(hu.psnr_fn_single(img, frame).item() - float(npz["psnr"][0])) < 0.02     # the +-0.02 dB bar
+    loss.backward()
+    for k, p in model.named_parameters():
+        gn = float(npz[f"gnorm/{k}"])
+        if gn < 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        got = p.grad.double().norm().item()
+        assert abs(got - gn) <= 5e-3 * gn + 1e-6, (k, got, gn)
+        if f"grad/{k}" in npz.files:
+            ref = torch.from_numpy(npz[f"grad/{k}"])
+            err = (p.grad.cpu() - ref).abs().max().item()
+            assert err <= 5e-3 * max(gn, float(ref.abs().max())) + 1e-6, (k, err, gn)
+    # and the recipe's own loss through the fused optimizer: finite everywhere
+    opt = Adan(model.parameters(), lr=1e-3)
+    img, _, _ = model(inp, norm_idx=norm_idx)
     loss = hu.loss_fn(img, frame, "Fusion10_freq")
     opt.zero_grad()
     loss.backward()

@@ -91,6 +91,10 @@ CONV_CASES = [  # B, Cin, Cout_total, H, W, k, s
     (1, 12, 12, 16, 64, 3, 1), (2, 12, 48, 9, 33, 3, 2), (1, 15, 48, 11, 40, 3, 2), (2, 30, 750, 9, 16, 3, 5),
     (1, 9, 63, 5, 6, 3, 3), (2, 20, 132, 6, 9, 1, 2), (1, 95, 100, 9, 16, 1, 5), (1, 55, 55, 17, 35, 3, 1),
     (1, 3, 3, 1, 1, 3, 1), (1, 70, 18, 8, 32, 3, 1),
+    # aligned rows (W % 4 == 0) with more than 16 total output channels: the wide weight-gradient kernels with the PixelShuffle
+    # 3 / 5 / 2 gather (the paths C3's 79->594 and C4's 177->792 up-convs take) and the stride-1 wide kernels
+    (1, 20, 180, 24, 36, 3, 3), (1, 24, 400, 9, 16, 3, 5), (1, 40, 160, 16, 32, 3, 2), (1, 38, 38, 24, 64, 3, 1),
+    (2, 79, 594, 9, 16, 3, 3),
 ]
 
 
@@ -158,7 +162,8 @@ def test_tat_block(ops, shape):
         close(a, r, msg=f"tat d{n}")
 
 
-@pytest.mark.parametrize("case", [(1, 12, 12, 16, 64, 3, 1), (2, 12, 12, 9, 33, 3, 2), (1, 30, 15, 9, 16, 3, 5), (1, 20, 33, 6, 9, 1, 2), (1, 9, 7, 5, 6, 3, 3)])
+@pytest.mark.parametrize("case", [(1, 12, 12, 16, 64, 3, 1), (2, 12, 12, 9, 33, 3, 2), (1, 30, 15, 9, 16, 3, 5), (1, 20, 33, 6, 9, 1, 2), (1, 9, 7, 5, 6, 3, 3),
+                                  (1, 20, 20, 24, 36, 3, 3), (1, 40, 38, 16, 32, 3, 2)])
 def test_snerv_block(ops, case):
     B, Cin, Cc, H, W, k, s = case
     x0, mods, w0, b0, w1, b1, g = _tat_inputs(B, Cc, H * s, W * s, seed=11)
