@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbnerv_hip.so")
+LIB_PATH = os.environ.get("BNERV_LIB") or os.path.join(_HERE, "libbnerv_hip.so")     # BNERV_LIB: another build of the same ABI (debug / trace variants)
 
 MAX_DENSE_GROUPS = 40
 ADAN_MAX_TENSORS = 48

@@ -21,6 +21,8 @@
 #include "common.h"
 #include "sidejob.h"
 
+int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec);   // convbf.hip
+
 namespace {
 
 constexpr int TH = 8, TW = 32;     // spatial tile
@@ -1766,6 +1768,10 @@ extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
         hipLaunchKernelGGL(head1x1_dgrad_kernel, dim3(cdiv(hw4, 256), d.B), dim3(256), 0, st, d, hw4);
         BNERV_LAUNCH_CHECK("head1x1_dgrad");
         return BNERV_OK;
+    }
+    if (ka.ksplit == 1) {                                  // split-bf16 kernels (convbf.hip) take the 12..16-channel stride-1 layers
+        const int rb = bnerv_convbf_try(st, d, ka.vec);
+        if (rb != -1) return rb;
     }
     const int rc = d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);
     if (rc != BNERV_OK || ka.ksplit == 1) return rc;

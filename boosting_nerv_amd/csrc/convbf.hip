@@ -1,0 +1,680 @@
+// convbf.hip -- split-bf16 implicit-GEMM convolution for the high-resolution 12..16-channel layers (gfx950).
+//
+// Forward convolution and data gradient of the stride-1 3x3 / 1x1 convs with 8 < Cin <= 16 and Cout <= 16 (every TAT conv, the
+// stride-1 block convs, heads and their data gradients of the NeRV-boost decoders at >= 180x320; reference call sites as in
+// conv.hip: lib/quant_ops.py:39-41 via model_blocks.py:74-89, :196-220).  Same GEMM view, work-item walk, buffer-load staging and
+// accumulator-direct epilogues as conv.hip's lean kernel; the contraction runs on the bf16 matrix pipe with f32 operands
+// split into bf16 pieces (see below), f32 accumulation.
+#include "common.h"
+#include "sidejob.h"
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int TH = 8, TW = 32;     // spatial tile (as conv.hip)
+
+template <int KS> struct Geo {
+    static constexpr int PAD = (KS - 1) / 2;
+    static constexpr int ROWS = TH + 2 * PAD;
+    static constexpr int XOFF = (KS == 3) ? 4 : 0;             // left margin, multiple of 4 -> aligned float4 segments
+    static constexpr int RS = TW + 2 * XOFF;                   // 40 / 32
+    static constexpr int SEGS = RS / 4;
+    static constexpr int T = KS * KS;
+    static constexpr int COL0 = XOFF - PAD;                    // planar column of input x = x0 + px + kx - PAD is px + kx + COL0
+};
+
+struct KArgs {
+    bnerv_conv_desc d;
+    int tiles_x, tiles_y, total_items;
+    unsigned magic_tiles, magic_tiles_x;   // floor(2^32 / n) + 1: a / n == umulhi(a, magic) for a * n < 2^32
+};
+
+static inline unsigned div_magic(int n) { return n <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)n) + 1ull); }   // 0 encodes n == 1
+__device__ __forceinline__ int fast_div(int a, unsigned magic) { return magic ? (int)__umulhi((unsigned)a, magic) : a; }
+
+template <int IN>
+__device__ __forceinline__ float xform1(float v, float sc, float sh, float aux) {
+    if constexpr (IN == BNERV_IN_AFFINE) return v * sc + sh;
+    if constexpr (IN == BNERV_IN_GELU_AFFINE) return gelu_f(v) * sc + sh;
+    return v;
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned shift_bytes, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(p) - shift_bytes), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, (int)voff, (int)soff, 0);
+    // store-data hazard of 128-bit buffer stores with an SGPR soffset (see conv.hip, bstore): pad, fenced against the scheduler
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 3");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+struct LItem { int b, ty, tx; };
+
+#ifdef BNERV_TRACE   // debug variant only (tools/ktrace_bf.py): s_memtime phase stamps
+__device__ unsigned long long g_trace_bf[1024 * 4 * 6 * 8];
+#define TRACE(slot) do { if (lane == 0 && blockIdx.x < 1024 && trace_iter < 6) g_trace_bf[((blockIdx.x * 4 + wave) * 6 + trace_iter) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TRACE(slot) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------- split kernels
+// Measured on gfx950 (tools/ubench/mfma_interleave.cpp, tools/ubench/bf16_split.cpp, profiles/r02_*): the f32-input MFMA runs at
+// the f32 VECTOR rate and ordinary VALU work does not hide under it (interleaved in one wave or phased across waves), so a
+// 12-channel layer on v_mfma_f32_16x16x4_f32 cannot beat  MFMA cycles + VALU cycles  -- 23.5 us of matrix work at 720x1280
+// (25 % of it the 12 -> 16 padding) plus everything around it.  The 16-bit matrix pipe is 16x faster, and an f32 product can
+// be rebuilt from 16-bit pieces with f32 accumulation (every partial product of two pieces is exact in f32):
+//   SP_BF16X6   x = x1 + x2 + x3 exactly (bf16 pieces of 8 mantissa bits, RNE at every level);  a b ~= a1 b1 + (a1 b2 + a2 b1) +
+//               (a2 b2 + a1 b3 + a3 b1): 6 MFMAs, dropped terms <= 2^-24 |a b|.  Measured 7.9e-8 * sum|a b| at K = 128 -- better than
+//               the k-ordered f32 chain of the f32 MFMA itself (1.3e-7).
+//   SP_F16X3    x s = h + l + O(2^-22) (f16 pieces of 11 bits after an exact power-of-two scale s that puts the TILE's largest
+//               |x| into [2^14, 2^15): no overflow, and whatever falls below the f16 range is < 2^-39 of that maximum);
+//               a b ~= a_h b_h + (a_h b_l + a_l b_h): 3 MFMAs, error ~2^-22 |a b|; the accumulators are rescaled exactly.
+//   SP_BF16X3   two bf16 pieces, 3 MFMAs, ~2^-16 |a b| (opt-in, for comparison only).
+// 6 x 16 (or 3 x 16) cycles replace 8 x 32 cycles per 32 k-values.
+//
+// Same scope, item walk, buffer-load staging and accumulator-direct epilogues as conv.hip's lean kernel; what changes:
+//   * v_mfma_f32_16x16x32_{bf16,f16}: lane (i = l & 15, kq = l >> 4) holds 8 consecutive k.  k is ordered (tap, channel): K step s
+//     covers taps 2s and 2s+1 x 16 channels, lane group kq -> tap 2s + (kq >> 1), channels 8 (kq & 1) .. +7.  A lane's A fragment
+//     is 8 channels of ONE pixel = 16 bytes of a PIXEL-MAJOR tile  s_a[piece][row][pixel][half]  (16-B slots; the slot index
+//     inside each group of 4 pixels is rotated by the group index, which spreads both the staging writes of 8 neighbouring
+//     segments and the 16 pixels of a fragment read over the banks).
+//   * staging: thread slot = (channel half, halo row, 4-px segment); waves 0-1 own channels 0..7, waves 2-3 channels 8..8+CB-1
+//     (CB = 4 for Cin <= 12: the padding channels are never loaded or converted).  One buffer load per channel in the coalescing
+//     pattern of the planar kernels, prologue transform, split, and 4 pixels x NS ds_write_b128.
+//   * B fragments live in LDS in lane order (one ds_read_b128 per (step, piece), shared by the wave's 4 M tiles), built once per
+//     block from a coalesced read of the weight tensor.  Channels >= Cin and tap 9 carry zero weights, so whatever finite value
+//     the A side holds there contributes nothing.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+enum { SP_BF16X6 = 0, SP_BF16X3 = 1, SP_F16X3 = 2 };
+template <int SP> struct Split {
+    static constexpr int NS = (SP == SP_BF16X6) ? 3 : 2;
+    static constexpr bool SCALED = (SP == SP_F16X3);
+};
+
+template <int SP>
+__device__ __forceinline__ unsigned pk16(float a, float b) {
+    if constexpr (SP == SP_F16X3) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, h2));
+    } else {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, b2));
+    }
+}
+template <int SP>
+__device__ __forceinline__ f32x2 unpk16(unsigned pk) {
+    if constexpr (SP == SP_F16X3) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        return __builtin_convertvector(__builtin_bit_cast(h2, pk), f32x2);
+    } else {
+        return f32x2{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
+    }
+}
+// NE (<= 8, even) floats -> NS packed 8-element pieces, round to nearest even at every level (the residuals are exact in f32);
+// elements NE..7 of every piece are zero
+template <int SP, int NE>
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[Split<SP>::NS]) {
+    constexpr int NS = Split<SP>::NS;
+    f32x2 r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = f32x2{x[2 * e], x[2 * e + 1]};
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (2 * e < NE) {
+                const unsigned pk = pk16<SP>(r[e][0], r[e][1]);
+                out[p][e] = pk;
+                if (p + 1 < NS) r[e] -= unpk16<SP>(pk);
+            } else {
+                out[p][e] = 0u;
+            }
+        }
+    }
+}
+// exact power of two that moves max_abs into [2^14, 2^15); 1 for 0 / non-finite input
+__device__ __forceinline__ float pow2_scale(float max_abs) {
+    const unsigned e = (__builtin_bit_cast(unsigned, max_abs) >> 23) & 0xffu;
+    return (e == 0u || e == 0xffu) ? 1.0f : __builtin_bit_cast(float, (268u - e) << 23);
+}
+__device__ __forceinline__ float pow2_inv(float s) {                      // 1 / s for s = 2^k, exact
+    return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, s));
+}
+
+template <int KS> struct BfGeo {
+    using G = Geo<KS>;
+    static constexpr int NP = (KS == 3) ? 34 : 32;                 // pixels per tile row kept in LDS (planar columns COL0 .. COL0 + NP - 1)
+    static constexpr int SPR = ((NP + 3) / 4) * 8;                 // 16-B slots per row: 72 / 64
+    static constexpr int PIECE = G::ROWS * SPR * 16;               // bytes per piece: 11520 / 8192
+    static constexpr int STEPS = (G::T + 1) / 2;                   // 5 / 1
+    static constexpr int HSLOT = G::ROWS * G::SEGS;                // staging slots per channel half: 100 / 64
+    static_assert(HSLOT <= 128, "one slot per thread of a wave pair");
+};
+__device__ __forceinline__ int bf_slot(int r, int p, int h, int spr) { return r * spr + 8 * (p >> 2) + ((2 * (p & 3) + h + (p >> 2)) & 7); }
+
+template <int SP>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (SP == SP_F16X3) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int KS, int IN, int EP, int SP, int CB>
+__global__ __launch_bounds__(256, 3) void conv_bf_kernel(const KArgs ka, const SidePack side) {
+    using G = Geo<KS>;
+    using BG = BfGeo<KS>;
+    constexpr int NS = Split<SP>::NS;
+    constexpr bool SCALED = Split<SP>::SCALED;
+    constexpr bool AFF = (IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE);
+    constexpr bool RED = (EP == BNERV_EP_DGELU || EP == BNERV_EP_DSIN || EP == BNERV_EP_DGELU_SAVED);
+    constexpr int SB_BYTES = BG::STEPS * NS * 64 * 16;
+    static_assert(IN != BNERV_IN_TANHGRAD && IN != BNERV_IN_UNSHUFFLE, "prologues of the split kernel");
+    const bnerv_conv_desc& d = ka.d;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* s_a = reinterpret_cast<char*>(smem);                      // [NS][ROWS][SPR] 16-B slots
+    char* s_b = s_a + NS * BG::PIECE;                              // [STEPS][NS][64 lanes] 16 B
+    float* s_red = reinterpret_cast<float*>(s_b + SB_BYTES);       // [4 waves][2][16]
+    float* s_aff = s_red + 128;                                    // [2][16]
+    float* s_max = s_aff + 32;                                     // [4] wave maxima (tile / weight scale)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
+    const int tiles_x = ka.tiles_x, tiles_y = ka.tiles_y;
+
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const int nlb = (gridDim.x - xcd + 7) >> 3;
+    const int per = ka.total_items >> 3, extra = ka.total_items & 7;
+    const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
+    int itx = r0 + lb;
+    if (itx >= r1) { side_run_hosted(side, smem); return; }
+    const int step_q = fast_div(nlb, ka.magic_tiles_x), step_r = nlb - step_q * tiles_x;
+    LItem it;
+    {
+        const int tiles = tiles_x * tiles_y;
+        it.b = fast_div(itx, ka.magic_tiles);
+        const int t = itx - it.b * tiles;
+        it.ty = fast_div(t, ka.magic_tiles_x);
+        it.tx = t - it.ty * tiles_x;
+    }
+    auto advance = [&](LItem a) __attribute__((always_inline)) {
+        a.tx += step_r;
+        a.ty += step_q;
+        if (a.tx >= tiles_x) { a.tx -= tiles_x; ++a.ty; }
+        while (a.ty >= tiles_y) { a.ty -= tiles_y; ++a.b; }
+        return a;
+    };
+
+    // ---- staging slot of this thread: waves 0-1 <-> channels 0..7, waves 2-3 <-> channels 8..8+CB-1; (halo row, 4-px segment) with
+    //      the segment fastest (the coalescing pattern of the planar kernels)
+    const int s_h = wave >> 1;                                     // wave-uniform
+    const int sidx = tid & 127;
+    const bool has_slot = sidx < BG::HSLOT;
+    const int s_sg = sidx % G::SEGS, s_r = (sidx / G::SEGS) % G::ROWS;
+    const unsigned voff0 = has_slot ? (unsigned)((((8 * s_h) * H + s_r) * W + 4 * s_sg) * 4) : OOB;
+    const unsigned hw4 = (unsigned)(H * W * 4);
+    const unsigned shift = (unsigned)((G::PAD * W + G::XOFF) * 4);
+    const unsigned in_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
+    const unsigned out_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, in_bytes);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ro2 = make_rsrc(((EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) && d.out2) ? d.out2 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(d.aux0 ? d.aux0 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(d.aux1 ? d.aux1 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ra2 = make_rsrc(d.aux2 ? d.aux2 : d.out, 0, out_bytes);
+    // LDS byte address of pixel j of this thread's segment (piece 0); pixels outside the kept columns are not written
+    int w_addr[4];
+    bool w_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = 4 * s_sg + j - G::COL0;
+        w_ok[j] = has_slot && p >= 0 && p < BG::NP;
+        w_addr[j] = bf_slot(s_r, w_ok[j] ? p : 0, s_h, BG::SPR) * 16;
+    }
+
+    const unsigned ovoff = li < Cout ? (unsigned)(((li * H) * W + 4 * kq) * 4) : OOB;
+    const float bias_l = (EP != BNERV_EP_PLAIN && !RED && d.bias && li < Cout) ? d.bias[li] : 0.f;
+
+    auto fetch_affine = [&](int b) __attribute__((always_inline)) {
+        const int c = tid & 15;
+        float v = 0.f;
+        if (tid < 32 && c < Cin) v = tid < 16 ? 1.0f + d.scale[b * Cin + c] : d.shift[b * Cin + c];
+        return v;
+    };
+    auto block_max = [&](float v) __attribute__((always_inline)) {                        // max over the block (a barrier on each side of the LDS exchange)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+        if (lane == 0) s_max[wave] = v;
+        lds_barrier();
+        const float m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        lds_barrier();
+        return m;
+    };
+    float scl = 0.f;
+
+    f32x4 ra[8];
+    auto issue = [&](const LItem& a) __attribute__((always_inline)) {
+        const int ty0 = a.ty * TH, tx0 = a.tx * TW;
+        unsigned sb = (unsigned)((((a.b * Cin) * H + ty0) * W + tx0) * 4);
+        const int gy = ty0 + s_r - G::PAD, gx = tx0 + 4 * s_sg - G::XOFF;
+        const unsigned vo = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? voff0 : OOB;
+        if (s_h == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ra[e] = bload(rx, vo, sb); sb += hw4; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < CB; ++e) { ra[e] = bload(rx, vo, sb); sb += hw4; }
+        }
+    };
+    // prologue transform in place (zero padding applies AFTER it); returns the largest |value| of this thread
+    auto transform_half = [&](const LItem& a, auto ne_tag) __attribute__((always_inline)) {
+        constexpr int NE = decltype(ne_tag)::value;
+        float mx = 0.f;
+        if constexpr (IN != BNERV_IN_PLAIN) {
+            const int ty0 = a.ty * TH, tx0 = a.tx * TW;
+            const int gy = ty0 + s_r - G::PAD, gx = tx0 + 4 * s_sg - G::XOFF;
+            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const float sc = (AFF && inside) ? s_aff[8 * s_h + e] : 0.f, sh = (AFF && inside) ? s_aff[16 + 8 * s_h + e] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ra[e][j] = xform1<IN>(ra[e][j], sc, sh, 0.f);
+            }
+        }
+        if constexpr (SCALED) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fabsf(ra[e][j]));
+        }
+        return mx;
+    };
+    auto write_half = [&](float s, auto ne_tag) __attribute__((always_inline)) {
+        constexpr int NE = decltype(ne_tag)::value;
+        float xs[4][8];                                    // (element-wise copies: a vector subscript that survives to codegen goes to scratch)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const f32x4 t = e < NE ? ra[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+            xs[0][e] = SCALED ? t.x * s : t.x;
+            xs[1][e] = SCALED ? t.y * s : t.y;
+            xs[2][e] = SCALED ? t.z * s : t.z;
+            xs[3][e] = SCALED ? t.w * s : t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4 pc[NS];
+            split8<SP, NE>(xs[j], pc);
+            if (w_ok[j]) {
+#pragma unroll
+                for (int p = 0; p < NS; ++p) *reinterpret_cast<u32x4*>(s_a + p * BG::PIECE + w_addr[j]) = pc[p];
+            }
+        }
+    };
+    // Staging of the tile whose loads are in `ra`, in two halves around a barrier the loop has anyway:
+    //   stage_pre   registers only: prologue transform, and (scaled split) this wave's largest |value| -> s_max[wave]
+    //   stage_post  after the barrier: block maximum -> power-of-two scale, split, LDS writes; returns 1 / scale
+    auto stage_pre = [&](const LItem& a) __attribute__((always_inline)) {
+        float mx;
+        if (s_h == 0) mx = transform_half(a, std::integral_constant<int, 8>{});
+        else mx = transform_half(a, std::integral_constant<int, CB>{});
+        if constexpr (SCALED) {
+            mx = has_slot ? mx : 0.f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            if (lane == 0) s_max[wave] = mx;
+        }
+    };
+    auto stage_post = [&]() __attribute__((always_inline)) {
+        float s = 1.0f;
+        if constexpr (SCALED) s = pow2_scale(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])));
+        if (s_h == 0) write_half(s, std::integral_constant<int, 8>{});
+        else write_half(s, std::integral_constant<int, CB>{});
+        return SCALED ? pow2_inv(s) : 1.0f;
+    };
+    auto flush_partials = [&](const LItem& a) __attribute__((always_inline)) {
+        if (wave == 0 && lane < 32) {
+            const int q = lane >> 4, c = lane & 15;
+            const float s = ((s_red[(0 * 2 + q) * 16 + c] + s_red[(1 * 2 + q) * 16 + c]) + s_red[(2 * 2 + q) * 16 + c]) + s_red[(3 * 2 + q) * 16 + c];
+            const size_t row = (size_t)(a.ty * tiles_x + a.tx) * d.B + a.b;
+            if (c < Cout) d.partial[(row * 2 + q) * Cout + c] = s;
+        }
+    };
+
+    // ---- prologue: first tile's loads in flight, then the B fragments.  The weight tensor is read coalesced (element i of the
+    //      OIHW array by thread i mod 256); element (a, b, tap) lands at fragment (step, lane group, column, k) of every piece.
+    int aff_b = -1, ep_b = -1;
+    float aff_v = 0.f;
+    if constexpr (AFF) { aff_v = fetch_affine(it.b); aff_b = it.b; }
+    issue(it);
+    float inv_b = 1.0f;
+    {
+        const int nw = d.wCo * d.wCi * G::T;
+        constexpr int NWV = (16 * 16 * G::T + 255) / 256;
+        float wv[NWV];
+        float wmx = 0.f;
+#pragma unroll
+        for (int k = 0; k < NWV; ++k) {
+            const int i = tid + k * 256;
+            wv[k] = i < nw ? d.w[i] : 0.f;
+            wmx = fmaxf(wmx, fabsf(wv[k]));
+        }
+        for (int i = tid; i < SB_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(s_b)[i] = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (AFF) { if (tid < 32) s_aff[tid] = aff_v; }
+        float sb_ = 1.0f;
+        if constexpr (SCALED) { sb_ = pow2_scale(block_max(wmx)); inv_b = pow2_inv(sb_); }
+        else lds_barrier();
+#pragma unroll
+        for (int k = 0; k < NWV; ++k) {
+            const int i = tid + k * 256;
+            const int pair = i / G::T, t = i - pair * G::T;
+            const int wa_ = pair / d.wCi, wb_ = pair - wa_ * d.wCi;
+            const int n = d.transposed ? wb_ : wa_, c = d.transposed ? wa_ : wb_;       // GEMM column (cout) and k-channel (cin)
+            if (i < nw && n < Cout && c < Cin) {
+                const int tg = d.transposed ? G::T - 1 - t : t;
+                const int st = tg >> 1, q = ((tg & 1) << 1) | (c >> 3), e = c & 7;
+                float r = SCALED ? wv[k] * sb_ : wv[k];
+#pragma unroll
+                for (int p = 0; p < NS; ++p) {
+                    unsigned short bits;
+                    float back;
+                    if constexpr (SP == SP_F16X3) { const _Float16 hv = (_Float16)r; bits = __builtin_bit_cast(unsigned short, hv); back = (float)hv; }
+                    else { const __bf16 hv = (__bf16)r; bits = __builtin_bit_cast(unsigned short, hv); back = (float)hv; }
+                    *reinterpret_cast<unsigned short*>(s_b + ((st * NS + p) * 64 + q * 16 + n) * 16 + e * 2) = bits;
+                    r -= back;
+                }
+            }
+        }
+    }
+    stage_pre(it);                                         // (the affine table was made visible by the barrier above)
+    if constexpr (SCALED) lds_barrier();
+    float inv_cur = stage_post() * inv_b;
+
+    // A-fragment byte addresses (tile-invariant): [step][x half of the M tile], rows of the M tile pair added as immediates
+    int a_addr[BG::STEPS][2];
+#pragma unroll
+    for (int s = 0; s < BG::STEPS; ++s) {
+        int t = 2 * s + (kq >> 1);
+        if (t > G::T - 1) t = G::T - 1;
+        const int ky = t / KS, kx = t - ky * KS;
+#pragma unroll
+        for (int xh = 0; xh < 2; ++xh) a_addr[s][xh] = bf_slot(2 * wave + ky, xh * 16 + li + kx, kq & 1, BG::SPR) * 16;
+    }
+    const int b_addr = lane * 16;
+
+    LItem prev = it;
+    bool have_prev = false;
+    int trace_iter = 0; (void)trace_iter;
+    for (; itx < r1; itx += nlb, ++trace_iter) {
+        TRACE(0);
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool has_next = itx + nlb < r1;
+        LItem nxt = it;
+        if (has_next) nxt = advance(it);
+        lds_barrier();                                     // (A) s_a(t), B fragments and s_red(t-1) visible
+        TRACE(1);
+        if (has_next) issue(nxt);
+        TRACE(2);
+        if constexpr (RED) { if (have_prev) flush_partials(prev); }
+#pragma unroll
+        for (int s = 0; s < BG::STEPS; ++s) {
+            u32x4 bfr[NS];
+#pragma unroll
+            for (int p = 0; p < NS; ++p) bfr[p] = *reinterpret_cast<const u32x4*>(s_b + (s * NS + p) * 1024 + b_addr);
+            // M tiles in groups of MG: consecutive MFMAs go to DIFFERENT accumulators (a dependent chain issues slower) while the
+            // fragments of one group stay within the register budget; smallest terms first
+            constexpr int MG = (NS == 3) ? 2 : 4;
+#pragma unroll
+            for (int m0 = 0; m0 < 4; m0 += MG) {
+                u32x4 afr[MG][NS];
+#pragma unroll
+                for (int m = 0; m < MG; ++m)
+#pragma unroll
+                    for (int p = 0; p < NS; ++p)
+                        afr[m][p] = *reinterpret_cast<const u32x4*>(s_a + p * BG::PIECE + a_addr[s][(m0 + m) & 1] + ((m0 + m) >> 1) * (BG::SPR * 16));
+#define BNERV_BF_PROD(pa, pb) _Pragma("unroll") for (int m = 0; m < MG; ++m) acc[m0 + m] = mfma16<SP>(afr[m][pa], bfr[pb], acc[m0 + m]);
+                if constexpr (NS == 3) {
+                    BNERV_BF_PROD(2, 0)
+                    BNERV_BF_PROD(0, 2)
+                    BNERV_BF_PROD(1, 1)
+                }
+                BNERV_BF_PROD(1, 0)
+                BNERV_BF_PROD(0, 1)
+                BNERV_BF_PROD(0, 0)
+#undef BNERV_BF_PROD
+            }
+        }
+        TRACE(3);
+        if (has_next) {
+            if constexpr (AFF) {
+                if (nxt.b != aff_b) {                      // sample change (B > 1): reload the affine table (rare, latency exposed)
+                    const float v = fetch_affine(nxt.b);
+                    lds_barrier();                         // (every wave has read the old table)
+                    if (tid < 32) s_aff[tid] = v;
+                    lds_barrier();
+                    aff_b = nxt.b;
+                }
+            }
+            stage_pre(nxt);                                // registers + s_max only: legal before barrier (B)
+        }
+        lds_barrier();                                     // (B) every wave is done reading s_a(t); s_max(t+1) visible
+        TRACE(4);
+        float inv_next = 1.0f;
+        if (has_next) inv_next = stage_post() * inv_b;
+        TRACE(5);
+        if constexpr (SCALED) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] *= inv_cur;
+        }
+        // ---- epilogue straight from the accumulators (as the lean kernel: the D fragment layout is the same)
+        {
+            const int ty0 = it.ty * TH, tx0 = it.tx * TW;
+            const unsigned ob = (unsigned)((((it.b * Cout) * H + ty0 + 2 * wave) * W + tx0) * 4);
+            const bool full = ty0 + TH <= H && tx0 + TW <= W;
+            if constexpr (RED) { if (it.b != ep_b) { scl = li < Cout ? 1.0f + d.scale[it.b * Cout + li] : 0.f; ep_b = it.b; } }
+            unsigned so[4], vo[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                so[m] = ob + (unsigned)(((m >> 1) * W + (m & 1) * 16) * 4);
+                vo[m] = ovoff;
+                if (!full) {
+                    const bool oky = ty0 + 2 * wave + (m >> 1) < H;
+                    const bool okx = tx0 + (m & 1) * 16 + 4 * kq < W;
+                    vo[m] = (okx && oky) ? ovoff : OOB;
+                    if constexpr (RED) { if (!(okx && oky)) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                }
+            }
+            if constexpr (EP == BNERV_EP_BIAS || EP == BNERV_EP_PLAIN) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) bstore(ro, vo[m], so[m], acc[m] + bias_l);
+            } else if constexpr (EP == BNERV_EP_BIAS_SIN) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x4 sv, cv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(acc[m][e] + bias_l, &s_, &c_); sv[e] = s_; cv[e] = c_; }
+                    bstore(ro, vo[m], so[m], sv);
+                    if (d.out2) bstore(ro2, vo[m], so[m], cv);
+                }
+            } else if constexpr (EP == BNERV_EP_BIAS_GELU) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x4 hv, gv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float h_, g_; gelu_pair_f(acc[m][e] + bias_l, &h_, &g_); hv[e] = h_; gv[e] = g_; }
+                    bstore(ro, vo[m], so[m], hv);
+                    if (d.out2) bstore(ro2, vo[m], so[m], gv);
+                }
+            } else if constexpr (EP == BNERV_EP_BIAS_TANH) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x4 r;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] = tanhf(acc[m][e] + bias_l) * 0.5f + 0.5f;
+                    bstore(ro, vo[m], so[m], r);
+                }
+            } else if constexpr (EP == BNERV_EP_BIAS_RES) {
+                f32x4 a0[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a0[m] = bload(ra0, vo[m], so[m]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) bstore(ro, vo[m], so[m], acc[m] + bias_l + a0[m]);
+            } else {                                       // DGELU / DSIN
+                f32x4 a0[4], a1[4], a2[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    a0[m] = bload(ra0, vo[m], so[m]);
+                    if constexpr (EP == BNERV_EP_DGELU_SAVED) a1[m] = bload(ra1, vo[m], so[m]);
+                    if constexpr (EP == BNERV_EP_DSIN) {
+                        a1[m] = bload(ra1, vo[m], so[m]);
+                        a2[m] = f32x4{1.f, 1.f, 1.f, 1.f};
+                        if (d.aux2) a2[m] = bload(ra2, vo[m], so[m]);
+                    }
+                }
+                float ps = 0.f, pt = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x4 r;
+                    const f32x4 v = acc[m];
+                    if constexpr (EP == BNERV_EP_DGELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { r[e] = v[e] * scl * gelu_grad_f(a0[m][e]); ps = fmaf(v[e], gelu_f(a0[m][e]), ps); pt += v[e]; }
+                    } else if constexpr (EP == BNERV_EP_DGELU_SAVED) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { r[e] = v[e] * scl * a0[m][e]; ps = fmaf(v[e], a1[m][e], ps); pt += v[e]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { r[e] = (a1[m][e] + v[e] * scl) * a2[m][e]; ps = fmaf(v[e], a0[m][e], ps); pt += v[e]; }
+                    }
+                    bstore(ro, vo[m], so[m], r);
+                }
+                ps += __shfl_xor(ps, 16, 64);
+                pt += __shfl_xor(pt, 16, 64);
+                ps += __shfl_xor(ps, 32, 64);
+                pt += __shfl_xor(pt, 32, 64);
+                if (lane < 16) { s_red[(wave * 2 + 0) * 16 + lane] = ps; s_red[(wave * 2 + 1) * 16 + lane] = pt; }
+            }
+        }
+        TRACE(6);
+        prev = it;
+        have_prev = true;
+        it = nxt;
+        inv_cur = inv_next;
+    }
+    if constexpr (RED) {
+        lds_barrier();
+        flush_partials(prev);
+    }
+    side_run_hosted(side, smem);
+}
+
+// Status (round 2, profiles/r02_split_*): correct in all three modes, but for ONE cout tile the staging work (split + LDS writes),
+// not the matrix pipe, sets the pace: 36.9 us (bf16x6) / 27.8 us (bf16x3) against 40.0 us for the f32 lean kernel on the
+// 12 -> 12 layer at 720x1280, and no gain on the data-gradient epilogues.  It is therefore OFF unless BNERV_SPLIT selects a mode;
+// the layers with several cout tiles per staged input tile are where the 16-bit pipe pays.
+static int split_mode() {                                  // BNERV_SPLIT = off (default) | bf16x6 | f16x3 | bf16x3
+    static const int v = [] {
+        const char* e = getenv("BNERV_SPLIT");
+        if (!e || !strcmp(e, "off") || !strcmp(e, "0")) return -1;
+        if (!strcmp(e, "f16x3")) return (int)SP_F16X3;
+        if (!strcmp(e, "bf16x3")) return (int)SP_BF16X3;
+        return (int)SP_BF16X6;
+    }();
+    return v;
+}
+
+template <int KS, int IN, int EP, int SP, int CB>
+int launch_bf(hipStream_t st, KArgs& ka) {
+    using BG = BfGeo<KS>;
+    constexpr int NS = Split<SP>::NS;
+    const bnerv_conv_desc& d = ka.d;
+    ka.total_items = d.B * ka.tiles_x * ka.tiles_y;
+    ka.magic_tiles = div_magic(ka.tiles_x * ka.tiles_y);
+    ka.magic_tiles_x = div_magic(ka.tiles_x);
+    const size_t lds = (size_t)NS * BG::PIECE + (size_t)BG::STEPS * NS * 1024 + (128 + 32 + 4) * sizeof(float);
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf_kernel<KS, IN, EP, SP, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_bf_kernel<KS, IN, EP, SP, CB>), 256, lds) != hipSuccess || nb < 1) nb = 1;
+        blocks_per_cu = nb > 3 ? 3 : nb;
+    }
+    int grid = 256 * blocks_per_cu;
+    if (grid > ka.total_items) grid = ka.total_items;
+    SidePack side;
+    bnerv_side_take(&side, 2 * grid);
+    hipLaunchKernelGGL((conv_bf_kernel<KS, IN, EP, SP, CB>), dim3(grid), dim3(256), lds, st, ka, side);
+    BNERV_LAUNCH_CHECK("conv_bf");
+    return BNERV_OK;
+}
+
+constexpr size_t LEAN_MAX_BYTES = 0x7ff00000;            // every tensor view must stay below the OOB marker offset
+
+template <int KS, int IN, int EP, int SP>
+int launch_cb(hipStream_t st, KArgs& ka) {
+    return ka.d.Cin <= 12 ? launch_bf<KS, IN, EP, SP, 4>(st, ka) : launch_bf<KS, IN, EP, SP, 8>(st, ka);
+}
+
+template <int KS, int IN, int EP>
+int launch_ns(hipStream_t st, KArgs& ka) {
+    const int sp = split_mode();
+    if (sp == SP_F16X3) return launch_cb<KS, IN, EP, SP_F16X3>(st, ka);
+    if (sp == SP_BF16X3) return launch_cb<KS, IN, EP, SP_BF16X3>(st, ka);
+    return launch_cb<KS, IN, EP, SP_BF16X6>(st, ka);
+}
+
+template <int KS>
+int launch_mode(hipStream_t st, KArgs& ka) {
+    const int in = ka.d.in_mode, ep = ka.d.ep_mode;
+#define BNERV_CASE(I, E) if (in == I && ep == E) return launch_ns<KS, I, E>(st, ka);
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS_SIN)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS_TANH)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_PLAIN)
+    if constexpr (KS == 3) {
+        BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS)
+        BNERV_CASE(BNERV_IN_GELU_AFFINE, BNERV_EP_BIAS_RES)
+        BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DGELU)
+        BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DSIN)
+        BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_GELU)
+        BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_RES)
+        BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DGELU_SAVED)
+    }
+#undef BNERV_CASE
+    return -1;
+}
+
+}  // namespace
+
+#ifdef BNERV_TRACE
+extern "C" int bnerv_debug_trace_read_bf(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_bf), sizeof(g_trace_bf)); }
+#endif
+
+// Called by bnerv_conv_igemm (conv.hip) after argument validation.  Returns -1 when the shape / mode is not this kernel's
+// (the caller then takes its f32-MFMA kernels), otherwise the launch status.
+int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec) {
+    if (split_mode() < 0 || !vec || d.out_s != 1 || d.Cout > 16 || d.Cin > 16 || d.Cin <= 8 || d.wCo > 16 || d.wCi > 16) return -1;
+    if (d.in_mode == BNERV_IN_UNSHUFFLE || d.in_mode == BNERV_IN_TANHGRAD) return -1;
+    const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
+    if ((size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 >= LEAN_MAX_BYTES) return -1;
+    KArgs ka;
+    ka.d = d;
+    ka.tiles_x = cdiv(d.W, TW);
+    ka.tiles_y = cdiv(d.H, TH);
+    return d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);
+}
