@@ -10,10 +10,14 @@ in HBM.  Workload at N=1: BASELINE configs[1] = NeRV-boost 1.5M on a Bunny-shape
 1 per GPU (the reference recipe's `-b 1`; `-b N -d` on N GPUs), weak scaling.  Prints ONE JSON line on rank 0.
 
 Extra objects on the line:
-  roofline      the dominant kernel (fp32 MFMA implicit-GEMM 3x3 conv 12->12 at 720x1280), timed live with HIP events on
-                the stream it is launched on, against its algorithmic flops / the dense fp32 MFMA peak
+  roofline      the conv family the step launches at the model's last stage (C -> C 3x3 at full resolution: TAT conv0 / conv1
+                forwards, their data gradients, the weight gradients), each instantiation timed live with HIP events on the
+                stream it is launched on; `achieved` = flop-weighted mean against the dense fp32 MFMA peak, `slowest` and the
+                per-kernel list beside it
+  step_roofline the whole measured step against max(flops / MFMA peak, bytes / HBM peak) of its algorithmic conv + dense work
+  eval_psnr_db  pred_seen_psnr of a few frames after the timed steps
   cpu_baseline  the CPU oracle (oracle/cpu_ref.py: the reference's algorithm in plain fp32 torch) running the SAME train step
-                on this box's host cores for a bounded sample (rank 0, N=1 only)
+                on this box's host cores for a bounded sample (rank 0, N=1 only): 3 warm-up + up to 20 timed steps, 30 s budget
 """
 import argparse
 import json
@@ -71,66 +75,148 @@ def build(cfg_name):
     return args, T.build_model(args)
 
 
-def dominant_kernel_roofline(dev, reps=30):
-    """TAT conv0 forward of the last stage: [affine prologue -> 3x3 conv 12->12 -> bias] at 720x1280, the most frequent heavy
-    launch of a C1 step (5 forward + 4 data-gradient launches of this shape per step share the same kernel body).
-    Algorithmic work per launch (SURVEY 8(d) convention: 2*MACs; activations once in + once out + weights, 4 B each):
-      flops = 2 * 12*12*9 * 720*1280 = 2.389 GFLOP ;  bytes = (12 + 12)*720*1280*4 + 12*12*9*4 = 88.5 MB  (AI = 27 flop/B)
-    AI is above the ridge (157.3 TF / 8 TB/s = 19.7 flop/B) -> bounded by the fp32 MFMA peak."""
-    from boosting_nerv_amd import ops, _lib as L
-    B, Cc, H, W = 1, 12, 720, 1280
-    g = torch.Generator(device="cpu").manual_seed(0)
-    x = torch.randn(B, Cc, H, W, generator=g).to(dev)
-    w = (torch.randn(Cc, Cc, 3, 3, generator=g) / 10).to(dev)
-    b = torch.randn(Cc, generator=g).to(dev)
-    sc, sh = torch.randn(B, Cc, generator=g).to(dev) * 0.1, torch.randn(B, Cc, generator=g).to(dev) * 0.1
-    out = torch.empty_like(x)
-    run = lambda: ops._conv(x, w, b, out, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS, scale=sc, shift=sh)
+# Algorithmic work per trained frame (BASELINE.md section 3 / SURVEY 8(d): conv + dense only, train = fwd + dgrad + wgrad,
+# 2 flops per MAC, every activation once in + once out per conv at 4 B)
+STEP_WORK = {"c1": (58.0e9, 2.165e9), "c3": (1542e9, 16.08e9), "c4": (367.8e9, 6.42e9), "c5": (1542e9, 16.08e9)}
+
+
+def _time_launches(fn, reps):
     for _ in range(5):
-        run()
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # current stream == launch stream
     torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
-        run()
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) * 1e-3 / reps
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def step_kernel_roofline(dev, Cc, H, W, reps=20):
+    """The heavy launches of one train step at the model's LAST stage (Cc -> Cc 3x3 at HxW: two TAT blocks + one stride-1 block
+    conv), each timed live with HIP events through the C-ABI exactly as ops._tat_forward / _tat_backward / _SNeRVBlock issue
+    them (same prologue / epilogue modes, same auxiliary tensors -> same template instantiations as the step's trace):
+        K2s  conv0 forward   [affine -> 3x3 -> bias -> gelu, gelu']      x2 per step
+        K3s  conv1 forward   [affine -> 3x3 -> bias -> + residual]       x2
+        K1   block conv      [3x3 -> bias -> sin, cos]                   x1
+        dK3s conv1 data grad [3x3^T -> * gelu' * (1+s) , channel sums]   x2
+        dK2s conv0 data grad [3x3^T -> (dout + . (1+s)) * cos, sums]     x2
+        wA   weight gradient with the affine prologue                    x4
+        wP   weight gradient, plain input                                x1
+    Algorithmic work per launch: flops = 2 * Cc*Cc*9 * H*W ; bytes = activations once in + once out (+ each auxiliary tensor
+    the mode reads or writes) + weights, 4 B each.  At Cc = 12 the plain modes sit just above the ridge (157.3 TF / 8 TB/s =
+    19.7 flop/B) and the data gradients with 3-4 auxiliary planes below it, so every row also carries its own bound
+    (max of flops / MFMA peak and bytes / HBM peak) and `frac_of_own_roof`.  `achieved` of the family = sum(flops) / sum(time)
+    with the per-step launch counts as weights against the dense fp32 MFMA peak; the slowest member is reported next to it."""
+    from boosting_nerv_amd import ops, _lib as L
+    B = 1
+    g = torch.Generator(device="cpu").manual_seed(0)
+    rn = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(dev)
+    x, y0, h, gp, c0, dout = (rn(B, Cc, H, W) for _ in range(6))
+    w = rn(Cc, Cc, 3, 3, sc=0.1)
+    b = rn(Cc)
+    sc, sh = rn(B, Cc, sc=0.1), rn(B, Cc, sc=0.1)
+    out, out2 = torch.empty_like(x), torch.empty_like(x)
+    dw, db = torch.empty_like(w), torch.empty_like(b)
+    kw = dict(B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3)
+    plane = Cc * H * W * 4.0
+    wb = Cc * Cc * 9 * 4.0
+    cases = [   # name, launches per step, tensors moved (in planes), launcher
+        ("K2s conv0 fwd: affine->conv->bias->gelu,gelu'", 2, 3, lambda: ops._conv(x, w, b, out, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=sc, shift=sh, out2=out2, **kw)),
+        ("K3s conv1 fwd: affine->conv->bias->+res", 2, 3, lambda: ops._conv(h, w, b, out, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_RES, scale=sc, shift=sh, aux0=y0, **kw)),
+        ("K1 block conv fwd: conv->bias->sin,cos", 1, 3, lambda: ops._conv(x, w, b, out, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_SIN, out2=out2, **kw)),
+        ("dK3s conv1 dgrad: conv^T->dgelu(saved)+sums", 2, 4, lambda: ops._conv(dout, w, None, out, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU_SAVED, transposed=1, aux0=gp, aux1=h, scale=sc, defer=True, **kw)),
+        ("dK2s conv0 dgrad: conv^T->dsin+sums", 2, 5, lambda: ops._conv(dout, w, None, out, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN, transposed=1, aux0=y0, aux1=dout, aux2=c0, scale=sc, defer=True, **kw)),
+        ("wA weight grad, affine prologue", 4, 2, lambda: ops._wgrad(h, dout, dw, db, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=sc, shift=sh, defer=True, **kw)),
+        ("wP weight grad, plain", 1, 2, lambda: ops._wgrad(x, dout, dw, db, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, defer=True, **kw)),
+    ]
     flops = 2.0 * Cc * Cc * 9 * H * W
-    nbytes = (2 * Cc * H * W + Cc * Cc * 9) * 4.0
-    ach = flops / t / 1e12
-    # HBM bytes per launch: PMC figure of the same kernel and shape, collected with rocprofv3 --pmc in separate passes and
-    # committed with its summary (bench.py cannot run under the counter collector itself); None if the file is absent.
+    rows, tf, tt = [], 0.0, 0.0
+    troof = 0.0
+    for name, n, planes, fn in cases:
+        t = _time_launches(fn, reps)       # (slab reductions are deferred exactly as in the step: they ride on the following launch)
+        ops._flush_deferred()
+        ach = flops / t / 1e12
+        nbytes = planes * plane + wb
+        t_m, t_h = flops / (PEAK_FP32_MFMA_TFLOPS * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
+        rows.append({"kernel": name, "per_step": n, "avg_launch_us": round(t * 1e6, 2), "achieved": round(ach, 2), "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                     "bytes_per_launch": nbytes, "algorithmic_GB_per_s": round(nbytes / t / 1e9, 1), "bound": "mfma" if t_m >= t_h else "hbm",
+                     "frac_of_own_roof": round(max(t_m, t_h) / t, 4)})
+        tf += n * flops
+        tt += n * t
+        troof += n * max(t_m, t_h)
+    ach = tf / tt / 1e12
+    slow = min(rows, key=lambda r: r["achieved"])
+    k2s = rows[0]
+    # HBM bytes per launch of the K2s kernel: PMC figure of the same kernel and shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate passes, gfx950 x2 FETCH correction), committed with its summary -- bench.py cannot run under the counter collector
     traffic, traffic_src = None, None
+    for name in ("r02_traffic.json", "r01_f_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if (Cc, H, W) == (12, 720, 1280):
+                traffic, traffic_src = float(tj["hbm_bytes_per_launch"]), tj["source"] + " [" + tj["kernel"] + "]"
+            break
+        except (OSError, KeyError, ValueError):
+            continue
+    return {"kernel": f"final-stage conv family of the step ({Cc}->{Cc} 3x3 @{H}x{W}): flop-weighted over the 14 launches below", "bound": "mfma",
+            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+            "avg_launch_us": round(tt / 14 * 1e6, 2), "flops_per_launch": flops, "bytes_per_launch": k2s["bytes_per_launch"],
+            "slowest": {"kernel": slow["kernel"], "achieved": slow["achieved"], "frac": slow["frac"]},
+            "frac_of_per_kernel_roof": round(troof / tt, 4), "kernels": rows}
+
+
+def cpu_model_string():
     try:
-        import json as _json
-        tj = _json.load(open(os.path.join(ROOT, "profiles", "r01_f_traffic.json")))
-        traffic, traffic_src = float(tj["hbm_bytes_per_launch"]), tj["source"]
-    except (OSError, KeyError, ValueError):
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
         pass
-    return {"kernel": "conv_lean_kernel<3,IN_AFFINE,EP_BIAS,NQ=3> 12->12 3x3 @720x1280", "bound": "mfma", "achieved": round(ach, 2),
-            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-            "avg_launch_us": round(t * 1e6, 2), "algorithmic_GB_per_s": round(nbytes / t / 1e9, 1), "flops_per_launch": flops,
-            "bytes_per_launch": nbytes}
+    return "unknown"
 
 
-def cpu_baseline(args, model_cpu_sd, frames, norm_idxs, budget_s=20.0, max_steps=8):
+def cpu_baseline(args, model_cpu_sd, frames, norm_idxs, budget_s=30.0, warmup=3, max_steps=20):
+    """SURVEY 8(d) protocol: the oracle restatement of the SAME train step on every host core, `warmup` untimed + up to
+    `max_steps` timed steps, bounded by `budget_s` of timed work (C1 takes ~3 s per step on 64 cores; the 1080p models 10-25 s,
+    so their sample is one warm-up + whatever fits the budget -- the sample string says what was run)."""
     from oracle import cpu_ref
     ncores = min(os.cpu_count() or 1, 64)      # one thread per physical core at most: SMT siblings / >64 threads slow the MKLDNN convs down
     torch.set_num_threads(ncores)
     sd = {k: v.clone().float().requires_grad_(True) for k, v in model_cpu_sd.items()}
     adan = cpu_ref.AdanState(list(sd.values()), lr=args.lr)
     kind = args.model
-    cpu_ref.train_step(kind, sd, adan, frames[0:1], norm_idxs[0:1], args.loss)       # warm-up
+    t_w = time.time()
+    nw = 0
+    while nw < warmup and (nw == 0 or time.time() - t_w < budget_s / 2):
+        cpu_ref.train_step(kind, sd, adan, frames[nw % frames.shape[0]:nw % frames.shape[0] + 1], norm_idxs[nw % frames.shape[0]:nw % frames.shape[0] + 1], args.loss)
+        nw += 1
     n, t0 = 0, time.time()
-    while n < max_steps and (time.time() - t0) < budget_s:
-        i = (n + 1) % frames.shape[0]
+    while n < max_steps and (n == 0 or (time.time() - t0) < budget_s):
+        i = (n + nw) % frames.shape[0]
         cpu_ref.train_step(kind, sd, adan, frames[i:i + 1], norm_idxs[i:i + 1], args.loss)
         n += 1
     dt = time.time() - t0
-    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full train steps (fwd + {args.loss} + bwd + Adan) of the same model/frame size after 1 warm-up, oracle/cpu_ref.py on torch CPU fp32"}
+    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model_string(),
+            "sample": f"{n} timed full train steps (fwd + {args.loss} + bwd + Adan) of the same model / frame size after {nw} warm-up, "
+                      f"oracle/cpu_ref.py on torch CPU fp32, {torch.get_num_threads()} threads, timed budget {budget_s:.0f} s"}
+
+
+@torch.no_grad()
+def eval_psnr(model, frames, norm, takes_image, n_eval=8):
+    """pred_seen_psnr of evaluate() (train_nerv_all.py:527-550 of the reference) on the first frames of this rank's shard, fp32 model,
+    after the timed steps: mean over frames of -10 log10(mse + 1e-9)."""
+    from boosting_nerv_amd import ops
+    model.eval()
+    vals = []
+    for i in range(min(n_eval, frames.shape[0])):
+        inp = frames[i:i + 1] if takes_image else norm[i:i + 1]
+        img = model(inp, norm_idx=norm[i:i + 1])[0]
+        vals.append(ops.psnr(img, frames[i:i + 1]))
+    model.train()
+    return torch.cat(vals).mean().item(), len(vals)
 
 
 def stock_rocm_yardstick(args, model_cpu_sd, frames, norm_idxs, dev, budget_s=10.0, max_steps=20):
@@ -152,6 +238,20 @@ def stock_rocm_yardstick(args, model_cpu_sd, frames, norm_idxs, dev, budget_s=10
     dt = time.time() - t0
     return {"value": round(n / dt, 3), "unit": "frames/s", "kind": "oracle restatement on stock PyTorch-ROCm ops (MIOpen/hipFFT), same GPU",
             "sample": f"{n} full train steps after 3 warm-up"}
+
+
+def last_stage_channels(model):
+    """Channel count of the decoder's last stage = input channels of the head conv."""
+    m = model
+    for name in ("head_layer", "head_layers"):
+        hl = getattr(m, name, None)
+        if hl is None:
+            continue
+        if isinstance(hl, torch.nn.ModuleList):
+            hl = [x for x in hl if x is not None][-1]
+        conv = hl if hasattr(hl, "weight") else next(x for x in hl.modules() if hasattr(x, "weight") and x.weight.dim() == 4)
+        return int(conv.weight.shape[1])
+    raise RuntimeError("no head layer found")
 
 
 def main():
@@ -244,7 +344,11 @@ def main():
     if rank == 0:
         frames_total = a.steps * per_gpu_batch * world
         out = {"metric": "train frames/sec", "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
-               "warmup": max(a.warmup, 5), "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "warmup": max(a.warmup, 5), "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
+               # per step every GPU trains ONE frame of its shard (the reference's `-b N -d`): per-GPU work per step is fixed -> "weak"
+               # by the contract's definition; the CLIP is fixed (132 / 600 frames sharded like DistributedSampler), so value =
+               # frames/s of one video and value(N) / value(1) is north_star's strong-scaling factor of an epoch
+               "scaling": "weak",
                "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
                "config": {"workload": f"{r['name']} ({n_params} params, fc_dim {args.fc_dim}) train step on a synthetic "
                                       f"{'Bunny' if a.config == 'c1' else 'UVG'}-shaped clip {r['n']}x3x{r['h']}x{r['w']}: "
@@ -253,7 +357,17 @@ def main():
                           "baseline_config": {"c1": "configs[1]", "c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]"}[a.config], "global_batch": per_gpu_batch * world,
                           "per_gpu_batch": per_gpu_batch, "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
                           "last_loss": round(loss, 4), "last_train_psnr_db": round(psnr, 3)}}
-        out["roofline"] = dominant_kernel_roofline(dev) if a.config == "c1" else None
+        c_last = last_stage_channels(model)
+        out["roofline"] = step_kernel_roofline(dev, c_last, r["h"], r["w"], reps=20 if r["h"] <= 720 else 8)
+        fl, by = STEP_WORK[a.config]
+        t_step = dt / a.steps / per_gpu_batch                                   # seconds per trained frame on one GPU
+        t_roof = max(fl / (PEAK_FP32_MFMA_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9))
+        out["step_roofline"] = {"flops_per_frame": fl, "bytes_per_frame": by, "t_roof_ms": round(t_roof * 1e3, 4), "bound": "mfma" if fl / (PEAK_FP32_MFMA_TFLOPS * 1e12) >= by / (PEAK_HBM_GBS * 1e9) else "hbm",
+                                "achieved_TFLOPs": round(fl / t_step / 1e12, 2), "achieved_GBs": round(by / t_step / 1e9, 1), "frac_of_t_roof": round(t_roof / t_step, 4),
+                                "note": "algorithmic conv+dense work of one trained frame (BASELINE.md section 3) against the whole measured step, loss / optimizer / launches included"}
+        ev, nev = eval_psnr(model, frames, norm, takes_image)
+        out["eval_psnr_db"] = round(ev, 3)
+        out["config"]["eval"] = f"pred_seen_psnr over the first {nev} frames of the shard after {max(a.warmup, 5) + a.steps} train steps from random init (fp32 model)"
         if world == 1 and not a.no_cpu_baseline:
             fcpu = torch.stack([vid.frame(i) for i in keep[:4]])
             ncpu = torch.tensor([(i + 1) / r["n"] for i in keep[:4]], dtype=torch.float64)

@@ -13,6 +13,10 @@ for f in abi conv convbf wgrad dense optim loss dwconv cem lnorm; do
     pids+=($!)
   fi
 done
+if [ ! -f _obj/ans.o ] || [ ans.cpp -nt _obj/ans.o ] || [ common.h -nt _obj/ans.o ] || [ ../../include/bnerv.h -nt _obj/ans.o ]; then
+  $HIPCC -x hip $FLAGS -c ans.cpp -o _obj/ans.o &
+  pids+=($!)
+fi
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT _obj/abi.o _obj/conv.o _obj/convbf.o _obj/wgrad.o _obj/dense.o _obj/optim.o _obj/loss.o _obj/dwconv.o _obj/cem.o _obj/lnorm.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT _obj/abi.o _obj/conv.o _obj/convbf.o _obj/wgrad.o _obj/dense.o _obj/optim.o _obj/loss.o _obj/dwconv.o _obj/cem.o _obj/lnorm.o _obj/ans.o
 echo "built $(realpath $OUT)"

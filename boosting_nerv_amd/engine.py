@@ -112,11 +112,15 @@ class CompressionStep(TrainStep):
     """The rate-distortion step of train_nerv_compression.py:354-367 (quantise + rate term over all tensors -> forward with the
     embedding's rate -> loss + lambda * bpp while bpp / N exceeds the target -> backward -> Adan) as ONE captured graph.  The
     `bpp > target` decision is a device-side gate and the training noise comes from the capture-aware default generator, so
-    nothing in the step needs the host.  Single GPU; returns (final_loss, psnr[B]); `bpp_out` holds bits per pixel (x N)."""
+    nothing in the step needs the host.  With several ranks the quantiser / rate parameters are part of the same flat gradient
+    bucket as the weights (they are model parameters), exchanged exactly as in TrainStep.  Returns (final_loss, psnr[B]);
+    `bpp_out` holds bits per pixel (x N)."""
 
-    def __init__(self, model, optimizer, entropy_model, args, batch_shape, device, use_graph=True, warmup_eager=3):
+    def __init__(self, model, optimizer, entropy_model, args, batch_shape, device, use_graph=True, warmup_eager=3, world_size=1,
+                 process_group=None, force_bucket=False):
         super().__init__(model, optimizer, args.loss, "HNeRV_Boost" in args.model or 'pe' not in args.embed, batch_shape, device,
-                         use_graph=use_graph, warmup_eager=warmup_eager, clip_max_norm=getattr(args, "clip_max_norm", 0.0))
+                         use_graph=use_graph, warmup_eager=warmup_eager, clip_max_norm=getattr(args, "clip_max_norm", 0.0),
+                         world_size=world_size, process_group=process_group, force_bucket=force_bucket)
         self.entropy_model, self.cargs = entropy_model, args
         self.bpp_out = None
 

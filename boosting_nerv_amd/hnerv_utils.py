@@ -111,45 +111,44 @@ class TransformInput(nn.Module):                                                
         return inp, gt, inpaint_mask.detach()
 
 
-def data_split(img_list, split_num_list, shuffle_data, rand_num=0):                      # reference hnerv_utils.py:87-98
-    valid_train_length, total_train_length, total_data_length = split_num_list
-    temp_train_list, temp_val_list = [], []
+def data_split(img_list, split_num_list, shuffle_data, rand_num=0):
+    """Periodic train / validation partition of the frame list (--data_split a_b_c, reference hnerv_utils.py:87-98): inside every
+    period of c frames the first a are training frames and those from position b on are held out.  `shuffle_data` permutes the
+    list first with Random(rand_num) -- the same generator call as the reference, so the same split."""
+    n_seen, n_train_end, period = split_num_list
+    frames = list(img_list)
     if shuffle_data:
-        random.Random(rand_num).shuffle(img_list)
-    for cur_i, frame_id in enumerate(img_list):
-        if (cur_i % total_data_length) < valid_train_length:
-            temp_train_list.append(frame_id)
-        elif (cur_i % total_data_length) >= total_train_length:
-            temp_val_list.append(frame_id)
-    return temp_train_list, temp_val_list
+        random.Random(rand_num).shuffle(frames)
+    train = [f for pos, f in enumerate(frames) if pos % period < n_seen]
+    held_out = [f for pos, f in enumerate(frames) if pos % period >= n_train_end]
+    return train, held_out
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# post-hoc 8-bit quantisation used by evaluate()/quant_model            reference hnerv_utils.py:101-134, :183-186
-# (eval-time reporting, stock torch ops -- not part of the train hot path)
+# post-hoc 8-bit quantisation used by evaluate() / quant_model (reference hnerv_utils.py:101-134, :183-186): eval-time
+# reporting on stock torch ops, not part of the train hot path
 # ----------------------------------------------------------------------------------------------------------------------
 def quant_tensor(t, bits=8):
-    tmin_scale_list = []
-    t_min, t_max = t.min(), t.max()
-    scale = (t_max - t_min) / (2 ** bits - 1)
-    tmin_scale_list.append([t_min, scale])
+    """Uniform `bits`-bit quantisation of a tensor on the best of several affine grids: one (min, step) pair for the whole tensor
+    (kept in fp32), and one pair per slice along every axis whose pair count stays below 2 % of the element count (stored as
+    fp16, as they are what gets transmitted).  The grid with the smallest mean absolute reconstruction error wins (first one on
+    ties).  Returns ({'quant': uint8 codes, 'min', 'scale'}, reconstructed tensor)."""
+    top = 2 ** bits - 1
+    grids = [(t.min(), (t.max() - t.min()) / top)]
     for axis in range(t.dim()):
-        t_min, t_max = t.min(axis, keepdim=True)[0], t.max(axis, keepdim=True)[0]
-        if t_min.nelement() / t.nelement() < 0.02:
-            scale = (t_max - t_min) / (2 ** bits - 1)
-            tmin_scale_list.append([t_min.to(torch.float16), scale.to(torch.float16)])
-    quant_t_list, new_t_list, err_t_list = [], [], []
-    for t_min, scale in tmin_scale_list:
-        t_min, scale = t_min.expand_as(t), scale.expand_as(t)
-        quant_t = ((t - t_min) / (scale)).round().clamp(0, 2 ** bits - 1)
-        new_t = t_min + scale * quant_t
-        quant_t_list.append(quant_t)
-        new_t_list.append(new_t)
-        err_t_list.append((t - new_t).abs().mean())
-    best_err_t = min(err_t_list)
-    best = err_t_list.index(best_err_t)
-    quant_t = {"quant": quant_t_list[best].to(torch.uint8), "min": tmin_scale_list[best][0], "scale": tmin_scale_list[best][1]}
-    return quant_t, new_t_list[best]
+        lo, hi = t.amin(axis, keepdim=True), t.amax(axis, keepdim=True)
+        if lo.nelement() / t.nelement() < 0.02:
+            grids.append((lo.to(torch.float16), ((hi - lo) / top).to(torch.float16)))
+    best = None
+    for lo, step in grids:
+        lo_e, step_e = lo.expand_as(t), step.expand_as(t)
+        codes = ((t - lo_e) / step_e).round().clamp(0, top)
+        rebuilt = lo_e + step_e * codes
+        err = (t - rebuilt).abs().mean()
+        if best is None or err < best[0]:
+            best = (err, codes, rebuilt, lo, step)
+    _, codes, rebuilt, lo, step = best
+    return {"quant": codes.to(torch.uint8), "min": lo, "scale": step}, rebuilt
 
 
 def dequant_tensor(quant_t):

@@ -1,0 +1,171 @@
+"""Driver-side plumbing shared by train_nerv_all.py and train_nerv_compression.py: run log, metric bookkeeping, checkpoint
+loading, data loaders over HBM-resident frames, results table.  None of it is on the hot path; it exists so that the two drivers
+honour the reference CLI's observable contract (files written under --outf, the lines printed, the metric names and their
+meaning: train_nerv_all.py:118-137, :139-148, :272-300, :451-619 of the reference) while being organised around this build's own
+pieces (device-side metric accumulation, one flat gradient bucket, frames resident in HBM)."""
+import csv
+import os
+from datetime import datetime
+
+import torch
+import torch.distributed as dist
+import yaml
+
+METRIC_NAMES = ['pred_seen_psnr', 'pred_seen_ssim', 'pred_unseen_psnr', 'pred_unseen_ssim',
+                'quant_seen_psnr', 'quant_seen_ssim', 'quant_unseen_psnr', 'quant_unseen_ssim']
+
+
+def fmt(t, digits):
+    """A tensor (any shape) as comma-separated rounded numbers -- the number format of every log line and CSV cell."""
+    vals = torch.as_tensor(t).detach().float().flatten().tolist()
+    return ','.join(str(round(v, digits)) for v in vals)
+
+
+def hms(seconds):
+    s = int(seconds) % 86400
+    return "%d:%02d:%02d" % (s // 3600, (s % 3600) // 60, s % 60)
+
+
+class RunLog:
+    """stdout + <outf>/rank0.txt (main rank only).  `line()` prints on every rank (the reference prints per rank) and appends to
+    the file on the main one."""
+
+    def __init__(self, outf, is_main=True, name='rank0.txt'):
+        self.path = os.path.join(outf, name)
+        self.is_main = is_main
+
+    def line(self, text, echo=True, every_rank=True):
+        if echo and (every_rank or self.is_main):
+            print(text, flush=True)
+        if self.is_main:
+            with open(self.path, 'a') as f:
+                f.write(text + '\n')
+
+    @staticmethod
+    def stamp():
+        return datetime.now().strftime("%Y/%m/%d %H:%M:%S")
+
+
+def dump_args(args, outf):
+    plain = {k: v for k, v in vars(args).items() if isinstance(v, (int, float, str, bool, list, type(None)))}
+    with open(os.path.join(outf, 'args.yaml'), 'w') as f:
+        f.write(yaml.safe_dump(plain, default_flow_style=False))
+
+
+class MetricBook:
+    """Per-frame PSNR / MS-SSIM values of one evaluate() call, kept ON THE DEVICE until a line is printed.
+
+    Slots follow METRIC_NAMES: {pred, quant} x {seen, unseen} x {psnr, ssim}.  `add(model_slot, frame_indices, psnr, ssim)` files a
+    batch under seen / unseen according to the validation index set; `means()` is what the reference calls results_list (mean
+    over frames, one tensor per slot, zeros for an empty slot); with several ranks the means are combined by sum / count
+    all-reduces -- every rank then holds the metrics of the WHOLE clip (the reference computes an all-reduce and drops it)."""
+
+    def __init__(self, val_indices, names=METRIC_NAMES):
+        self.names = list(names)
+        self.val = set(int(i) for i in val_indices)
+        self.vals = [[] for _ in self.names]
+
+    def add(self, model_slot, frame_indices, psnr, ssim):
+        for col, fi in enumerate(frame_indices):
+            base = 4 * model_slot + (2 if int(fi) in self.val else 0)
+            self.vals[base].append(psnr[col:col + 1])
+            self.vals[base + 1].append(ssim[col:col + 1])
+
+    def running(self):
+        return [torch.cat(v).mean().reshape(1).cpu() if v else torch.zeros(1) for v in self.vals]
+
+    def means(self, device=None):
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        out = []
+        for v in self.vals:
+            tot = torch.cat(v).sum().reshape(1).float() if v else torch.zeros(1, device=device)
+            cnt = torch.tensor([float(len(v))], device=tot.device)
+            if world > 1:
+                pack = torch.cat([tot, cnt]).to(device if device is not None else tot.device)
+                dist.all_reduce(pack)
+                tot, cnt = pack[:1], pack[1:]
+            out.append((tot / cnt.clamp(min=1)).cpu())
+        return out
+
+    def describe(self, values, digits=4):
+        return ''.join(f'{n}: {fmt(v, digits)} | ' for n, v in zip(self.names, values))
+
+
+class BestTracker:
+    """Best-so-far value of every metric slot (the reference's best_metric_list)."""
+
+    def __init__(self, names=METRIC_NAMES):
+        self.names = list(names)
+        self.best = [torch.tensor(0) for _ in self.names]
+
+    def update(self, values):
+        for i, v in enumerate(values):
+            top = v.max()
+            if not (self.best[i] > top):
+                self.best[i] = top
+        return self.best
+
+
+def load_initial_state(model, args, outf, strict_resume=True, rename=None):
+    """--weight (a pretrained / regression checkpoint, loaded non-strictly after optional key renaming) and then, unless
+    --not_resume, <outf>/model_latest.pth.  Returns the last checkpoint dict that was loaded (or None) -- its 'epoch' seeds
+    --start_epoch, its 'optimizer' is NOT restored (as in the reference, which restarts the optimizer state)."""
+    ckpt = None
+    if args.weight != 'None':
+        print(f"=> loading checkpoint '{args.weight}'")
+        ckpt = torch.load(args.weight, map_location='cpu')
+        sd = ckpt['state_dict']
+        if rename is not None:
+            sd = {rename(k): v for k, v in sd.items()}
+        model.load_state_dict(sd, strict=False)
+        print(f"=> loaded checkpoint '{args.weight}' (epoch {ckpt['epoch']})")
+    if not args.not_resume:
+        latest = os.path.join(outf, 'model_latest.pth')
+        if os.path.isfile(latest):
+            ckpt = torch.load(latest, map_location='cpu')
+            model.load_state_dict(ckpt['state_dict'], strict=strict_resume)
+            print(f"=> Auto resume loaded checkpoint '{latest}' (epoch {ckpt['epoch']})")
+        else:
+            print(f"=> No resume checkpoint found at '{latest}'")
+    return ckpt
+
+
+class IndexOnly(torch.utils.data.Dataset):
+    """Same length / indices as the full dataset but yields only (idx, norm_idx): the frames themselves stay resident in HBM
+    and are gathered on the device, so the loader (and its shuffling RNG, which the train-order golden pins) moves 16 bytes a step."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        return {'idx': idx, 'norm_idx': float(idx + 1) / self.n}
+
+
+def results_row(args, best, values, psnr_trace):
+    """One row of the results table (epochN.csv / eval.csv): run configuration, sizes, bit accounting, best and final metrics."""
+    g = lambda k, d=0: getattr(args, k, d)
+    sizes = '_'.join(str(round(g(k), 2)) for k in ('encoder_param', 'decoder_param', 'total_param'))
+    row = [('Vid', args.vid), ('CurEpoch', g('cur_epoch')), ('Time', g('train_time')), ('FPS', g('fps')), ('Split', args.data_split),
+           ('Embed', args.embed), ('Crop', args.crop_list), ('Resize', args.resize_list), ('Lr_type', args.lr_type), ('LR (E-3)', args.lr * 1e3),
+           ('Batch', args.batchSize), ('Size (M)', sizes), ('ModelSize', args.modelsize), ('Epoch', args.epochs), ('Loss', args.loss),
+           ('Act', args.act), ('Norm', args.norm), ('FC', args.fc_hw), ('Reduce', args.reduce), ('ENC_type', args.conv_type[0]),
+           ('ENC_strds', args.enc_strd_str), ('KS', args.ks), ('enc_dim', args.enc_dim), ('DEC', args.conv_type[1]),
+           ('DEC_strds', args.dec_strd_str), ('lower_width', args.lower_width), ('Quant', args.quant_str),
+           ('bits/param', g('bits_per_param')), ('bits/param w/ overhead', g('full_bits_per_param')), ('bits/pixel', g('total_bpp')),
+           (f'PSNR_list_{args.eval_freq}', ','.join(fmt(v, 2) for v in psnr_trace))]
+    row += [(f'best_{n}', fmt(v, 4)) for n, v in zip(args.metric_names, best)]
+    row += [(n, fmt(v, 4)) for n, v in zip(args.metric_names, values)]
+    return row
+
+
+def write_results_csv(args, best, values, psnr_trace, filename='results.csv'):
+    row = results_row(args, best, values, psnr_trace)
+    path = os.path.join(args.outf, filename)
+    print(f'results dumped to {path}')
+    with open(path, 'w', newline='') as f:
+        wr = csv.writer(f)
+        wr.writerow([''] + [k for k, _ in row])          # (pandas' index column of the reference's DataFrame.to_csv)
+        wr.writerow([0] + [v for _, v in row])

@@ -9,13 +9,12 @@ MI355X-motivated and listed in DESIGN.md:
   * evaluation metrics of all ranks are combined correctly (the reference drops the all-reduce result, :554-556).
 TensorBoard, GIF dumps and the seaborn histogram branch are reporting-only and optional/absent."""
 import argparse
-import csv
+import copy
 import heapq
 import os
 import random
 import shutil
-from copy import deepcopy
-from datetime import datetime
+import time
 
 import numpy as np
 import torch
@@ -23,13 +22,13 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 import torch.optim as optim
 import torch.utils.data
-import yaml
 from torch.utils.data import Subset
 
-from .engine import TrainStep
 from . import ops
-from .hnerv_utils import (RoundTensor, TransformInput, VideoDataSet, adjust_lr, all_reduce, data_split, msssim_fn_batch,
-                          psnr_fn_batch, quant_tensor, worker_init_fn)
+from . import runtime as rt
+from .dp import GradBucket
+from .engine import TrainStep
+from .hnerv_utils import TransformInput, VideoDataSet, adjust_lr, data_split, loss_fn, psnr_fn_device, quant_tensor, worker_init_fn
 from .model_enerv import ENeRV_Boost
 from .model_hnerv import HNeRV, HNeRV_Boost
 from .model_nerv import NeRV_Boost
@@ -158,31 +157,28 @@ def build_model(args):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    torch.set_printoptions(precision=4)
+    torch.set_printoptions(precision=2)
     if args.debug:
-        args.eval_freq = 1
-        args.outf = 'output/debug'
+        args.eval_freq, args.outf = 1, 'output/debug'
     else:
         args.outf = os.path.join('output', args.outf)
-    args.enc_strd_str, args.dec_strd_str = ','.join([str(x) for x in args.enc_strds]), ','.join([str(x) for x in args.dec_strds])
+    args.enc_strd_str = ','.join(str(x) for x in args.enc_strds)
+    args.dec_strd_str = ','.join(str(x) for x in args.dec_strds)
     args.quant_str = f'quant_M{args.quant_model_bit}_E{args.quant_embed_bit}'
-    args.exp_id = exp_id = f'{args.vid}/Size{args.modelsize}'
-    args.outf = os.path.join(args.outf, exp_id)
+    args.exp_id = f'{args.vid}/Size{args.modelsize}'
+    args.outf = os.path.join(args.outf, args.exp_id)
     if args.overwrite and os.path.isdir(args.outf):
         print('Will overwrite the existing output dir!')
         shutil.rmtree(args.outf)
     os.makedirs(args.outf, exist_ok=True)
-    port = hash(args.exp_id) % 20000 + 10000
-    args.init_method = f'tcp://127.0.0.1:{port}'
-    print(f'init_method: {args.init_method}', flush=True)
-    torch.set_printoptions(precision=2)
     args.ngpus_per_node = torch.cuda.device_count()
-    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:      # launched by torchrun: one process per GPU already
-        args.distributed = True
-        args.ngpus_per_node = int(os.environ["WORLD_SIZE"])
-        args.init_method = "env://"
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world > 1:                                      # launched by torchrun: one process per GPU exists already
+        args.distributed, args.ngpus_per_node, args.init_method = True, env_world, "env://"
         train(int(os.environ.get("LOCAL_RANK", 0)), args)
-    elif args.distributed and args.ngpus_per_node > 1:
+    elif args.distributed and args.ngpus_per_node > 1:     # the reference's own launch form: -d spawns one process per GPU
+        args.init_method = f'tcp://127.0.0.1:{hash(args.exp_id) % 20000 + 10000}'
+        print(f'init_method: {args.init_method}', flush=True)
         mp.spawn(train, nprocs=args.ngpus_per_node, args=(args,))
     else:
         train(None, args)
@@ -192,260 +188,196 @@ def data_to_gpu(x, device):
     return x.to(device, non_blocking=True)
 
 
-class _IndexOnly(torch.utils.data.Dataset):
-    """Same length / indices as the full dataset but returns only (idx, norm_idx): frames stay resident in HBM."""
+_IndexOnly = rt.IndexOnly      # (name kept for the loader-order test)
 
-    def __init__(self, n):
-        self.n = n
 
-    def __len__(self):
-        return self.n
+def _join_process_group(local_rank, args):
+    """-> (world, device).  One process per GPU over RCCL; the per-GPU batch is -b / #GPUs as in the reference (:168)."""
+    if not (args.distributed and args.ngpus_per_node > 1):
+        return 1, torch.device('cuda', local_rank if local_rank is not None else 0)
+    rank = int(os.environ["RANK"]) if args.init_method == "env://" else local_rank
+    dist.init_process_group(backend='nccl', init_method=args.init_method, world_size=args.ngpus_per_node, rank=rank)
+    torch.cuda.set_device(local_rank)
+    world = args.ngpus_per_node
+    if args.batchSize < world:
+        raise ValueError(f"-b {args.batchSize} with {world} GPUs gives a per-GPU batch of 0 (the reference needs -b >= #GPUs)")
+    args.batchSize = args.batchSize // world
+    return world, torch.device('cuda', local_rank)
 
-    def __getitem__(self, idx):
-        return {'idx': idx, 'norm_idx': float(idx + 1) / self.n}
+
+def _make_loaders(args, world):
+    """Full-clip loader (evaluation, unshuffled) and train loader (shuffled, drop_last) in the reference's construction order --
+    the loaders consume the global RNG, and the frame order golden pins it.  With frames resident in HBM the loaders iterate
+    indices only."""
+    full = VideoDataSet(args)
+    args.final_size, args.full_data_length = full.final_size, len(full)
+    resident = not args.host_frames and not full.embed_inter
+    items = rt.IndexOnly(len(full)) if resident else full
+    workers = 0 if resident else args.workers
+    sharded = torch.utils.data.distributed.DistributedSampler
+
+    def loader(ds, batch, train):
+        sampler = sharded(ds) if world > 1 else None
+        return torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=(train and sampler is None), num_workers=workers, pin_memory=True,
+                                           sampler=sampler, drop_last=train, worker_init_fn=worker_init_fn)
+    full_loader = loader(items, args.batchSize, False)
+    train_ids, args.val_ind_list = data_split(list(range(args.full_data_length)), [int(x) for x in args.data_split.split('_')], args.shuffle_data, 0)
+    train_loader = loader(Subset(items, train_ids), args.batchSize, True)
+    return full, full_loader, train_loader, resident
+
+
+def _make_optimizer(model, args):
+    if args.optim_type == "Adam":
+        return optim.Adam(model.parameters(), lr=args.lr)
+    if args.optim_type == "Adan":
+        from .optimizer import Adan
+        return Adan(model.parameters(), lr=args.lr)
+    raise ValueError(f"--optim_type {args.optim_type!r}: pass Adan or Adam (the reference's default 'adan' matches neither of its branches)")
 
 
 def train(local_rank, args):
-    torch.manual_seed(args.manualSeed)
-    np.random.seed(args.manualSeed)
-    random.seed(args.manualSeed)
+    for seed_fn in (torch.manual_seed, np.random.seed, random.seed):
+        seed_fn(args.manualSeed)
     if not torch.cuda.is_available():
         raise RuntimeError("train_nerv_all: no ROCm GPU visible -- the decoder path has no CPU fallback")
-    torch.backends.cudnn.benchmark = True   # train_nerv_all.py:154 (on ROCm: MIOpen solver search for the stock-PyTorch encoder convs)
-    world = 1
-    if args.distributed and args.ngpus_per_node > 1:
-        rank = int(os.environ["RANK"]) if args.init_method == "env://" else local_rank
-        dist.init_process_group(backend='nccl', init_method=args.init_method, world_size=args.ngpus_per_node, rank=rank)
-        torch.cuda.set_device(local_rank)
-        world = args.ngpus_per_node
-        if args.batchSize < world:
-            raise ValueError(f"-b {args.batchSize} with {world} GPUs gives a per-GPU batch of 0 (the reference needs -b >= #GPUs, :168)")
-        args.batchSize = int(args.batchSize / world)
-    is_main = local_rank in [0, None]
-    device = torch.device('cuda', local_rank if local_rank is not None else 0)
+    torch.backends.cudnn.benchmark = True   # as the reference (on ROCm: MIOpen solver search for the encoder's stock convs)
+    world, device = _join_process_group(local_rank, args)
+    is_main = local_rank in (0, None)
+    args.metric_names = list(rt.METRIC_NAMES)
+    best = rt.BestTracker(args.metric_names)
+    log = rt.RunLog(args.outf, is_main)
 
-    args.metric_names = ['pred_seen_psnr', 'pred_seen_ssim', 'pred_unseen_psnr', 'pred_unseen_ssim',
-                         'quant_seen_psnr', 'quant_seen_ssim', 'quant_unseen_psnr', 'quant_unseen_ssim']
-    best_metric_list = [torch.tensor(0) for _ in range(len(args.metric_names))]
-
-    # dataloaders (same construction order as the reference: full loader, split, train loader -- then the model)
-    full_dataset = VideoDataSet(args)
-    args.final_size = full_dataset.final_size
-    args.full_data_length = len(full_dataset)
-    resident = not args.host_frames and not full_dataset.embed_inter
-    loader_ds = _IndexOnly(len(full_dataset)) if resident else full_dataset
-    workers = 0 if resident else args.workers
-    sampler = torch.utils.data.distributed.DistributedSampler(loader_ds) if world > 1 else None
-    full_dataloader = torch.utils.data.DataLoader(loader_ds, batch_size=args.batchSize, shuffle=False, num_workers=workers,
-                                                  pin_memory=True, sampler=sampler, drop_last=False, worker_init_fn=worker_init_fn)
-    split_num_list = [int(x) for x in args.data_split.split('_')]
-    train_ind_list, args.val_ind_list = data_split(list(range(args.full_data_length)), split_num_list, args.shuffle_data, 0)
-    args.dump_vis = (args.dump_images or args.dump_videos)
-    train_dataset = Subset(loader_ds, train_ind_list)
-    train_sampler = torch.utils.data.distributed.DistributedSampler(train_dataset) if world > 1 else None
-    train_dataloader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batchSize, shuffle=(train_sampler is None),
-                                                   num_workers=workers, pin_memory=True, sampler=train_sampler, drop_last=True,
-                                                   worker_init_fn=worker_init_fn)
-
+    full_dataset, full_loader, train_loader, resident = _make_loaders(args, world)
+    args.dump_vis = args.dump_images or args.dump_videos
     args.fc_dim, embed_param = solve_fc_dim(args, args.final_size, args.full_data_length)
     model = build_model(args)
 
-    if is_main:
-        with open(os.path.join(args.outf, 'args.yaml'), 'w') as f:
-            f.write(yaml.safe_dump({k: v for k, v in args.__dict__.items() if isinstance(v, (int, float, str, bool, list, type(None)))},
-                                   default_flow_style=False))
-        encoder_param = (sum([p.data.nelement() for p in model.encoder.parameters()]) / 1e6)
-        decoder_param = model.decoder_params()
-        total_param = decoder_param + embed_param / 1e6
-        args.encoder_param, args.decoder_param, args.total_param = encoder_param, decoder_param, total_param
-        param_str = f'Encoder_{round(encoder_param, 2)}M_Decoder_{round(decoder_param, 4)}M_Total_{round(total_param, 4)}M'
-        print(f'{args}\n {param_str}', flush=True)
-        with open('{}/rank0.txt'.format(args.outf), 'a') as f:
-            f.write(str(model) + '\n' + f'{param_str}\n')
     writer = None
     if is_main:
+        rt.dump_args(args, args.outf)
+        args.encoder_param = sum(p.numel() for p in model.encoder.parameters()) / 1e6
+        args.decoder_param = model.decoder_params()
+        args.total_param = args.decoder_param + embed_param / 1e6
+        sizes = f'Encoder_{round(args.encoder_param, 2)}M_Decoder_{round(args.decoder_param, 4)}M_Total_{round(args.total_param, 4)}M'
+        print(f'{args}\n {sizes}', flush=True)
+        log.line(f'{model}\n{sizes}', echo=False)
         try:
             from torch.utils.tensorboard import SummaryWriter
-            writer = SummaryWriter(os.path.join(args.outf, param_str, 'tensorboard'))
+            writer = SummaryWriter(os.path.join(args.outf, sizes, 'tensorboard'))
         except Exception:
             writer = None
 
-    print("Use GPU: {} for training".format(local_rank))
+    print(f"Use GPU: {local_rank} for training")
     model = model.to(device)
-    if args.optim_type == "Adam":
-        optimizer = optim.Adam(model.parameters(), lr=args.lr)
-    elif args.optim_type == "Adan":
-        from .optimizer import Adan
-        optimizer = Adan(model.parameters(), lr=args.lr)
-    else:
-        raise ValueError(f"--optim_type {args.optim_type!r}: pass Adan or Adam (the reference's default 'adan' matches neither branch, :260-264)")
+    optimizer = _make_optimizer(model, args)
     args.transform_func = TransformInput(args)
-
-    # resume
-    checkpoint = None
-    if args.weight != 'None':
-        print("=> loading checkpoint '{}'".format(args.weight))
-        checkpoint = torch.load(args.weight, map_location='cpu')
-        new_ckt = {k.replace('blocks.0.', '').replace('module.', ''): v for k, v in checkpoint['state_dict'].items()}
-        model.load_state_dict(new_ckt, strict=False)
-        print("=> loaded checkpoint '{}' (epoch {})".format(args.weight, checkpoint['epoch']))
-    if not args.not_resume:
-        checkpoint_path = os.path.join(args.outf, 'model_latest.pth')
-        if os.path.isfile(checkpoint_path):
-            checkpoint = torch.load(checkpoint_path, map_location='cpu')
-            model.load_state_dict(checkpoint['state_dict'])
-            print("=> Auto resume loaded checkpoint '{}' (epoch {})".format(checkpoint_path, checkpoint['epoch']))
-        else:
-            print("=> No resume checkpoint found at '{}'".format(checkpoint_path))
+    ckpt = rt.load_initial_state(model, args, args.outf, rename=lambda k: k.replace('blocks.0.', '').replace('module.', ''))
     if args.start_epoch < 0:
-        if checkpoint is not None:
-            args.start_epoch = checkpoint['epoch']
-        args.start_epoch = max(args.start_epoch, 0)
+        args.start_epoch = max(ckpt['epoch'] if ckpt is not None else 0, 0)
 
-    frames_dev = None
-    if resident:
-        frames_dev = torch.stack([full_dataset[i]['img'] for i in range(len(full_dataset))]).to(device)
-    args._frames_dev = frames_dev
+    args._frames_dev = torch.stack([full_dataset[i]['img'] for i in range(len(full_dataset))]).to(device) if resident else None
 
     if args.eval_only:
-        results_list, hw = evaluate(model, full_dataloader, local_rank, args, args.dump_vis, huffman_coding=True)
-        print_str = f'PSNR for output {hw} for quant {args.quant_str}: '
-        for i, (metric_name, best_metric_value, metric_value) in enumerate(zip(args.metric_names, best_metric_list, results_list)):
-            best_metric_value = best_metric_value if best_metric_value > metric_value.max() else metric_value.max()
-            print_str += f'best_{metric_name}: {RoundTensor(best_metric_value, 2 if "psnr" in metric_name else 4)} | '
-            best_metric_list[i] = best_metric_value
+        values, hw = evaluate(model, full_loader, local_rank, args, args.dump_vis, huffman_coding=True)
+        top = best.update(values)
+        text = f'PSNR for output {hw} for quant {args.quant_str}: ' + ''.join(
+            f'best_{n}: {rt.fmt(v, 2 if "psnr" in n else 4)} | ' for n, v in zip(args.metric_names, top))
         if is_main:
-            print(print_str, flush=True)
-            with open('{}/eval.txt'.format(args.outf), 'a') as f:
-                f.write(print_str + '\n\n')
+            print(text, flush=True)
+            with open(os.path.join(args.outf, 'eval.txt'), 'a') as f:
+                f.write(text + '\n\n')
             args.train_time, args.cur_epoch = 0, args.epochs
-            Dump2CSV(args, best_metric_list, results_list, [torch.tensor(0)], 'eval.csv')
+            rt.write_results_csv(args, top, values, [torch.tensor(0)], 'eval.csv')
         return
 
-    h, w = [int(x) for x in args.crop_list.split('_')[:2]]
+    h, w = (int(x) for x in args.crop_list.split('_')[:2])
     takes_image = 'pe' not in args.embed or "HNeRV_Boost" in args.model
-    step = TrainStep(model, optimizer, args.loss, takes_image, (args.batchSize, 3, h, w), device, use_graph=not args.no_graph and args.optim_type == "Adan",
-                     world_size=world, clip_max_norm=args.clip_max_norm) if args.optim_type == "Adan" and args.transform_func.identity else None
+    fused = args.optim_type == "Adan" and args.transform_func.identity
+    step = TrainStep(model, optimizer, args.loss, takes_image, (args.batchSize, 3, h, w), device, use_graph=not args.no_graph,
+                     world_size=world, clip_max_norm=args.clip_max_norm) if fused else None
+    # the generic path (Adam, inpainting masks) averages its gradients over the ranks with the same flat bucket the fused step uses
+    bucket = GradBucket(model.parameters()) if (step is None and world > 1) else None
 
-    start = datetime.now()
-    time_list, psnr_list = [], []
-    results_list = [torch.zeros(1) for _ in args.metric_names]
+    t_start = time.time()
+    epoch_secs, psnr_trace = [], []
+    values = [torch.zeros(1) for _ in args.metric_names]
+    lr = args.lr
     for epoch in range(args.start_epoch, args.epochs):
         model.train()
-        epoch_start_time = datetime.now()
-        psnr_sum = torch.zeros((), dtype=torch.float32, device=device)      # accumulated on the device: no per-step sync
-        psnr_cnt = 0
-        n_iter = len(train_dataloader)
-        for i, sample in enumerate(train_dataloader):
-            if i > 10 and args.debug:
+        t_epoch = time.time()
+        psnr_sum = torch.zeros((), dtype=torch.float32, device=device)     # accumulated on the device: no per-step host sync
+        seen = 0
+        n_iter = len(train_loader)
+        for i, sample in enumerate(train_loader):
+            if args.debug and i > 10:
                 break
             norm_idx, img_idx = data_to_gpu(sample['norm_idx'], device), data_to_gpu(sample['idx'], device)
-            img_data = frames_dev[img_idx] if resident else data_to_gpu(sample['img'], device)
-            cur_epoch = (epoch + float(i) / n_iter) / args.epochs
-            lr = adjust_lr(optimizer, cur_epoch, i, args)
+            frames = args._frames_dev[img_idx] if resident else data_to_gpu(sample['img'], device)
+            lr = adjust_lr(optimizer, (epoch + float(i) / n_iter) / args.epochs, i, args)
             if step is not None:
-                _, psnr_b = step(img_data, norm_idx)
-            else:      # generic path (Adam, inpainting masks): same kernels, eager
-                img_in, img_gt, inpaint_mask = args.transform_func(img_data, img_idx)
-                cur_input = img_in if takes_image else norm_idx
-                img_out, _, _ = model(cur_input, norm_idx=norm_idx)
-                from .hnerv_utils import loss_fn, psnr_fn_device
-                if inpaint_mask is not None:
-                    final_loss = loss_fn(img_out * inpaint_mask, img_gt * inpaint_mask, args.loss)
-                else:
-                    final_loss = loss_fn(img_out, img_gt, args.loss)
-                optimizer.zero_grad()
-                final_loss.backward()
-                if args.clip_max_norm > 0:
-                    torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_max_norm)
-                optimizer.step()
-                psnr_b = psnr_fn_device(img_out.detach(), img_gt)
+                _, psnr_b = step(frames, norm_idx)
+            else:
+                psnr_b = _generic_step(model, optimizer, bucket, args, frames, img_idx, norm_idx, takes_image)
             psnr_sum += psnr_b.sum()
-            psnr_cnt += psnr_b.numel()
-            if i % args.print_freq == 0 or i == n_iter - 1:
-                pred_psnr = (psnr_sum / psnr_cnt).cpu()          # the only host sync of the loop, every print_freq steps
-                print_str = '[{}] Rank:{}, Epoch[{}/{}], Step [{}/{}], lr:{:.2e} pred_PSNR: {}'.format(
-                    datetime.now().strftime("%Y/%m/%d %H:%M:%S"), local_rank, epoch + 1, args.epochs, i + 1, n_iter, lr, RoundTensor(pred_psnr, 4))
-                print(print_str, flush=True)
-                if is_main:
-                    with open('{}/rank0.txt'.format(args.outf), 'a') as f:
-                        f.write(print_str + '\n')
-        pred_psnr = psnr_sum / max(psnr_cnt, 1)
+            seen += psnr_b.numel()
+            if i % args.print_freq == 0 or i == n_iter - 1:                 # the only host sync of the loop
+                log.line('[{}] Rank:{}, Epoch[{}/{}], Step [{}/{}], lr:{:.2e} pred_PSNR: {}'.format(
+                    log.stamp(), local_rank, epoch + 1, args.epochs, i + 1, n_iter, lr, rt.fmt((psnr_sum / seen).cpu(), 4)))
+        train_psnr = psnr_sum / max(seen, 1)
         if world > 1:
-            pred_psnr = all_reduce([pred_psnr.clone()])[0]
-        pred_psnr = pred_psnr.cpu()
+            dist.all_reduce(train_psnr)
+            train_psnr /= world
         if is_main:
-            epoch_end_time = datetime.now()
+            now = time.time()
             if writer is not None:
-                writer.add_scalar(f'Train/pred_PSNR_{h}X{w}', pred_psnr, epoch + 1)
+                writer.add_scalar(f'Train/pred_PSNR_{h}X{w}', train_psnr.cpu(), epoch + 1)
                 writer.add_scalar('Train/lr', lr, epoch + 1)
-            print("Time/epoch: \tCurrent:{:.2f} \tAverage:{:.2f}".format((epoch_end_time - epoch_start_time).total_seconds(),
-                                                                        (epoch_end_time - start).total_seconds() / (epoch + 1 - args.start_epoch)))
-            time_list.append((epoch_end_time - epoch_start_time).total_seconds())
+            print("Time/epoch: \tCurrent:{:.2f} \tAverage:{:.2f}".format(now - t_epoch, (now - t_start) / (epoch + 1 - args.start_epoch)))
+            epoch_secs.append(now - t_epoch)
 
-        if (epoch + 1) % args.eval_freq == 0 or (args.epochs - epoch) in [1, 3, 5]:
-            results_list, hw = evaluate(model, full_dataloader, local_rank, args, args.dump_vis if epoch == args.epochs - 1 else False,
-                                        True if epoch == args.epochs - 1 else False)
+        last = epoch == args.epochs - 1
+        if (epoch + 1) % args.eval_freq == 0 or (args.epochs - epoch) in (1, 3, 5):
+            values, hw = evaluate(model, full_loader, local_rank, args, args.dump_vis and last, last)
             if is_main:
-                print_str = f'Eval at epoch {epoch + 1} for {hw}: '
-                for i, (metric_name, best_metric_value, metric_value) in enumerate(zip(args.metric_names, best_metric_list, results_list)):
-                    best_metric_value = best_metric_value if best_metric_value > metric_value.max() else metric_value.max()
-                    if 'psnr' in metric_name:
-                        if writer is not None:
-                            writer.add_scalar(f'Val/{metric_name}_{hw}', metric_value.max(), epoch + 1)
-                            writer.add_scalar(f'Val/best_{metric_name}_{hw}', best_metric_value, epoch + 1)
-                        if metric_name == 'pred_seen_psnr':
-                            psnr_list.append(metric_value.max())
-                    print_str += f'{metric_name}: {RoundTensor(metric_value, 4)} | '
-                    best_metric_list[i] = best_metric_value
-                print(print_str, flush=True)
-                with open('{}/rank0.txt'.format(args.outf), 'a') as f:
-                    f.write(print_str + '\n')
+                top = best.update(values)
+                for name, v, b in zip(args.metric_names, values, top):
+                    if 'psnr' in name and writer is not None:
+                        writer.add_scalar(f'Val/{name}_{hw}', v.max(), epoch + 1)
+                        writer.add_scalar(f'Val/best_{name}_{hw}', b, epoch + 1)
+                psnr_trace.append(values[args.metric_names.index('pred_seen_psnr')].max())
+                log.line(f'Eval at epoch {epoch + 1} for {hw}: ' + ''.join(f'{n}: {rt.fmt(v, 4)} | ' for n, v in zip(args.metric_names, values)))
 
         if is_main:
-            torch.save({'epoch': epoch + 1, 'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict()},
-                       '{}/model_latest.pth'.format(args.outf))
-            if (epoch + 1) % args.epochs == 0:
-                args.cur_epoch = epoch + 1
-                args.train_time = str(datetime.now() - start)
-                Dump2CSV(args, best_metric_list, results_list, psnr_list, f'epoch{epoch + 1}.csv')
+            state = {'epoch': epoch + 1, 'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict()}
+            torch.save(state, os.path.join(args.outf, 'model_latest.pth'))
+            if last:
+                args.cur_epoch, args.train_time = epoch + 1, rt.hms(time.time() - t_start)
+                rt.write_results_csv(args, best.best, values, psnr_trace, f'epoch{epoch + 1}.csv')
 
-    print_str = "Training complete in: " + str(datetime.now() - start)
-    total_time_seconds = float(sum(time_list))
-    print_str += "\n Training wo evaluation complete in: {}, {}s".format(convert(total_time_seconds), total_time_seconds)
-    print(print_str)
+    total = float(sum(epoch_secs))
+    text = f"Training complete in: {rt.hms(time.time() - t_start)}\n Training wo evaluation complete in: {rt.hms(total)}, {total}s"
+    print(text)
     if is_main:
-        with open('{}/rank0.txt'.format(args.outf), 'a') as f:
-            f.write(print_str + '\n')
+        log.line(text, echo=False)
     if world > 1:
         dist.destroy_process_group()
 
 
-def convert(seconds):
-    seconds = seconds % (24 * 3600)
-    hour = seconds // 3600
-    seconds %= 3600
-    return "%d:%02d:%02d" % (hour, seconds // 60, seconds % 60)
-
-
-def Dump2CSV(args, best_results_list, results_list, psnr_list, filename='results.csv'):
-    g = lambda k, d=0: getattr(args, k, d)
-    result_dict = {'Vid': args.vid, 'CurEpoch': g('cur_epoch'), 'Time': g('train_time'), 'FPS': g('fps'), 'Split': args.data_split,
-                   'Embed': args.embed, 'Crop': args.crop_list, 'Resize': args.resize_list, 'Lr_type': args.lr_type, 'LR (E-3)': args.lr * 1e3,
-                   'Batch': args.batchSize, 'Size (M)': f'{round(g("encoder_param"), 2)}_{round(g("decoder_param"), 2)}_{round(g("total_param"), 2)}',
-                   'ModelSize': args.modelsize, 'Epoch': args.epochs, 'Loss': args.loss, 'Act': args.act, 'Norm': args.norm, 'FC': args.fc_hw,
-                   'Reduce': args.reduce, 'ENC_type': args.conv_type[0], 'ENC_strds': args.enc_strd_str, 'KS': args.ks, 'enc_dim': args.enc_dim,
-                   'DEC': args.conv_type[1], 'DEC_strds': args.dec_strd_str, 'lower_width': args.lower_width, 'Quant': args.quant_str,
-                   'bits/param': g('bits_per_param'), 'bits/param w/ overhead': g('full_bits_per_param'), 'bits/pixel': g('total_bpp'),
-                   f'PSNR_list_{args.eval_freq}': ','.join([RoundTensor(v, 2) for v in psnr_list])}
-    result_dict.update({f'best_{k}': RoundTensor(v, 4) for k, v in zip(args.metric_names, best_results_list)})
-    result_dict.update({f'{k}': RoundTensor(v, 4) for k, v in zip(args.metric_names, results_list)})
-    csv_path = os.path.join(args.outf, filename)
-    print(f'results dumped to {csv_path}')
-    with open(csv_path, 'w', newline='') as f:
-        wr = csv.writer(f)
-        wr.writerow([''] + list(result_dict.keys()))
-        wr.writerow([0] + list(result_dict.values()))
+def _generic_step(model, optimizer, bucket, args, frames, img_idx, norm_idx, takes_image):
+    """One eager step for the configurations the captured step does not cover (--optim_type Adam, --inpanting masks): the same
+    kernels, driven op by op.  With several ranks the gradients are averaged through the flat bucket before clipping / the step
+    (the reference gets this from its DistributedDataParallel wrap)."""
+    img_in, img_gt, mask = args.transform_func(frames, img_idx)
+    out, _, _ = model(img_in if takes_image else norm_idx, norm_idx=norm_idx)
+    loss = loss_fn(out, img_gt, args.loss) if mask is None else loss_fn(out * mask, img_gt * mask, args.loss)
+    optimizer.zero_grad()
+    loss.backward()
+    if bucket is not None:
+        bucket.allreduce_mean()
+    if args.clip_max_norm > 0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_max_norm)
+    optimizer.step()
+    return psnr_fn_device(out.detach(), img_gt)
 
 
 def _huffman_total_bits(counts):
@@ -467,152 +399,125 @@ def _huffman_total_bits(counts):
     return sum(int(c) * d for c, d in zip(counts, depth[:n]))
 
 
+def quant_model(model, args):
+    """[fp32 copy, post-hoc quantised twin], {key: quantised tensor record} -- the two models evaluate() reports on
+    (reference train_nerv_all.py:622-642).  Every decoder tensor goes through hnerv_utils.quant_tensor at --quant_model_bit bits;
+    the encoder is left alone (it is not part of the transmitted model).  --quant_model_bit -1 disables the twin."""
+    plain = copy.deepcopy(model)
+    if args.quant_model_bit == -1:
+        return [plain], None
+    twin = copy.deepcopy(model)
+    records, dequantised = {}, {}
+    for key, tensor in twin.state_dict().items():
+        if 'encoder' in key:
+            dequantised[key] = tensor
+        else:
+            records[key], dequantised[key] = quant_tensor(tensor, args.quant_model_bit)
+    twin.load_state_dict(dequantised)
+    return [plain, twin], records
+
+
+def _timed_decodes(net, cur_input, embed, norm_idx, graph):
+    """100 repeated decodes of one batch for --eval_fps; a captured hipGraph of the same forward unless BNERV_EVAL_GRAPH=0."""
+    times = []
+    if cur_input.is_cuda and os.environ.get('BNERV_EVAL_GRAPH', '1') != '0':
+        from .engine import DecodeGraph
+        if graph is None or not graph.matches(cur_input, embed, norm_idx):
+            graph = DecodeGraph(net, cur_input, embed, norm_idx)
+        for _ in range(100):
+            times.append(graph(cur_input, embed, norm_idx)[1])
+    else:
+        for _ in range(100):
+            times.append(net(cur_input, embed, norm_idx=norm_idx)[2])
+    return times, graph
+
+
 @torch.no_grad()
 def evaluate(model, full_dataloader, local_rank, args, dump_vis=False, huffman_coding=False):
-    img_embed_list = []
-    model_list, quant_ckt = quant_model(model, args)
-    metric_list = [[] for _ in range(len(args.metric_names))]
+    """PSNR / MS-SSIM of the fp32 model and of its post-hoc quantised twin over the whole clip (seen / unseen frames apart),
+    decode FPS, and -- on request -- the Huffman bit accounting of the quantised tensors.  Returns (values per metric slot, (h, w))."""
+    nets, records = quant_model(model, args)
+    book = rt.MetricBook(args.val_ind_list, args.metric_names)
+    log = rt.RunLog(args.outf, local_rank in (0, None))
     frames_dev = getattr(args, '_frames_dev', None)
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    dequant_vid_embed = None
+    takes_image = 'pe' not in args.embed or "HNeRV_Boost" in args.model
+    is_hnerv = "HNeRV" in args.model
+    embeds, dequant_embeds, quant_embed = [], None, None
     fps, hw = 0.0, (0, 0)
-    for model_ind, cur_model in enumerate(model_list):
-        time_list = []
-        decode_graph = None
-        cur_model.eval()
-        cur_model.time_decode = True
-        device = next(cur_model.parameters()).device
+    for slot, net in enumerate(nets):
+        net.eval()
+        net.time_decode = True
+        device = next(net.parameters()).device
+        times, graph = [], None
+        vis_dir = None
         if dump_vis:
-            visual_dir = f'{args.outf}/visualize_model' + ('_quant' if model_ind else '_orig')
-            os.makedirs(visual_dir, exist_ok=True)
+            vis_dir = os.path.join(args.outf, 'visualize_model' + ('_quant' if slot else '_orig'))
+            os.makedirs(vis_dir, exist_ok=True)
+        n_batches = len(full_dataloader)
         for i, sample in enumerate(full_dataloader):
-            if i > 10 and args.debug:
+            if args.debug and i > 10:
                 break
             norm_idx, img_idx = data_to_gpu(sample['norm_idx'], device), data_to_gpu(sample['idx'], device)
-            img_data = frames_dev[img_idx] if frames_dev is not None else data_to_gpu(sample['img'], device)
-            img_data, img_gt, inpaint_mask = args.transform_func(img_data, img_idx)
-            takes_image = 'pe' not in args.embed or "HNeRV_Boost" in args.model
-            cur_input = img_data if takes_image else norm_idx
-            embed_in = dequant_vid_embed[i] if model_ind and "HNeRV" in args.model else None
+            frames = frames_dev[img_idx] if frames_dev is not None else data_to_gpu(sample['img'], device)
+            img_in, img_gt, _mask = args.transform_func(frames, img_idx)
+            cur_input = img_in if takes_image else norm_idx
+            embed_in = dequant_embeds[i] if (slot and is_hnerv) else None
+            extra = {}
             if args.interpolation and args.embed_inter and 'pre_img' in sample and img_idx.item() in args.val_ind_list:
-                img_out, embed_list, dec_time = cur_model(cur_input, embed_in, pre_img=data_to_gpu(sample['pre_img'], device),
-                                                          post_img=data_to_gpu(sample['post_img'], device), norm_idx=norm_idx)
-            else:
-                img_out, embed_list, dec_time = cur_model(cur_input, embed_in, norm_idx=norm_idx)
-            if model_ind == 0:
-                img_embed_list.append(embed_list[0])
-            time_list.append(dec_time)
+                extra = dict(pre_img=data_to_gpu(sample['pre_img'], device), post_img=data_to_gpu(sample['post_img'], device))
+            out, embed_list, dec_time = net(cur_input, embed_in, norm_idx=norm_idx, **extra)
+            if slot == 0:
+                embeds.append(embed_list[0])
             if args.eval_fps:
-                time_list.pop()
-                # row N4: the 100 timing decodes replay a captured hipGraph of the same forward (BNERV_EVAL_GRAPH=0: eager, as the reference)
-                if img_out.is_cuda and os.environ.get('BNERV_EVAL_GRAPH', '1') != '0':
-                    from .engine import DecodeGraph
-                    if decode_graph is None or not decode_graph.matches(cur_input, embed_list[0], norm_idx):
-                        decode_graph = DecodeGraph(cur_model, cur_input, embed_list[0], norm_idx)
-                    for _ in range(100):
-                        _, dec_time = decode_graph(cur_input, embed_list[0], norm_idx)
-                        time_list.append(dec_time)
-                else:
-                    for _ in range(100):
-                        _, _, dec_time = cur_model(cur_input, embed_list[0], norm_idx=norm_idx)
-                        time_list.append(dec_time)
-            # metrics stay on the device (row N4): no per-frame .cpu(); they are read when a line is printed and at the end
-            pred_psnr, pred_ssim = ops.psnr(img_out, img_gt)[None], ops.msssim(img_out.float(), img_gt)[None]
-            for metric_idx, cur_v in enumerate([pred_psnr, pred_ssim]):
-                for batch_i, cur_img_idx in enumerate(sample['idx'].tolist()):      # the loader's host copy: no device sync
-                    metric_idx_start = 2 if cur_img_idx in args.val_ind_list else 0
-                    metric_list[metric_idx_start + metric_idx + 4 * model_ind].append(cur_v[:, batch_i])
-            if dump_vis:
-                _save_images(img_out, img_idx, pred_psnr, visual_dir, i, args)
-            if i % args.print_freq == 0 or i == len(full_dataloader) - 1:
-                fps = args.batchSize / (sum(time_list) / len(time_list))
-                print_str = '[{}] Rank:{}, Eval at Step [{}/{}] , FPS {}, '.format(datetime.now().strftime("%Y/%m/%d %H:%M:%S"), local_rank, i + 1,
-                                                                                   len(full_dataloader), round(fps, 1))
-                for v_name, v_list in zip(args.metric_names, metric_list):
-                    cur_value = torch.stack(v_list, dim=-1).mean(-1).cpu() if len(v_list) else torch.zeros(1)
-                    print_str += f'{v_name}: {RoundTensor(cur_value, 4)} | '
-                if local_rank in [0, None]:
-                    print(print_str, flush=True)
-                    with open('{}/rank0.txt'.format(args.outf), 'a') as f:
-                        f.write(print_str + '\n')
-        if model_ind == 0:
-            if "HNeRV" in args.model:
-                vid_embed = torch.cat(img_embed_list, 0)
-                quant_embed, dequant_emved = quant_tensor(vid_embed, args.quant_embed_bit)
-                dequant_vid_embed = dequant_emved.split(args.batchSize, dim=0)
+                more, graph = _timed_decodes(net, cur_input, embed_list[0], norm_idx, graph)
+                times.extend(more)
             else:
-                quant_embed = None
-        args.fps = fps
-        hw = tuple(img_data.shape[-2:])
-        cur_model.time_decode = False
-        cur_model.train()
-    # mean of per-frame values (== the reference's results_list, :550), combined over ranks by sum/count
-    results_list = []
-    for v_list in metric_list:
-        if len(v_list):
-            s = torch.stack(v_list, dim=1).sum(1).cpu()
-            n = torch.tensor([float(len(v_list))])
-        else:
-            s, n = torch.zeros(1), torch.zeros(1)
-        if world > 1:
-            dev = next(model.parameters()).device
-            s, n = s.to(dev), n.to(dev)
-            dist.all_reduce(s)
-            dist.all_reduce(n)
-            s, n = s.cpu(), n.cpu()
-        results_list.append(s / n.clamp(min=1))
-
-    if local_rank in [0, None] and quant_ckt is not None and huffman_coding:
-        quant_v_list, tmin_scale_len = [], 0
-        if "HNeRV" in args.model and quant_embed is not None:
-            quant_v_list.append(quant_embed['quant'].flatten().cpu())
-            tmin_scale_len += quant_embed['min'].nelement() + quant_embed['scale'].nelement()
-        for k, layer_wt in quant_ckt.items():
-            quant_v_list.append(layer_wt['quant'].flatten().cpu())
-            tmin_scale_len += layer_wt['min'].nelement() + layer_wt['scale'].nelement()
-        allv = torch.cat(quant_v_list).to(torch.int64)
-        counts = torch.bincount(allv, minlength=1)
-        counts = counts[counts > 0].tolist()
-        total_bits = _huffman_total_bits(counts)
-        args.bits_per_param = total_bits / allv.numel()
-        total_bits += tmin_scale_len * 16
-        args.full_bits_per_param = total_bits / allv.numel()
-        args.total_bpp = total_bits / args.final_size / args.full_data_length
-        print_str = f'After quantization and encoding: \n bits per parameter: {round(args.full_bits_per_param, 2)}, bits per pixel: {round(args.total_bpp, 4)}'
-        print(print_str, flush=True)
-        with open('{}/rank0.txt'.format(args.outf), 'a') as f:
-            f.write(print_str + '\n')
-    return results_list, hw
+                times.append(dec_time)
+            psnr, ssim = ops.psnr(out, img_gt), ops.msssim(out.float(), img_gt)     # stay on the device until a line is printed
+            book.add(slot, sample['idx'].tolist(), psnr, ssim)
+            if dump_vis:
+                _save_images(out, psnr, vis_dir, i, args)
+            if i % args.print_freq == 0 or i == n_batches - 1:
+                fps = args.batchSize / (sum(times) / len(times))
+                log.line(f'[{log.stamp()}] Rank:{local_rank}, Eval at Step [{i + 1}/{n_batches}] , FPS {round(fps, 1)}, ' + book.describe(book.running()),
+                         every_rank=False)
+        if slot == 0 and is_hnerv:
+            quant_embed, deq = quant_tensor(torch.cat(embeds, 0), args.quant_embed_bit)
+            dequant_embeds = deq.split(args.batchSize, dim=0)
+        args.fps, hw = fps, tuple(frames.shape[-2:])
+        net.time_decode = False
+        net.train()
+    values = book.means(device=next(model.parameters()).device)
+    if local_rank in (0, None) and records is not None and huffman_coding:
+        _huffman_report(args, records, quant_embed if is_hnerv else None, log)
+    return values, hw
 
 
-def _save_images(img_out, img_idx, pred_psnr, visual_dir, i, args):
+def _huffman_report(args, records, quant_embed, log):
+    """Bits per parameter / per pixel of the post-hoc quantised tensors under one Huffman code over all symbols, plus 16 bits for
+    every stored (min, scale) entry (reference train_nerv_all.py:577-612)."""
+    symbols, side_entries = [], 0
+    for rec in ([quant_embed] if quant_embed is not None else []) + list(records.values()):
+        symbols.append(rec['quant'].flatten().cpu())
+        side_entries += rec['min'].nelement() + rec['scale'].nelement()
+    flat = torch.cat(symbols).to(torch.int64)
+    hist = torch.bincount(flat, minlength=1)
+    bits = _huffman_total_bits(hist[hist > 0].tolist())
+    args.bits_per_param = bits / flat.numel()
+    bits += side_entries * 16
+    args.full_bits_per_param = bits / flat.numel()
+    args.total_bpp = bits / args.final_size / args.full_data_length
+    log.line(f'After quantization and encoding: \n bits per parameter: {round(args.full_bits_per_param, 2)}, bits per pixel: {round(args.total_bpp, 4)}')
+
+
+def _save_images(out, psnr, vis_dir, batch_no, args):
     from PIL import Image
-    for batch_ind in range(img_out.shape[0]):
-        full_ind = i * args.batchSize + batch_ind
-        psnr_s = ','.join([str(round(x[batch_ind].item(), 2)) for x in pred_psnr])
-        arr = (img_out[batch_ind].clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
-        Image.fromarray(arr).save(f'{visual_dir}/pred_{full_ind:04d}_{psnr_s}.png')
+    for b in range(out.shape[0]):
+        arr = (out[b].clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+        Image.fromarray(arr).save(os.path.join(vis_dir, f'pred_{batch_no * args.batchSize + b:04d}_{round(psnr[b].item(), 2)}.png'))
 
 
-def quant_model(model, args):                                                         # reference train_nerv_all.py:622-642
-    model_list = [deepcopy(model)]
-    if args.quant_model_bit == -1:
-        return model_list, None
-    cur_model = deepcopy(model)
-    quant_ckt, cur_ckt = [cur_model.state_dict() for _ in range(2)]
-    encoder_k_list = []
-    for k, v in cur_ckt.items():
-        if 'encoder' in k:
-            encoder_k_list.append(k)
-        else:
-            quant_v, new_v = quant_tensor(v, args.quant_model_bit)
-            quant_ckt[k] = quant_v
-            cur_ckt[k] = new_v
-    for encoder_k in encoder_k_list:
-        del quant_ckt[encoder_k]
-    cur_model.load_state_dict(cur_ckt)
-    model_list.append(cur_model)
-    return model_list, quant_ckt
+Dump2CSV = rt.write_results_csv      # (the reference's name for the results table writer)
 
 
 if __name__ == '__main__':

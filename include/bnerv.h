@@ -222,6 +222,21 @@ int bnerv_cem_scale_fwd(void* stream, const bnerv_cem_chunk* chunk, float* stats
 int bnerv_cem_scale_bwd(void* stream, const bnerv_cem_chunk_bwd* chunk, const float* stats, const float* d_bits, float* dscale);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Range-ANS entropy coder of the compression report (HOST buffers; csrc/ans.cpp).  Replaces constriction's AnsCoder +
+ * QuantizedGaussian / Categorical models behind `real_bitrate` (lib/entropy_model.py:46-62, :65-81; consumed at
+ * train_nerv_compression.py:484-512, 560-577): rANS, 64-bit state, 32-bit words, 24-bit probabilities, symbols pushed in
+ * reverse so that decoding yields them in message order.
+ *   *_encode_*  returns the number of 32-bit words of the compressed message (also when out == NULL or cap_words is too small:
+ *               nothing is written then), or -1 on a bad argument (bnerv_last_error()).
+ *   *_decode_*  the inverse; BNERV_OK or an error code.
+ *   gaussian:    integer symbols in [min_sym, max_sym] under the leaky quantised Gaussian(mean, std) on that support
+ *   categorical: symbols 0 .. K-1 under probs[K] (any non-negative weights; normalised internally) */
+long bnerv_ans_encode_gaussian(const int32_t* symbols, size_t n, int32_t min_sym, int32_t max_sym, double mean, double std, uint32_t* out, size_t cap_words);
+int bnerv_ans_decode_gaussian(const uint32_t* words, size_t n_words, size_t n, int32_t min_sym, int32_t max_sym, double mean, double std, int32_t* symbols_out);
+long bnerv_ans_encode_categorical(const int32_t* symbols, size_t n, const double* probs, int K, uint32_t* out, size_t cap_words);
+int bnerv_ans_decode_categorical(const uint32_t* words, size_t n_words, size_t n, const double* probs, int K, int32_t* symbols_out);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Depthwise KxK convolution (K odd <= 7, stride 1, padding K/2) of the ConvNeXt encoder block of HNeRV_Boost
  * (model_blocks.py:223-247: nn.Conv2d(dim, dim, 7, padding=3, groups=dim)); first kernels of SURVEY 8(f) row N3.
  *   bnerv_dwconv_fwd(flip=0): y = conv(x, w) + bias;   flip=1: the data gradient (taps flipped, bias ignored: pass g as x)

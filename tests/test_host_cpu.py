@@ -272,3 +272,64 @@ def test_cem_model_surface_matches_reference():
     assert a.quant and a.quantizer_e == "scalebeta" and a.lambda_rate == 0.05 and a.target_bit == 4 and a.embed_entropy
     with pytest.raises(NotImplementedError):
         quant_map["lsq"](8, signed=True)
+
+
+# ------------------------------------------------------------------------------------------------------------ ANS coder (row N2)
+def test_ans_coder_roundtrip_and_rate_on_cem_golden_symbols():
+    """The range-ANS coder behind `real_bitrate` (csrc/ans.cpp through the C-ABI; host code, runs without a GPU): on the rounded
+    symbols the REFERENCE's quantisers produced (tests/golden/cem.npz) and under the Gaussian the reference's rate model fits to
+    them, decode(encode(x)) is bit-exact and the message is within 1 % + 64 bits of the ideal code length."""
+    from boosting_nerv_amd.lib import entropy_model as em
+    npz = load_golden("cem.npz")
+    for name in ("w", "b"):
+        quant = torch.from_numpy(npz[f"scale/{name}/quant"])
+        mean, std = float(npz[f"rate/{name}/mean"]), float(npz[f"rate/{name}/std"])
+        sym = quant.int().flatten().numpy()
+        lo, hi = int(sym.min()), int(sym.max())
+        words = em.ans_encode_gaussian(sym, lo, hi, mean, std)
+        back = em.ans_decode_gaussian(words, sym.size, lo, hi, mean, std)
+        assert np.array_equal(back, sym), name
+        ideal = em.ideal_code_bits(quant, torch.tensor(mean), torch.tensor(std))
+        assert ideal <= words.size * 32 <= 1.01 * ideal + 64, (name, words.size * 32, ideal)
+        assert em.compress_matrix_flatten_gaussian_global(quant, torch.tensor(mean), torch.tensor(std)) == words.size * 32
+    # the embedding quantiser's symbols (unsigned, wide support)
+    q = torch.from_numpy(npz["scalebeta/quant"])
+    code = torch.from_numpy(npz["scalebeta/code"])
+    sym = q.int().flatten().numpy()
+    words = em.ans_encode_gaussian(sym, int(sym.min()), int(sym.max()), float(code.mean()), float(code.std()))
+    assert np.array_equal(em.ans_decode_gaussian(words, sym.size, int(sym.min()), int(sym.max()), float(code.mean()), float(code.std())), sym)
+    ideal = em.ideal_code_bits(q, code.mean(), code.std())
+    assert ideal <= words.size * 32 <= 1.01 * ideal + 64
+
+
+def test_ans_coder_edge_cases():
+    """Empty message, one symbol, a constant tensor (min == max -> the reference widens the support by one), a degenerate
+    Gaussian (std at the 1e-5 clamp: every symbol off the mean costs the 24-bit leak), symbols outside the support (error),
+    a long random message, and the categorical model on a skewed histogram."""
+    from boosting_nerv_amd import _lib as L
+    from boosting_nerv_amd.lib import entropy_model as em
+    assert em.ans_encode_gaussian(np.zeros(0, np.int32), 0, 1, 0.0, 1.0).size == 0
+    assert em.ans_decode_gaussian(np.zeros(0, np.uint32), 0, 0, 1, 0.0, 1.0).size == 0
+    one = em.ans_encode_gaussian(np.array([3], np.int32), -4, 4, 0.5, 2.0)
+    assert 1 <= one.size <= 2 and em.ans_decode_gaussian(one, 1, -4, 4, 0.5, 2.0)[0] == 3
+    const = torch.full((1000,), 7.0)
+    assert em.compress_matrix_flatten_gaussian_global(const, const.mean(), const.std()) <= 64          # ~0 bits per symbol
+    sym = np.array([0, 0, 5, -5, 0], np.int32)
+    w = em.ans_encode_gaussian(sym, -5, 5, 0.0, 1e-5)
+    assert np.array_equal(em.ans_decode_gaussian(w, 5, -5, 5, 0.0, 1e-5), sym) and 32 < w.size * 32 <= 2 * 24 + 64
+    with pytest.raises(L.BnervError):
+        em.ans_encode_gaussian(np.array([9], np.int32), -4, 4, 0.0, 1.0)
+    with pytest.raises(L.BnervError):
+        em.ans_decode_gaussian(np.array([123456789, 42], np.uint32), 50, -4, 4, 0.0, 1.0)     # garbage does not decode silently
+    g = np.random.RandomState(3)
+    big = np.clip(np.rint(g.normal(2.0, 9.0, size=200000)), -128, 127).astype(np.int32)
+    w = em.ans_encode_gaussian(big, -128, 127, float(big.mean()), float(big.std()))
+    assert np.array_equal(em.ans_decode_gaussian(w, big.size, -128, 127, float(big.mean()), float(big.std())), big)
+    ideal = em.ideal_code_bits(torch.from_numpy(big).float(), torch.tensor(float(big.mean())), torch.tensor(float(big.std())))
+    assert ideal <= w.size * 32 <= 1.01 * ideal + 64
+    vals = g.choice([0, 1, 2, 3, 200], p=[0.6, 0.2, 0.1, 0.09, 0.01], size=50000)
+    words, counts, unique = em.compress_matrix_flatten_categorical(vals)
+    inv = np.searchsorted(unique, vals).astype(np.int32)
+    assert np.array_equal(em.ans_decode_categorical(words, vals.size, counts / counts.sum()), inv)
+    h = -(counts * np.log2(counts / counts.sum())).sum()
+    assert h <= words.size * 32 <= 1.01 * h + 64
