@@ -36,14 +36,14 @@ class ConvDesc(C.Structure):
                 ("aux2", _fp), ("scale", _fp), ("shift", _fp), ("partial", _fp),
                 ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("H", C.c_int), ("W", C.c_int), ("k", C.c_int),
                 ("in_mode", C.c_int), ("ep_mode", C.c_int), ("in_s", C.c_int), ("out_s", C.c_int),
-                ("transposed", C.c_int), ("wCo", C.c_int), ("wCi", C.c_int)]
+                ("transposed", C.c_int), ("wCo", C.c_int), ("wCi", C.c_int), ("ctx", _fp)]
 
 
 class WgradDesc(C.Structure):
     _fields_ = [("x", _fp), ("g", _fp), ("gaux", _fp), ("scale", _fp), ("shift", _fp), ("dw", _fp), ("db", _fp),
                 ("ws", _fp), ("ws_bytes", C.c_size_t),
                 ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("H", C.c_int), ("W", C.c_int), ("k", C.c_int),
-                ("in_mode", C.c_int), ("g_mode", C.c_int), ("g_s", C.c_int), ("defer_finish", C.c_int)]
+                ("in_mode", C.c_int), ("g_mode", C.c_int), ("g_s", C.c_int), ("defer_finish", C.c_int), ("ctx", _fp)]
 
 
 class LossDesc(C.Structure):
@@ -101,9 +101,11 @@ SYMBOLS = {
     "bnerv_sft_affine_fwd": (_I, [_V, _V, _V, _V, _V, _I, _I, _I]),
     "bnerv_sft_affine_bwd": (_I, [_V, _V, _V, _V, _V, _V, _I, _I, _I]),
     "bnerv_reduce_slabs": (_I, [_V, _V, _I, _I, _V]),
-    "bnerv_reduce_slabs_deferred": (_I, [_V, _I, _I, _V]),
-    "bnerv_flush_deferred": (_I, [_V]),
-    "bnerv_deferred_pending": (_I, []),
+    "bnerv_ctx_create": (_I, [C.POINTER(C.c_void_p)]),
+    "bnerv_ctx_destroy": (None, [_V]),
+    "bnerv_reduce_slabs_deferred": (_I, [_V, _V, _V, _I, _I, _V]),
+    "bnerv_flush_deferred": (_I, [_V, _V]),
+    "bnerv_deferred_pending": (_I, [_V]),
     "bnerv_conv_tiles": (_I, [_I, _I]),
     "bnerv_conv_igemm": (_I, [_V, C.POINTER(ConvDesc)]),
     "bnerv_conv_splitk_ws_bytes": (_Z, [C.POINTER(ConvDesc)]),
@@ -118,7 +120,7 @@ SYMBOLS = {
     "bnerv_ans_decode_categorical": (_I, [_V, _Z, _Z, _V, _I, _V]),
     "bnerv_dwconv_fwd": (_I, [_V, _V, _V, _V, _V, _I, _I, _I, _I, _I, _I]),
     "bnerv_dwconv_wgrad_ws_bytes": (_Z, [_I, _I, _I, _I, _I]),
-    "bnerv_dwconv_wgrad": (_I, [_V, _V, _V, _V, _V, _Z, _I, _I, _I, _I, _I, _I]),
+    "bnerv_dwconv_wgrad": (_I, [_V, _V, _V, _V, _V, _Z, _I, _I, _I, _I, _I, _V]),
     "bnerv_lncf_fwd": (_I, [_V, _V, _V, _V, _V, _I, _I, _I, _F]),
     "bnerv_lncf_bwd_ws_bytes": (_Z, [_I, _I, _I]),
     "bnerv_lncf_bwd": (_I, [_V, _V, _V, _V, _V, _V, _V, _Z, _I, _I, _I, _F]),
@@ -134,6 +136,7 @@ SYMBOLS = {
 }
 
 _lib = None
+ABI_VERSION = 2
 
 
 class BnervError(RuntimeError):
@@ -154,7 +157,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header and library out of sync
         fn.restype = res
         fn.argtypes = args
-    if lib.bnerv_abi_version() != 1:
+    if lib.bnerv_abi_version() != ABI_VERSION:
         raise BnervError(f"ABI version mismatch: {lib.bnerv_abi_version()}")
     _lib = lib
     return lib
@@ -186,3 +189,34 @@ def f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()
+
+
+class StreamContext:
+    """The deferred-reduction context (include/bnerv.h, bnerv_ctx) of one HIP stream, plus the workspaces its queued jobs still
+    read.  The library keeps no global queue: whoever launches on a stream passes that stream's context."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(load().bnerv_ctx_create(C.byref(h)), "bnerv_ctx_create")
+        self.handle = h
+        self.keep = []
+
+    def __del__(self):
+        try:
+            if _lib is not None and self.handle:
+                _lib.bnerv_ctx_destroy(self.handle)
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def ctx():
+    """Context of torch's current stream (created on first use; one per (device, stream))."""
+    st = torch.cuda.current_stream()
+    key = (st.device_index, st.cuda_stream)
+    c = _contexts.get(key)
+    if c is None:
+        c = _contexts[key] = StreamContext()
+    return c

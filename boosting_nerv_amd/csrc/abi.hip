@@ -18,18 +18,20 @@ extern "C" const char* bnerv_build_arch(void) { return "gfx950"; }
 
 // ---------------------------------------------------------------------------------------------------------------- side jobs
 #include "sidejob.h"
+#include <new>
 #include <vector>
 
-namespace {
-std::vector<SideJob> g_side_queue;       // one process drives one GPU with one launching thread (torch's autograd thread order)
+struct bnerv_ctx {
+    std::vector<SideJob> queue;          // deferred slab reductions of ONE stream, in issue order
+};
 
+namespace {
 __global__ __launch_bounds__(256) void side_flush_kernel(const SidePack sp) {
     __shared__ float red[256];
     side_slice(sp, blockIdx.x, red);
 }
-}  // namespace
 
-void bnerv_side_push(const void* src, int n_slabs, int count, int ncols, float* out, float* out2) {
+SideJob make_job(const void* src, int n_slabs, int count, int ncols, float* out, float* out2) {
     SideJob j;
     j.src = reinterpret_cast<const float*>(src);
     j.out = out;
@@ -42,38 +44,59 @@ void bnerv_side_push(const void* src, int n_slabs, int count, int ncols, float* 
     while (lanes < 128 && lanes * 16 < n_slabs) lanes *= 2;
     j.epb = 256 / lanes;
     j.slices = (count + j.epb - 1) / j.epb;
-    g_side_queue.push_back(j);
+    return j;
+}
+}  // namespace
+
+void bnerv_side_push(bnerv_ctx* ctx, hipStream_t st, const void* src, int n_slabs, int count, int ncols, float* out, float* out2) {
+    const SideJob j = make_job(src, n_slabs, count, ncols, out, out2);
+    if (ctx) { ctx->queue.push_back(j); return; }
+    SidePack sp;                                          // no context: run it now
+    sp.j[0] = j;
+    sp.n_jobs = 1;
+    sp.n_slices = j.slices;
+    hipLaunchKernelGGL(side_flush_kernel, dim3(sp.n_slices), dim3(256), 0, st, sp);
 }
 
-void bnerv_side_take(SidePack* sp, int max_slices) {
+void bnerv_side_take(bnerv_ctx* ctx, SidePack* sp, int max_slices) {
     sp->n_jobs = 0;
     sp->n_slices = 0;
+    if (!ctx) return;
+    std::vector<SideJob>& q = ctx->queue;
     int n = 0;
-    while (n < (int)g_side_queue.size() && n < SIDE_MAX_JOBS && sp->n_slices + g_side_queue[n].slices <= max_slices) {
-        sp->j[n] = g_side_queue[n];
-        sp->n_slices += g_side_queue[n].slices;
+    while (n < (int)q.size() && n < SIDE_MAX_JOBS && sp->n_slices + q[n].slices <= max_slices) {
+        sp->j[n] = q[n];
+        sp->n_slices += q[n].slices;
         ++n;
     }
     sp->n_jobs = n;
-    g_side_queue.erase(g_side_queue.begin(), g_side_queue.begin() + n);
+    q.erase(q.begin(), q.begin() + n);
 }
 
-int bnerv_side_pending() { return (int)g_side_queue.size(); }
+int bnerv_side_pending(const bnerv_ctx* ctx) { return ctx ? (int)ctx->queue.size() : 0; }
 
-int bnerv_side_flush(hipStream_t st) {
-    while (!g_side_queue.empty()) {
+int bnerv_side_flush(bnerv_ctx* ctx, hipStream_t st) {
+    while (ctx && !ctx->queue.empty()) {
         SidePack sp;
-        bnerv_side_take(&sp, 0x7fffffff);
+        bnerv_side_take(ctx, &sp, 0x7fffffff);
         hipLaunchKernelGGL(side_flush_kernel, dim3(sp.n_slices), dim3(256), 0, st, sp);
         BNERV_LAUNCH_CHECK("side_flush");
     }
     return BNERV_OK;
 }
 
-extern "C" int bnerv_reduce_slabs_deferred(const float* slabs, int n_slabs, int count, float* out) {
+extern "C" int bnerv_ctx_create(bnerv_ctx** out) {
+    BNERV_REQUIRE(out != nullptr, "ctx_create: null output");
+    *out = new (std::nothrow) bnerv_ctx();
+    return *out ? BNERV_OK : bnerv_set_error(BNERV_E_ARG, "ctx_create: out of memory");
+}
+extern "C" void bnerv_ctx_destroy(bnerv_ctx* ctx) { delete ctx; }
+
+extern "C" int bnerv_reduce_slabs_deferred(bnerv_ctx* ctx, void* stream, const float* slabs, int n_slabs, int count, float* out) {
     BNERV_REQUIRE(slabs && out && n_slabs > 0 && count > 0, "reduce_slabs_deferred: bad args");
-    bnerv_side_push(slabs, n_slabs, count, 0, out, nullptr);
+    bnerv_side_push(ctx, reinterpret_cast<hipStream_t>(stream), slabs, n_slabs, count, 0, out, nullptr);
+    if (!ctx) BNERV_LAUNCH_CHECK("reduce_slabs_deferred(immediate)");
     return BNERV_OK;
 }
-extern "C" int bnerv_flush_deferred(void* stream) { return bnerv_side_flush(reinterpret_cast<hipStream_t>(stream)); }
-extern "C" int bnerv_deferred_pending(void) { return bnerv_side_pending(); }
+extern "C" int bnerv_flush_deferred(bnerv_ctx* ctx, void* stream) { return bnerv_side_flush(ctx, reinterpret_cast<hipStream_t>(stream)); }
+extern "C" int bnerv_deferred_pending(const bnerv_ctx* ctx) { return bnerv_side_pending(ctx); }

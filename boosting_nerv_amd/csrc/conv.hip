@@ -711,7 +711,7 @@ int launch_fast(hipStream_t st, KArgs& ka) {
     int grid = 256 * blocks_per_cu;                       // everything resident: the static item partition is then balanced
     if (grid > ka.total_items) grid = ka.total_items;
     SidePack side;
-    bnerv_side_take(&side, 2 * grid);
+    bnerv_side_take(ka.d.ctx, &side, 2 * grid);
     hipLaunchKernelGGL((conv_fast_kernel<KS, IN, EP, NTB, NQ1>), dim3(grid), dim3(256), lds, st, ka, ncs, side);
     BNERV_LAUNCH_CHECK("conv_fast");
     return BNERV_OK;
@@ -1130,7 +1130,7 @@ int launch_lean(hipStream_t st, KArgs& ka) {
     int grid = 256 * blocks_per_cu;                       // everything resident: the static item partition is then balanced
     if (grid > ka.total_items) grid = ka.total_items;
     SidePack side;
-    bnerv_side_take(&side, 2 * grid);
+    bnerv_side_take(ka.d.ctx, &side, 2 * grid);
     hipLaunchKernelGGL((conv_lean_kernel<KS, IN, EP, NQ1>), dim3(grid), dim3(256), lds, st, ka, side);
     BNERV_LAUNCH_CHECK("conv_lean");
     return BNERV_OK;
@@ -1537,7 +1537,7 @@ int launch_lean2(hipStream_t st, KArgs& ka) {
     int grid = 256 * (nb > 4 ? 4 : nb);
     if (grid > ka.total_items) grid = ka.total_items;
     SidePack side;
-    bnerv_side_take(&side, 2 * grid);
+    bnerv_side_take(ka.d.ctx, &side, 2 * grid);
     hipLaunchKernelGGL((conv_lean2_kernel<KS, IN, EP, NTB>), dim3(grid), dim3(256), lds, st, ka, side);
     BNERV_LAUNCH_CHECK("conv_lean2");
     return BNERV_OK;
@@ -1600,7 +1600,7 @@ int launch_one(hipStream_t st, KArgs& ka) {
     int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     if (grid > ka.total_items) grid = ka.total_items;
     SidePack side;
-    bnerv_side_take(&side, 2 * grid);
+    bnerv_side_take(ka.d.ctx, &side, 2 * grid);
     hipLaunchKernelGGL((conv_igemm_kernel<KS, IN, EP, NTB>), dim3(grid), dim3(256), lds, st, ka, side);
     BNERV_LAUNCH_CHECK("conv_igemm");
     return BNERV_OK;

@@ -617,7 +617,7 @@ int launch_bf(hipStream_t st, KArgs& ka) {
     int grid = 256 * blocks_per_cu;
     if (grid > ka.total_items) grid = ka.total_items;
     SidePack side;
-    bnerv_side_take(&side, 2 * grid);
+    bnerv_side_take(ka.d.ctx, &side, 2 * grid);
     hipLaunchKernelGGL((conv_bf_kernel<KS, IN, EP, SP, CB>), dim3(grid), dim3(256), lds, st, ka, side);
     BNERV_LAUNCH_CHECK("conv_bf");
     return BNERV_OK;

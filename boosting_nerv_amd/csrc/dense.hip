@@ -226,7 +226,6 @@ extern "C" int bnerv_dense_grouped_fwd(void* stream, const bnerv_dense_fwd_desc*
 }
 
 extern "C" int bnerv_dense_grouped_bwd(void* stream, const bnerv_dense_bwd_desc* groups, int n_groups, int B) {
-    { const int rc_ = bnerv_side_flush(reinterpret_cast<hipStream_t>(stream)); if (rc_ != BNERV_OK) return rc_; }   // consumers of deferred reductions
     BNERV_REQUIRE(groups && n_groups > 0 && n_groups <= BNERV_MAX_DENSE_GROUPS && B > 0 && B <= 65535, "dense_grouped_bwd: bad args (n_groups=%d)", n_groups);
     BwdArgs a;
     a.B = B;
@@ -262,7 +261,6 @@ extern "C" int bnerv_sft_affine_fwd(void* stream, const float* x, const float* s
 }
 
 extern "C" int bnerv_sft_affine_bwd(void* stream, const float* x, const float* scale, const float* g, float* dx, float* part, int B, int C, int HW) {
-    { const int rc_ = bnerv_side_flush(reinterpret_cast<hipStream_t>(stream)); if (rc_ != BNERV_OK) return rc_; }   // consumers of deferred reductions
     BNERV_REQUIRE(x && scale && g && dx && part && B > 0 && C > 0 && HW > 0 && B * C <= 65535, "sft_affine_bwd: bad args");
     hipLaunchKernelGGL(sft_affine_bwd_kernel, dim3(BNERV_SFT_CHUNKS, B * C), dim3(256), 0, (hipStream_t)stream, x, scale, g, dx, part, B * C, HW);
     BNERV_LAUNCH_CHECK("sft_affine_bwd");
@@ -270,7 +268,6 @@ extern "C" int bnerv_sft_affine_bwd(void* stream, const float* x, const float* s
 }
 
 extern "C" int bnerv_reduce_slabs(void* stream, const float* slabs, int n_slabs, int count, float* out) {
-    { const int rc_ = bnerv_side_flush(reinterpret_cast<hipStream_t>(stream)); if (rc_ != BNERV_OK) return rc_; }   // consumers of deferred reductions
     BNERV_REQUIRE(slabs && out && n_slabs > 0 && count > 0, "reduce_slabs: bad args");
     if (count >= 2048 || n_slabs <= 16)
         hipLaunchKernelGGL(reduce_slabs_kernel<32>, dim3(cdiv(count, 32)), dim3(1024), 0, (hipStream_t)stream, slabs, n_slabs, count, out);

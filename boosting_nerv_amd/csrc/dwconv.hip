@@ -126,7 +126,7 @@ extern "C" size_t bnerv_dwconv_wgrad_ws_bytes(int B, int C, int H, int W, int K)
 }
 
 // dwb: [C][K*K + 1] (weight gradient rows with the bias gradient as the last column); `defer`: queue the slab reduction
-extern "C" int bnerv_dwconv_wgrad(void* stream, const float* x, const float* g, float* dwb, void* ws, size_t ws_bytes, int B, int C, int H, int W, int K, int defer) {
+extern "C" int bnerv_dwconv_wgrad(void* stream, const float* x, const float* g, float* dwb, void* ws, size_t ws_bytes, int B, int C, int H, int W, int K, bnerv_ctx* defer_ctx) {
     BNERV_REQUIRE(x && g && dwb && ws && B > 0 && C > 0 && H > 0 && W > 0, "dwconv_wgrad: bad args");
     BNERV_REQUIRE(K >= 1 && K <= KMAX && (K & 1) == 1, "dwconv_wgrad: K must be odd and <= %d (got %d)", KMAX, K);
     BNERV_REQUIRE((size_t)B * C <= 65535, "dwconv_wgrad: B*C too large");
@@ -135,8 +135,8 @@ extern "C" int bnerv_dwconv_wgrad(void* stream, const float* x, const float* g, 
     dim3 grid(cdiv(W, DTW), cdiv(H, DTH), B * C);
     hipLaunchKernelGGL(dwconv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, g, (float*)ws, C, H, W, K, tiles);
     BNERV_LAUNCH_CHECK("dwconv_wgrad");
-    if (defer) {
-        bnerv_side_push(ws, B * tiles, C * (K * K + 1), 0, dwb, nullptr);
+    if (defer_ctx) {
+        bnerv_side_push(defer_ctx, reinterpret_cast<hipStream_t>(stream), ws, B * tiles, C * (K * K + 1), 0, dwb, nullptr);
         return BNERV_OK;
     }
     return bnerv_reduce_slabs(stream, (const float*)ws, B * tiles, C * (K * K + 1), dwb);

@@ -68,7 +68,6 @@ __global__ __launch_bounds__(256) void bucket_kernel(const BucketArgs a) {
 }  // namespace
 
 extern "C" int bnerv_adan_multi_tensor(void* stream, const bnerv_adan_chunk* chunk, const bnerv_adan_hyper* h) {
-    { const int rc_ = bnerv_side_flush(reinterpret_cast<hipStream_t>(stream)); if (rc_ != BNERV_OK) return rc_; }   // consumers of deferred reductions
     BNERV_REQUIRE(chunk && h && h->sched_dev, "adan_multi_tensor: null args");
     BNERV_REQUIRE(chunk->n_tensors > 0 && chunk->n_tensors <= BNERV_ADAN_MAX_TENSORS, "adan_multi_tensor: n_tensors=%d", chunk->n_tensors);
     AdanArgs a;
@@ -104,7 +103,6 @@ static int bucket_launch(void* stream, const bnerv_bucket_chunk* c, float* bucke
 }
 
 extern "C" int bnerv_bucket_gather(void* stream, const bnerv_bucket_chunk* c, float* bucket, float scale) {
-    { const int rc_ = bnerv_side_flush(reinterpret_cast<hipStream_t>(stream)); if (rc_ != BNERV_OK) return rc_; }   // consumers of deferred reductions
     return bucket_launch(stream, c, bucket, scale, 1);
 }
 extern "C" int bnerv_bucket_scatter(void* stream, const bnerv_bucket_chunk* c, const float* bucket, float scale) {

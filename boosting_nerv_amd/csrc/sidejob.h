@@ -29,12 +29,13 @@ struct SidePack {
     int n_jobs, n_slices;
 };
 
-// host side (abi.hip)
-void bnerv_side_push(const void* src, int n_slabs, int count, int ncols, float* out, float* out2);
-void bnerv_side_take(SidePack* sp, int max_slices);      // moves up to SIDE_MAX_JOBS queued jobs (while their slices fit max_slices)
-                                                         // into *sp (n_jobs = 0 if none): a small grid must not host a big reduction
-int bnerv_side_flush(hipStream_t st);                    // standalone launch(es) for everything still queued
-int bnerv_side_pending();
+// host side (abi.hip).  The queue belongs to the caller's bnerv_ctx; ctx == NULL means "no queue": nothing to take, and a push
+// runs the reduction at once on `st`.
+void bnerv_side_push(bnerv_ctx* ctx, hipStream_t st, const void* src, int n_slabs, int count, int ncols, float* out, float* out2);
+void bnerv_side_take(bnerv_ctx* ctx, SidePack* sp, int max_slices);   // moves up to SIDE_MAX_JOBS queued jobs (while their slices fit
+                                                         // max_slices) into *sp (n_jobs = 0 if none): a small grid must not host a big reduction
+int bnerv_side_flush(bnerv_ctx* ctx, hipStream_t st);    // standalone launch(es) for everything still queued
+int bnerv_side_pending(const bnerv_ctx* ctx);
 
 // one slice (256 threads, `red` = 256 floats of LDS the caller no longer needs; caller guarantees a barrier before)
 __device__ __forceinline__ void side_slice(const SidePack& sp, int s, float* red) {

@@ -734,7 +734,7 @@ int launch_wlean(hipStream_t st, const WArgs& wa) {
     const size_t lds_red = (size_t)4 * 16 * NTW * 16;
     const size_t lds = (lds_main > lds_red ? lds_main : lds_red) * sizeof(float);
     SidePack side;
-    bnerv_side_take(&side, 2 * wlean_blocks(wa.d));
+    bnerv_side_take(wa.d.ctx, &side, 2 * wlean_blocks(wa.d));
     hipLaunchKernelGGL((wgrad_lean_kernel<KS, IN, GM2>), dim3(wlean_blocks(wa.d)), dim3(256), lds, st, wa, n_grows, side);
     BNERV_LAUNCH_CHECK("wgrad_lean");
     return BNERV_OK;
@@ -1112,7 +1112,7 @@ int launch_wide(hipStream_t st, const WArgs& wa, const WidePlan& p) {
     }
     const int grid = 8 * p.slots * p.ngroups * p.mgroups;
     SidePack side;
-    bnerv_side_take(&side, 2 * grid);
+    bnerv_side_take(wa.d.ctx, &side, 2 * grid);
     hipLaunchKernelGGL((wgrad_wide_kernel<IN, GM2, MTW, NTW>), dim3(grid), dim3(256), lds, st, wa, p.slots, side);
     BNERV_LAUNCH_CHECK("wgrad_wide");
     return BNERV_OK;
@@ -1276,8 +1276,8 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
     if (rc == -1) rc = d.k == 1 ? launch_modes<1>(st, wa, p) : launch_modes<3>(st, wa, p);
     if (rc != BNERV_OK) return rc;
     const int count = d.Cout * wa.ncols;
-    if (d.defer_finish) {                                  // (queued AFTER the launch: this launch may host older jobs, never its own)
-        bnerv_side_push(wa.slab, n_slabs, count, wa.ncols, d.dw, d.db);
+    if (d.defer_finish && d.ctx) {                                  // (queued AFTER the launch: this launch may host older jobs, never its own)
+        bnerv_side_push(d.ctx, st, wa.slab, n_slabs, count, wa.ncols, d.dw, d.db);
         return BNERV_OK;
     }
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3(cdiv(count, 32)), dim3(1024), 0, st, wa.slab, n_slabs, d.Cout, wa.ncols, d.dw, d.db);

@@ -31,7 +31,7 @@ def _conv(x, w, bias, out, *, B, Cin, Cout, H, W, k, in_mode, ep_mode, in_s=1, o
           aux0=None, aux1=None, aux2=None, scale=None, shift=None, partial=None, defer=False):
     d = L.ConvDesc(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(out), L.ptr(out2), L.ptr(aux0), L.ptr(aux1), L.ptr(aux2),
                    L.ptr(scale), L.ptr(shift), L.ptr(partial), B, Cin, Cout, H, W, k, in_mode, ep_mode, in_s, out_s,
-                   transposed, w.shape[0], w.shape[1])
+                   transposed, w.shape[0], w.shape[1], L.ctx().handle)
     lib = L.load()
     ws = None
     if ep_mode in (L.EP_DGELU, L.EP_DSIN, L.EP_DGELU_SAVED):
@@ -56,29 +56,29 @@ def _wgrad(x, g, dw, db, *, B, Cin, Cout, H, W, k, in_mode, g_mode, g_s=1, gaux=
     nbytes = lib.bnerv_conv_wgrad_ws_bytes(B, Cin, Cout, H, W, k)
     ws = _ws(nbytes, x.device)
     d = L.WgradDesc(L.ptr(x), L.ptr(g), L.ptr(gaux), L.ptr(scale), L.ptr(shift), L.ptr(dw), L.ptr(db), L.ptr(ws), nbytes,
-                    B, Cin, Cout, H, W, k, in_mode, g_mode, g_s, 1 if defer else 0)
+                    B, Cin, Cout, H, W, k, in_mode, g_mode, g_s, 1 if defer else 0, L.ctx().handle)
     L.check(lib.bnerv_conv_wgrad(L.stream(), C.byref(d)), "bnerv_conv_wgrad")
     if defer:
-        _deferred_keep.append(ws)
+        L.ctx().keep.append(ws)
 
 
-# Deferred slab reductions (include/bnerv.h, bnerv_reduce_slabs_deferred): inside one backward the reductions are queued and
-# ride on the next lean conv / weight-gradient launch; _flush_deferred() at the end of the backward launches the leftovers, so
-# every tensor a backward returns is complete on the stream.  The workspaces of queued jobs are kept alive until then.
-_deferred_keep = []
-
-
+# Deferred slab reductions (include/bnerv.h, bnerv_reduce_slabs_deferred): inside one backward the reductions are queued in the
+# CONTEXT of the current stream (L.ctx()) and ride on the next lean conv / weight-gradient launch of that stream;
+# _flush_deferred() at the end of the backward launches the leftovers, so every tensor a backward returns is complete on the
+# stream.  The workspaces of queued jobs are kept alive by the context until then.
 def _reduce_slabs(slabs, n_slabs, count, out, defer=False):
     if defer:
-        L.check(L.load().bnerv_reduce_slabs_deferred(L.ptr(slabs), n_slabs, count, L.ptr(out)), "bnerv_reduce_slabs_deferred")
-        _deferred_keep.append(slabs)
+        c = L.ctx()
+        L.check(L.load().bnerv_reduce_slabs_deferred(c.handle, L.stream(), L.ptr(slabs), n_slabs, count, L.ptr(out)), "bnerv_reduce_slabs_deferred")
+        c.keep.append(slabs)
         return
     L.check(L.load().bnerv_reduce_slabs(L.stream(), L.ptr(slabs), n_slabs, count, L.ptr(out)), "bnerv_reduce_slabs")
 
 
 def _flush_deferred():
-    L.check(L.load().bnerv_flush_deferred(L.stream()), "bnerv_flush_deferred")
-    _deferred_keep.clear()
+    c = L.ctx()
+    L.check(L.load().bnerv_flush_deferred(c.handle, L.stream()), "bnerv_flush_deferred")
+    c.keep.clear()
 
 
 def _tiles(H, W):
@@ -538,7 +538,7 @@ class _DWConv(torch.autograd.Function):
         nbytes = lib.bnerv_dwconv_wgrad_ws_bytes(B, Cc, H, W, K)
         ws = _ws(nbytes, x.device)
         dwb = torch.empty(Cc, K * K + 1, dtype=torch.float32, device=x.device)
-        L.check(lib.bnerv_dwconv_wgrad(L.stream(), L.ptr(x), L.ptr(g), L.ptr(dwb), L.ptr(ws), nbytes, B, Cc, H, W, K, 0), "bnerv_dwconv_wgrad")
+        L.check(lib.bnerv_dwconv_wgrad(L.stream(), L.ptr(x), L.ptr(g), L.ptr(dwb), L.ptr(ws), nbytes, B, Cc, H, W, K, None), "bnerv_dwconv_wgrad")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)

@@ -47,7 +47,16 @@ class RunLog:
 
 
 def dump_args(args, outf):
-    plain = {k: v for k, v in vars(args).items() if isinstance(v, (int, float, str, bool, list, type(None)))}
+    def plain_value(v):                   # numpy scalars are float / int subclasses the YAML dumper refuses
+        if isinstance(v, bool) or v is None or isinstance(v, str):
+            return v
+        if isinstance(v, int):
+            return int(v)
+        if isinstance(v, float):
+            return float(v)
+        return [plain_value(x) for x in v]
+    plain = {k: plain_value(v) for k, v in vars(args).items()
+             if isinstance(v, (int, float, str, bool, type(None))) or (isinstance(v, list) and all(isinstance(x, (int, float, str, bool)) for x in v))}
     with open(os.path.join(outf, 'args.yaml'), 'w') as f:
         f.write(yaml.safe_dump(plain, default_flow_style=False))
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BNERV_ABI_VERSION 1
+#define BNERV_ABI_VERSION 2
 
 #define BNERV_OK 0
 #define BNERV_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -108,13 +108,21 @@ int bnerv_reduce_slabs(void* stream, const float* slabs, int n_slabs, int count,
 
 /* Deferred form of the same reduction.  On MI355X a tiny dependent kernel between two big ones costs ~10 us of pipeline,
  * so the ~45 slab reductions of a train step are queued instead of launched: the next bnerv_conv_igemm / bnerv_conv_wgrad
- * launch whose kernel can host them executes the queued reductions at the end of its least-loaded blocks (same fixed
- * summation order whoever executes them).  `slabs` and `out` must stay valid, and `out` must not be read, until a hosting
- * launch or bnerv_flush_deferred() has been issued on the stream; bnerv_flush_deferred launches whatever is still queued
- * (a no-op when the queue is empty).  One queue per process, used from the thread that launches the kernels. */
-int bnerv_reduce_slabs_deferred(const float* slabs, int n_slabs, int count, float* out);
-int bnerv_flush_deferred(void* stream);
-int bnerv_deferred_pending(void);
+ * launch GIVEN THE SAME CONTEXT whose kernel can host them executes the queued reductions at the end of its least-loaded
+ * blocks (same fixed summation order whoever executes them).  `slabs` and `out` must stay valid, and `out` must not be read,
+ * until a hosting launch or bnerv_flush_deferred() has been issued on the stream; bnerv_flush_deferred launches whatever is
+ * still queued (a no-op when the queue is empty).
+ *
+ * The queue lives in a CALLER-OWNED context: the library keeps no mutable global state.  One context serves one stream
+ * (every launch that names it must go to that stream, from one thread at a time); contexts are independent of each other, so
+ * two streams / two models in one process never see each other's jobs.  A NULL context is legal everywhere: nothing is
+ * hosted, and a deferral request is executed immediately instead. */
+typedef struct bnerv_ctx bnerv_ctx;
+int bnerv_ctx_create(bnerv_ctx** out);
+void bnerv_ctx_destroy(bnerv_ctx* ctx);
+int bnerv_reduce_slabs_deferred(bnerv_ctx* ctx, void* stream, const float* slabs, int n_slabs, int count, float* out);
+int bnerv_flush_deferred(bnerv_ctx* ctx, void* stream);
+int bnerv_deferred_pending(const bnerv_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution (fp32 MFMA 16x16x4), stride 1, square kernel k in {1,3}, zero padding (k-1)/2, with fused
@@ -165,6 +173,7 @@ typedef struct {
     int transposed;       /* 0: forward  (Cout=wCo, Cin=wCi, W(co,ci,t) = w[co][ci][t]);
                              1: data gradient (Cout=wCi, Cin=wCo, W(co,ci,t) = w[ci][co][k*k-1-t]) */
     int wCo, wCi;
+    bnerv_ctx* ctx;       /* deferred-reduction context of the stream (may be NULL) */
 } bnerv_conv_desc;
 
 /* number of 8x32 spatial tiles per sample of an H x W conv-space image */
@@ -198,6 +207,7 @@ typedef struct {
     int g_mode;           /* BNERV_IN_PLAIN / BNERV_IN_UNSHUFFLE / BNERV_IN_TANHGRAD */
     int g_s;
     int defer_finish;     /* 1: queue the slab reduction into dw/db (see bnerv_reduce_slabs_deferred) instead of launching it */
+    bnerv_ctx* ctx;       /* deferred-reduction context of the stream (NULL: nothing hosted, defer_finish ignored) */
 } bnerv_wgrad_desc;
 
 size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int k);
@@ -241,10 +251,10 @@ int bnerv_ans_decode_categorical(const uint32_t* words, size_t n_words, size_t n
  * (model_blocks.py:223-247: nn.Conv2d(dim, dim, 7, padding=3, groups=dim)); first kernels of SURVEY 8(f) row N3.
  *   bnerv_dwconv_fwd(flip=0): y = conv(x, w) + bias;   flip=1: the data gradient (taps flipped, bias ignored: pass g as x)
  *   bnerv_dwconv_wgrad: dwb[C][K*K+1] = weight gradient rows with the bias gradient in the last column (slabs in ws;
- *   defer=1 queues the slab reduction, see bnerv_reduce_slabs_deferred).  x, y, g: [B, C, H, W];  w: [C, 1, K, K]. */
+ *   defer_ctx != NULL queues the slab reduction there, see bnerv_reduce_slabs_deferred).  x, y, g: [B, C, H, W];  w: [C, 1, K, K]. */
 int bnerv_dwconv_fwd(void* stream, const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W, int K, int flip);
 size_t bnerv_dwconv_wgrad_ws_bytes(int B, int C, int H, int W, int K);
-int bnerv_dwconv_wgrad(void* stream, const float* x, const float* g, float* dwb, void* ws, size_t ws_bytes, int B, int C, int H, int W, int K, int defer);
+int bnerv_dwconv_wgrad(void* stream, const float* x, const float* g, float* dwb, void* ws, size_t ws_bytes, int B, int C, int H, int W, int K, bnerv_ctx* defer_ctx);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Loss and metrics.  Replaces loss_fn (hnerv_utils.py:335-397; variants L1, L2, L1_freq, Fusion10, Fusion10_freq)

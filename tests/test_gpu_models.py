@@ -496,3 +496,36 @@ def test_compression_cli_end_to_end(tmp_path, monkeypatch):
     log = (tmp_path / "output" / "t" / "tiny" / "Size0.05" / "rank0.txt").read_text()
     bpps = [float(x.split("bpp:")[1]) for x in log.splitlines() if "bpp:" in x and "Epoch[" in x]
     assert len(bpps) >= 6 and bpps[-1] < bpps[0], bpps
+
+
+def test_train_cli_end_to_end(tmp_path, monkeypatch):
+    """train_nerv_all.py through its CLI on a tiny synthetic clip (the reference recipe's flags, scaled down): 3 epochs with the
+    captured step, evaluation of the fp32 model and its post-hoc 8-bit twin with the Huffman bit report, the artefacts the
+    reference writes (args.yaml, rank0.txt, model_latest.pth, epochN.csv), then an --eval_only run from the checkpoint that
+    reproduces the final metrics, and one epoch on the generic path (--optim_type Adam)."""
+    import csv
+    from boosting_nerv_amd import train_nerv_all as T
+    monkeypatch.chdir(tmp_path)
+    base = ("--outf t --data_path synthetic:6x180x320 --vid tiny --model NeRV_Boost --sft_block res_sft --ch_t 32 --conv_type convnext pshuffel_3x3 "
+            "--act sin --norm none --crop_list 180_320 --resize_list -1 --loss Fusion10_freq --embed pe_1.25_80 --fc_hw 9_16 --dec_strds 5 2 2 "
+            "--ks 0_3_3 --reduce 2 --dec_blks 1 1 2 --modelsize 0.05 --lower_width 6 -b 1 --lr 0.003 --eval_freq 3 -p 2 --data_split 4_5_6")
+    T.main((base + " --optim_type Adan -e 3 --not_resume").split())
+    out = tmp_path / "output" / "t" / "tiny" / "Size0.05"
+    for f in ("args.yaml", "rank0.txt", "model_latest.pth", "epoch3.csv"):
+        assert (out / f).is_file(), f
+    log = (out / "rank0.txt").read_text()
+    assert "Eval at epoch 3" in log and "bits per pixel" in log and "Training complete in" in log
+    rows = list(csv.reader(open(out / "epoch3.csv")))
+    rec = dict(zip(rows[0][1:], rows[1][1:]))
+    psnr, qpsnr, unseen = float(rec["pred_seen_psnr"]), float(rec["quant_seen_psnr"]), float(rec["pred_unseen_psnr"])
+    assert 8.0 < psnr < 60.0 and abs(psnr - qpsnr) < 1.0 and unseen > 5.0 and float(rec["bits/pixel"]) > 0
+    train_psnrs = [float(l.split("pred_PSNR: ")[1]) for l in log.splitlines() if "pred_PSNR" in l]
+    assert train_psnrs[-1] > train_psnrs[0]                                   # it learns
+    # evaluation only, from the checkpoint the run left behind: same numbers
+    T.main((base + " --optim_type Adan -e 3 --eval_only").split())
+    rows = list(csv.reader(open(out / "eval.csv")))
+    rec2 = dict(zip(rows[0][1:], rows[1][1:]))
+    assert abs(float(rec2["pred_seen_psnr"]) - psnr) < 0.02 and abs(float(rec2["quant_seen_psnr"]) - qpsnr) < 0.05
+    # generic path (Adam): resumes from epoch 3 and trains one more
+    T.main((base + " --optim_type Adam -e 4").split())
+    assert "Epoch[4/4]" in (out / "rank0.txt").read_text()

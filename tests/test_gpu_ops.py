@@ -300,8 +300,9 @@ def test_adan_against_reference_trajectory():
 
 
 def test_deferred_reductions_match_immediate(ops):
-    """Slab reductions queued with bnerv_reduce_slabs_deferred and executed by a hosting conv launch / by the flush give
-    the same sums as the immediate kernel (fixed summation order -> compare tightly), for both job layouts."""
+    """Slab reductions queued with bnerv_reduce_slabs_deferred in a caller-owned context and executed by a hosting conv launch /
+    by the flush give the same sums as the immediate kernel (fixed summation order -> compare tightly), for both job layouts;
+    contexts are independent (a launch never hosts another context's jobs), and a NULL context runs the reduction at once."""
     import ctypes as C
     from boosting_nerv_amd import _lib as L
     lib = L.load()
@@ -310,30 +311,39 @@ def test_deferred_reductions_match_immediate(ops):
     parts = torch.randn(3600, 24, generator=g).to(DEV)           # per-tile epilogue sums
     ref_a, ref_b = slabs.double().sum(0), parts.double().sum(0)
     out_a, out_b = torch.empty(1308, device=DEV), torch.empty(24, device=DEV)
-    assert lib.bnerv_deferred_pending() == 0
-    L.check(lib.bnerv_reduce_slabs_deferred(L.ptr(slabs), 700, 1308, L.ptr(out_a)), "defer")
-    L.check(lib.bnerv_reduce_slabs_deferred(L.ptr(parts), 3600, 24, L.ptr(out_b)), "defer")
-    assert lib.bnerv_deferred_pending() == 2
+    ctx = L.ctx().handle                                         # the context ops._conv passes for the current stream
+    other = L.StreamContext()                                    # a second, unrelated context
+    assert lib.bnerv_deferred_pending(ctx) == 0
+    L.check(lib.bnerv_reduce_slabs_deferred(ctx, L.stream(), L.ptr(slabs), 700, 1308, L.ptr(out_a)), "defer")
+    L.check(lib.bnerv_reduce_slabs_deferred(ctx, L.stream(), L.ptr(parts), 3600, 24, L.ptr(out_b)), "defer")
+    out_o = torch.zeros(24, device=DEV)
+    L.check(lib.bnerv_reduce_slabs_deferred(other.handle, L.stream(), L.ptr(parts), 3600, 24, L.ptr(out_o)), "defer")
+    assert lib.bnerv_deferred_pending(ctx) == 2 and lib.bnerv_deferred_pending(other.handle) == 1
     # a launch with a small grid must not host a big reduction (16 tiles here): the jobs stay queued ...
     w = (torch.randn(12, 12, 3, 3, generator=g) / 10).to(DEV); b = torch.randn(12, generator=g).to(DEV)
     xs = torch.randn(1, 12, 64, 128, generator=g).to(DEV)
     ops._conv(xs, w, b, torch.empty_like(xs), B=1, Cin=12, Cout=12, H=64, W=128, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS)
-    assert lib.bnerv_deferred_pending() == 2
-    # ... and a lean conv launch with enough blocks hosts both
+    assert lib.bnerv_deferred_pending(ctx) == 2
+    # ... and a lean conv launch with enough blocks hosts both -- of ITS context only
     x = torch.randn(1, 12, 256, 512, generator=g).to(DEV)
     y = torch.empty_like(x)
     ops._conv(x, w, b, y, B=1, Cin=12, Cout=12, H=256, W=512, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS)
-    assert lib.bnerv_deferred_pending() == 0
+    assert lib.bnerv_deferred_pending(ctx) == 0 and lib.bnerv_deferred_pending(other.handle) == 1
+    torch.cuda.synchronize()
+    assert float(out_o.abs().max()) == 0.0                      # the other context's job has not run
     torch.testing.assert_close(y.cpu(), F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(out_a.double().cpu(), ref_a.cpu(), rtol=1e-5, atol=1e-4)
     torch.testing.assert_close(out_b.double().cpu(), ref_b.cpu(), rtol=1e-5, atol=1e-3)
-    # flush path (no host launch) and the immediate kernel agree with it
-    out_c, out_d = torch.empty(1308, device=DEV), torch.empty(1308, device=DEV)
-    L.check(lib.bnerv_reduce_slabs_deferred(L.ptr(slabs), 700, 1308, L.ptr(out_c)), "defer")
-    L.check(lib.bnerv_flush_deferred(L.stream()), "flush")
-    assert lib.bnerv_deferred_pending() == 0
+    L.check(lib.bnerv_flush_deferred(other.handle, L.stream()), "flush other")
+    assert lib.bnerv_deferred_pending(other.handle) == 0 and torch.equal(out_o, out_b)
+    # flush path (no host launch), the NULL-context form and the immediate kernel agree
+    out_c, out_d, out_e = torch.empty(1308, device=DEV), torch.empty(1308, device=DEV), torch.empty(1308, device=DEV)
+    L.check(lib.bnerv_reduce_slabs_deferred(ctx, L.stream(), L.ptr(slabs), 700, 1308, L.ptr(out_c)), "defer")
+    L.check(lib.bnerv_flush_deferred(ctx, L.stream()), "flush")
+    assert lib.bnerv_deferred_pending(ctx) == 0
     L.check(lib.bnerv_reduce_slabs(L.stream(), L.ptr(slabs), 700, 1308, L.ptr(out_d)), "reduce")
-    assert torch.equal(out_a, out_c)
+    L.check(lib.bnerv_reduce_slabs_deferred(None, L.stream(), L.ptr(slabs), 700, 1308, L.ptr(out_e)), "defer without a context")
+    assert torch.equal(out_a, out_c) and torch.equal(out_c, out_e)
     torch.testing.assert_close(out_c, out_d, rtol=1e-5, atol=1e-4)
 
 
