@@ -3,7 +3,8 @@ with per-step PSNR accumulated on the device.  After a few eager steps the fixed
 replayed (≈100 short kernels per step: launch latency, not arithmetic, is what a Python-driven loop would pay for).
 
   world == 1 :  one graph   [fwd, loss, bwd, Adan]
-  world  > 1 :  two graphs  [fwd, loss, bwd, bucket-gather]  --eager RCCL all-reduce of ONE flat bucket--  [bucket-scatter, Adan]
+  world  > 1 :  one graph   [fwd, loss, bwd, bucket-gather, RCCL all-reduce of ONE flat bucket, bucket-scatter, Adan]
+                (two graphs around an eager all-reduce when the collective cannot be captured: gloo in the CPU-transport tests)
 
 Everything that changes per step and is not data (lr, Adan bias corrections) lives in device memory written by
 Adan.prepare_step(), so the captured kernels never see a stale scalar."""
@@ -28,6 +29,7 @@ class TrainStep:
         self.warmup_eager = warmup_eager
         self.n_calls = 0
         self.graph_a = self.graph_b = None
+        self.collective_in_graph = False
         self._opt_epoch = getattr(optimizer, "state_epoch", 0)
         self.loss_out = self.psnr_out = None
         self.world = world_size
@@ -57,31 +59,60 @@ class TrainStep:
         self.opt.prepare_step()
         self.opt.launch_step()
 
+    def _bucket_calls(self, which):
+        import ctypes as C
+        from . import _lib as L
+        lib = L.load()
+        fn, scale = (lib.bnerv_bucket_gather, 1.0 / self.world) if which == "gather" else (lib.bnerv_bucket_scatter, 1.0)
+        for ck in self.bucket._build():
+            L.check(fn(L.stream(), C.byref(ck), L.ptr(self.bucket.bucket), scale), "bnerv_bucket_" + which)
+
     def _capture(self):
+        """world == 1: one graph.  world > 1 on RCCL: ONE graph as well -- the all-reduce of the flat bucket is captured between the
+        gather and the scatter, so a step is a single launch with no host round trip around the collective (BNERV_DP_INGRAPH=0, a
+        backend whose collectives cannot be captured (gloo), or a failed capture fall back to graph A -> eager all-reduce -> graph B)."""
+        import os
+        import torch.distributed as dist
         torch.cuda.synchronize()
         self._opt_epoch = getattr(self.opt, "state_epoch", 0)
         pool = torch.cuda.graph_pool_handle()
-        self.graph_a = torch.cuda.CUDAGraph()
+        self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), None
         if self.bucket is None:
             with torch.cuda.graph(self.graph_a, pool=pool):
                 self._fwd_bwd()
                 self.opt.launch_step()
-        else:
-            import ctypes as C
-            from . import _lib as L
-            lib = L.load()
-            with torch.cuda.graph(self.graph_a, pool=pool):
-                self._fwd_bwd()
-                for p in self.params:
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                for ck in self.bucket._build():
-                    L.check(lib.bnerv_bucket_gather(L.stream(), C.byref(ck), L.ptr(self.bucket.bucket), 1.0 / self.world), "bucket_gather")
-            self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=pool):
-                for ck in self.bucket._build():
-                    L.check(lib.bnerv_bucket_scatter(L.stream(), C.byref(ck), L.ptr(self.bucket.bucket), 1.0), "bucket_scatter")
-                self.opt.launch_step()
+            return
+
+        def head():
+            self._fwd_bwd()
+            for p in self.params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            self._bucket_calls("gather")
+
+        def tail():
+            self._bucket_calls("scatter")
+            self.opt.launch_step()
+        backend = dist.get_backend(self.bucket.group) if dist.is_initialized() else ""
+        if backend == "nccl" and os.environ.get("BNERV_DP_INGRAPH", "1") != "0":
+            try:
+                with torch.cuda.graph(self.graph_a, pool=pool):
+                    head()
+                    dist.all_reduce(self.bucket.bucket, op=dist.ReduceOp.SUM, group=self.bucket.group)
+                    tail()
+                self.collective_in_graph = True
+                return
+            except Exception as e:                        # capture of the collective is not available on this stack: two graphs
+                import warnings
+                warnings.warn(f"RCCL all-reduce could not be captured ({type(e).__name__}: {e}); falling back to the two-graph step")
+                torch.cuda.synchronize()
+                self.graph_a = torch.cuda.CUDAGraph()
+        self.collective_in_graph = False
+        with torch.cuda.graph(self.graph_a, pool=pool):
+            head()
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, pool=pool):
+            tail()
 
     # ---- one step ------------------------------------------------------------------------------------------------------
     def __call__(self, img, norm_idx):

@@ -321,8 +321,9 @@ def test_smoke_entry():
 
 
 def test_dp_step_path_on_one_rank_group():
-    """The multi-GPU step (graph A [fwd,loss,bwd,bucket gather] -> RCCL all-reduce -> graph B [scatter, Adan]) executed on a
-    1-rank NCCL(=RCCL) group: must reproduce the single-GPU trajectory exactly (mean over 1 rank is the identity)."""
+    """The multi-GPU step executed on a 1-rank NCCL(=RCCL) group, in both forms -- ONE graph with the all-reduce captured inside,
+    and graph A [fwd,loss,bwd,bucket gather] -> eager all-reduce -> graph B [scatter, Adan]: each must reproduce the single-GPU
+    trajectory exactly (mean over 1 rank is the identity)."""
     import os
     import torch.distributed as dist
     from boosting_nerv_amd.engine import TrainStep
@@ -340,7 +341,8 @@ def test_dp_step_path_on_one_rank_group():
         frames = torch.stack([vid.frame(i) for i in range(3)]).to(DEV)
         norm = torch.tensor([(i + 1) / 3 for i in range(3)], dtype=torch.float64, device=DEV)
         results = []
-        for force in (False, True):
+        for force, ingraph in ((False, "1"), (True, "1"), (True, "0")):
+            os.environ["BNERV_DP_INGRAPH"] = ingraph
             torch.manual_seed(1)
             model = NeRV_Boost(1, args=configs.tiny_nerv()).to(DEV)
             opt = Adan(model.parameters(), lr=0.003)
@@ -349,12 +351,17 @@ def test_dp_step_path_on_one_rank_group():
             for s in range(7):
                 loss, _ = step(frames[s % 3:s % 3 + 1], norm[s % 3:s % 3 + 1])
                 losses.append(loss.item())
-            if force:
-                assert step.graph_b is not None
+            if force and ingraph == "0":
+                assert step.graph_b is not None and not step.collective_in_graph
+            if force and ingraph == "1":          # the captured collective (one launch per step) when the stack allows it
+                assert step.collective_in_graph == (step.graph_b is None)
+                print("RCCL all-reduce captured in the step graph:", step.collective_in_graph)
             results.append((losses, [p.detach().clone() for p in model.parameters()]))
-        assert results[0][0] == results[1][0], (results[0][0], results[1][0])
-        for a, b in zip(results[0][1], results[1][1]):
-            assert torch.equal(a, b)
+        os.environ.pop("BNERV_DP_INGRAPH", None)
+        for other in results[1:]:
+            assert results[0][0] == other[0], (results[0][0], other[0])
+            for a, b in zip(results[0][1], other[1]):
+                assert torch.equal(a, b)
     finally:
         if created:
             dist.destroy_process_group()
@@ -529,3 +536,25 @@ def test_train_cli_end_to_end(tmp_path, monkeypatch):
     # generic path (Adam): resumes from epoch 3 and trains one more
     T.main((base + " --optim_type Adam -e 4").split())
     assert "Epoch[4/4]" in (out / "rank0.txt").read_text()
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), with BNERV_BENCH_SHARE_GPU=1 so that
+    both ranks use this box's single GPU over gloo: the N > 1 code path of the script runs end to end and prints ONE JSON line with
+    the contract's keys (the numbers of such a run mean nothing)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BNERV_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29671",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["scaling"] == "weak" and out["value"] > 0 and out["cpu_baseline"] is None and out["roofline"]["frac"] > 0
+    assert "eval_psnr_db" in out and "step_roofline" in out
