@@ -71,7 +71,6 @@ def build(cfg_name):
     args.outf = "bench"
     args.fc_dim, _ = T.solve_fc_dim(args, args.final_size, args.full_data_length)
     torch.manual_seed(args.manualSeed)
-    torch.backends.cudnn.benchmark = True     # as train_nerv_all.py:154 (MIOpen solver search for the HNeRV encoder's stock convs)
     return args, T.build_model(args)
 
 

@@ -1,0 +1,382 @@
+// gemm.hip -- the two places of the path that really are GEMMs (north_star: "MFMA used only for the 1x1 / stem dense projections
+// where they really are GEMMs"), on v_mfma_f32_16x16x4_f32:
+//
+//  (1) bnerv_dense_gemm_*: dense layers applied to 16 or more rows -- NeRV_MLP / the token MLPs of E-NeRV's transformer stem
+//      (reference model_blocks.py:66-71, model_enerv.py:22-60: nn.Linear / 1x1 conv on [tokens, C]).  One strided kernel serves
+//        forward   y  = act(x W^T + b)                       (epilogue: bias, relu | sin with cos saved)
+//        dx        dx = dpre W                                (A-side prologue: dpre = dy * act'(.) rebuilt on load)
+//        dW, db    dW = dpre^T x,  db = column sums           (same prologue; the bias gradient is a virtual column of ones)
+//  (2) bnerv_cnx_mlp_*: the pointwise MLP of the ConvNeXt encoder block of HNeRV_Boost (reference model_blocks.py:245-258:
+//      pwconv1 -> GELU -> pwconv2 -> gamma -> + residual), NCHW, as ONE forward and ONE backward kernel.  Per 16-pixel N tile the
+//      hidden activations never leave registers: the D fragments of GEMM 1 (4 consecutive hidden units of one pixel per lane)
+//      ARE the B fragments of GEMM 2 once its K index is walked in the order (hidden tile, register) -- no shuffle, no LDS.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------- dense GEMM
+// C[m][n] = epi( sum_k A(m,k) * B(k,n) ),  A(m,k) = pro(a[m*sam + k*sak]),  B(k,n) = b[k*sbk + n*sbn]  (n == N-1 may be a virtual
+// column of ones).  Block = 4 waves = 32 x 32 outputs (wave w: M tile w & 1, N tile w >> 1), K walked 16 at a time through LDS.
+enum { PRO_NONE = 0, PRO_RELU = 1, PRO_COS = 2 };           // A-side: a * (aux > 0) | a * aux
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_BIAS_SIN = 3, EPI_SPLIT_LAST = 4 };   // SPLIT_LAST: column N-1 goes to c2[m]
+
+struct GemmArgs {
+    const float* a; const float* a_aux; const float* b; const float* bias;
+    float* c; float* c2;
+    int M, N, K;
+    long sam, sak, sbk, sbn;
+    int ldc;              // row stride of c (EPI_SPLIT_LAST: N - 1 real columns)
+    int pro, epi, ones_col;
+};
+
+__global__ __launch_bounds__(256) void dense_gemm_kernel(const GemmArgs g) {
+    __shared__ float s_a[32][17];                          // [m][k]
+    __shared__ float s_b[16][33];                          // [k][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int mt = wave & 1, nt = wave >> 1;
+    f32x4 acc{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+        // stage A: 32 x 16 and B: 16 x 32 (two elements of each per thread), zero outside the matrix
+        for (int e = tid; e < 512; e += 256) {
+            const int m = e >> 4, k = e & 15;
+            float v = 0.f;
+            if (m0 + m < g.M && k0 + k < g.K) {
+                const long idx = (long)(m0 + m) * g.sam + (long)(k0 + k) * g.sak;
+                v = g.a[idx];
+                if (g.pro == PRO_RELU) v = g.a_aux[idx] > 0.f ? v : 0.f;
+                else if (g.pro == PRO_COS) v *= g.a_aux[idx];
+            }
+            s_a[m][k] = v;
+            const int kb = e >> 5, n = e & 31;
+            float u = 0.f;
+            if (k0 + kb < g.K && n0 + n < g.N)
+                u = (g.ones_col && n0 + n == g.N - 1) ? 1.0f : g.b[(long)(k0 + kb) * g.sbk + (long)(n0 + n) * g.sbn];
+            s_b[kb][n] = u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s_a[mt * 16 + li][4 * s + kq], s_b[4 * s + kq][nt * 16 + li], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    // D: lane (n = li, rows 4 kq .. 4 kq + 3)
+    const int n = n0 + nt * 16 + li;
+    if (n >= g.N) return;
+    const float bias = (g.epi >= EPI_BIAS && g.epi <= EPI_BIAS_SIN && g.bias) ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + mt * 16 + 4 * kq + r;
+        if (m >= g.M) continue;
+        float v = acc[r] + bias;
+        if (g.epi == EPI_SPLIT_LAST) {
+            if (n == g.N - 1) { if (g.c2) g.c2[m] = v; }
+            else g.c[(long)m * g.ldc + n] = v;
+            continue;
+        }
+        if (g.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        else if (g.epi == EPI_BIAS_SIN) {
+            float sv, cv;
+            sincosf(v, &sv, &cv);
+            v = sv;
+            if (g.c2) g.c2[(long)m * g.ldc + n] = cv;
+        }
+        g.c[(long)m * g.ldc + n] = v;
+    }
+}
+
+int launch_gemm(hipStream_t st, const GemmArgs& g) {
+    hipLaunchKernelGGL(dense_gemm_kernel, dim3(cdiv(g.N, 32), cdiv(g.M, 32)), dim3(256), 0, st, g);
+    BNERV_LAUNCH_CHECK("dense_gemm");
+    return BNERV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- ConvNeXt MLP
+// x, inp, out, dout, dx: [B, C, HW];  w1 [4C, C], b1 [4C], w2 [C, 4C], b2 [C], gamma [C] (may be NULL: no layer scale).
+// C in {16, 32, 48, 64}.  Block = 256 threads; every wave owns NT consecutive 16-pixel tiles of one sample; the weights sit in
+// LDS as MFMA A fragments ([tile][k step][lane]) for the whole block.
+constexpr int CNX_NT = 2;                                  // pixel tiles per wave (A-fragment reuse)
+
+struct MlpArgs {
+    const float* x; const float* inp; const float* w1; const float* b1; const float* w2; const float* b2; const float* gamma;
+    float* out; float* hsave;                              // forward (hsave: [B, 4C, HW] pre-activations kept for backward, or NULL)
+    const float* dout; const float* hin; float* dx; float* gbuf; float* dhbuf;   // backward
+    int B, C, HW;
+};
+
+// A fragments of W1 for hidden tile t, k step s (input channels 4s .. 4s+3): lane (m = li, kq) <- w1[16 t + li][4 s + kq]
+// A fragments of W2 for output tile o, k index (t, r): lane (m = li, kq) <- w2[16 o + li][16 t + 4 kq + r]
+template <int C>
+__device__ __forceinline__ void stage_weights(const MlpArgs& a, float* s_w1, float* s_w2, int tid) {
+    constexpr int HID = 4 * C;
+    for (int e = tid; e < HID * C; e += 256) {             // s_w1[(t * (C/4) + s) * 64 + lane]
+        const int lane = e & 63, rest = e >> 6, s = rest % (C / 4), t = rest / (C / 4);
+        s_w1[e] = a.w1[(16 * t + (lane & 15)) * C + 4 * s + (lane >> 4)];
+    }
+    for (int e = tid; e < C * HID; e += 256) {             // s_w2[((o * (HID/16) + t) * 4 + r) * 64 + lane]
+        const int lane = e & 63, rest = e >> 6, r = rest & 3, t = (rest >> 2) % (HID / 16), o = (rest >> 2) / (HID / 16);
+        s_w2[e] = a.w2[(16 * o + (lane & 15)) * HID + 16 * t + 4 * (lane >> 4) + r];
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void cnx_mlp_fwd_kernel(const MlpArgs a) {
+    constexpr int HID = 4 * C, KS1 = C / 4, HT = HID / 16, OT = C / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_w1 = smem;
+    float* s_w2 = smem + HID * C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    stage_weights<C>(a, s_w1, s_w2, tid);
+    __syncthreads();
+    const int tiles_per_b = (a.HW + 16 * CNX_NT - 1) / (16 * CNX_NT);
+    const int total = a.B * tiles_per_b;
+    for (int item = blockIdx.x * 4 + wave; item < total; item += gridDim.x * 4) {
+        const int b = item / tiles_per_b, p0 = (item - b * tiles_per_b) * 16 * CNX_NT;
+        const float* xb = a.x + (size_t)b * C * a.HW;
+        // B fragments of x: lane (n = pixel li, kq) <- x[4 s + kq][pixel]
+        float xf[CNX_NT][KS1];
+        int px[CNX_NT];
+#pragma unroll
+        for (int n = 0; n < CNX_NT; ++n) {
+            px[n] = p0 + 16 * n + li;
+            const bool ok = px[n] < a.HW;
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) xf[n][s] = ok ? xb[(size_t)(4 * s + kq) * a.HW + px[n]] : 0.f;
+        }
+        f32x4 acc2[OT][CNX_NT];
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int n = 0; n < CNX_NT; ++n) acc2[o][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < HT; ++t) {
+            f32x4 h[CNX_NT];
+#pragma unroll
+            for (int n = 0; n < CNX_NT; ++n) h[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                const float wf = s_w1[(t * KS1 + s) * 64 + lane];
+#pragma unroll
+                for (int n = 0; n < CNX_NT; ++n) h[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, xf[n][s], h[n], 0, 0, 0);
+            }
+            // lane holds hidden units 16 t + 4 kq + r of pixel li: bias, GELU, then straight into GEMM 2 as B fragments
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hid = 16 * t + 4 * kq + r;
+                const float bb = a.b1[hid];
+#pragma unroll
+                for (int n = 0; n < CNX_NT; ++n) {
+                    const float pre = h[n][r] + bb;
+                    if (a.hsave && px[n] < a.HW) a.hsave[((size_t)b * HID + hid) * a.HW + px[n]] = pre;
+                    h[n][r] = gelu_f(pre);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < OT; ++o)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float wf = s_w2[((o * HT + t) * 4 + r) * 64 + lane];
+#pragma unroll
+                    for (int n = 0; n < CNX_NT; ++n) acc2[o][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, h[n][r], acc2[o][n], 0, 0, 0);
+                }
+        }
+        // epilogue: lane (pixel li, channels 16 o + 4 kq + r): out = inp + gamma * (y + b2)
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * o + 4 * kq + r;
+                const float gm = a.gamma ? a.gamma[c] : 1.0f, bb = a.b2[c];
+#pragma unroll
+                for (int n = 0; n < CNX_NT; ++n)
+                    if (px[n] < a.HW) {
+                        const size_t idx = ((size_t)b * C + c) * a.HW + px[n];
+                        a.out[idx] = a.inp[idx] + gm * (acc2[o][n][r] + bb);
+                    }
+            }
+    }
+}
+
+// backward, per pixel tile, from the pre-activations h1 the forward kept:  G = gelu(h1), G' = gelu'(h1);  dY = gamma * dout;
+// dG = W2^T dY;  dH = dG * G';  dX = W1^T dH.  Writes G and dH ([B, 4C, HW]: the K = pixel operands of the two weight-gradient
+// GEMMs, which go through bnerv_conv_wgrad with k = 1) and dX.  The transposed weights are staged as A fragments:
+//   W2^T for hidden tile t, k step s (output channels 4s..4s+3): lane (m = li, kq) <- w2[4 s + kq][16 t + li]
+//   W1^T for input tile i, k index (t, r):                         lane (m = li, kq) <- w1[16 t + 4 kq + r][16 i + li]
+template <int C>
+__global__ __launch_bounds__(256) void cnx_mlp_bwd_kernel(const MlpArgs a) {
+    constexpr int HID = 4 * C, KS1 = C / 4, HT = HID / 16, OT = C / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_w2t = smem;                                   // [(t * KS1 + s) * 64 + lane]
+    float* s_w1t = smem + HID * C;                         // [((i * HT + t) * 4 + r) * 64 + lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    for (int e = tid; e < HID * C; e += 256) {
+        const int ln = e & 63, rest = e >> 6;
+        { const int s = rest % KS1, t = rest / KS1;
+          s_w2t[e] = a.w2[(4 * s + (ln >> 4)) * HID + 16 * t + (ln & 15)]; }
+        { const int r = rest & 3, t = (rest >> 2) % HT, i = (rest >> 2) / HT;
+          s_w1t[e] = a.w1[(16 * t + 4 * (ln >> 4) + r) * C + 16 * i + (ln & 15)]; }
+    }
+    __syncthreads();
+    const int tiles_per_b = (a.HW + 16 * CNX_NT - 1) / (16 * CNX_NT);
+    const int total = a.B * tiles_per_b;
+    for (int item = blockIdx.x * 4 + wave; item < total; item += gridDim.x * 4) {
+        const int b = item / tiles_per_b, p0 = (item - b * tiles_per_b) * 16 * CNX_NT;
+        const float* gb = a.dout + (size_t)b * C * a.HW;
+        float yf[CNX_NT][KS1];                             // B fragments of dY = gamma * dout (k = channel 4 s + kq)
+        int px[CNX_NT];
+#pragma unroll
+        for (int n = 0; n < CNX_NT; ++n) {
+            px[n] = p0 + 16 * n + li;
+            const bool ok = px[n] < a.HW;
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                const int c = 4 * s + kq;
+                yf[n][s] = ok ? gb[(size_t)c * a.HW + px[n]] * (a.gamma ? a.gamma[c] : 1.0f) : 0.f;
+            }
+        }
+        f32x4 accx[OT][CNX_NT];
+#pragma unroll
+        for (int i = 0; i < OT; ++i)
+#pragma unroll
+            for (int n = 0; n < CNX_NT; ++n) accx[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < HT; ++t) {
+            f32x4 dg[CNX_NT];
+            float pre[CNX_NT][4];
+#pragma unroll
+            for (int n = 0; n < CNX_NT; ++n) {
+                dg[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pre[n][r] = px[n] < a.HW ? a.hin[((size_t)b * HID + 16 * t + 4 * kq + r) * a.HW + px[n]] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                const float wt = s_w2t[(t * KS1 + s) * 64 + lane];
+#pragma unroll
+                for (int n = 0; n < CNX_NT; ++n) dg[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt, yf[n][s], dg[n], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hid = 16 * t + 4 * kq + r;
+#pragma unroll
+                for (int n = 0; n < CNX_NT; ++n) {
+                    const float gv = gelu_f(pre[n][r]);
+                    const float dh = dg[n][r] * gelu_grad_f(pre[n][r]);
+                    dg[n][r] = dh;
+                    if (px[n] < a.HW) {
+                        const size_t idx = ((size_t)b * HID + hid) * a.HW + px[n];
+                        a.gbuf[idx] = gv;
+                        a.dhbuf[idx] = dh;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < OT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float wf = s_w1t[((i * HT + t) * 4 + r) * 64 + lane];
+#pragma unroll
+                    for (int n = 0; n < CNX_NT; ++n) accx[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, dg[n][r], accx[i][n], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < OT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * i + 4 * kq + r;
+#pragma unroll
+                for (int n = 0; n < CNX_NT; ++n)
+                    if (px[n] < a.HW) a.dx[((size_t)b * C + c) * a.HW + px[n]] = accx[i][n][r];
+            }
+    }
+}
+
+template <int C>
+int launch_mlp(hipStream_t st, const MlpArgs& a, bool bwd) {
+    const size_t lds = (size_t)2 * 4 * C * C * sizeof(float);
+    const int total = a.B * cdiv(a.HW, 16 * CNX_NT);
+    int grid = cdiv(total, 4);
+    const int cap = 256 * (lds > 80 * 1024 ? 1 : 2);
+    if (grid > cap) grid = cap;
+    if (bwd) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnx_mlp_bwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(cnx_mlp_bwd_kernel<C>, dim3(grid), dim3(256), lds, st, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnx_mlp_fwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(cnx_mlp_fwd_kernel<C>, dim3(grid), dim3(256), lds, st, a);
+    }
+    BNERV_LAUNCH_CHECK(bwd ? "cnx_mlp_bwd" : "cnx_mlp_fwd");
+    return BNERV_OK;
+}
+
+int launch_mlp_c(hipStream_t st, const MlpArgs& a, bool bwd) {
+    switch (a.C) {
+        case 16: return launch_mlp<16>(st, a, bwd);
+        case 32: return launch_mlp<32>(st, a, bwd);
+        case 48: return launch_mlp<48>(st, a, bwd);
+        case 64: return launch_mlp<64>(st, a, bwd);
+    }
+    return bnerv_set_error(BNERV_E_ARG, "cnx_mlp: C must be 16, 32, 48 or 64 (got %d)", a.C);
+}
+
+}  // namespace
+
+extern "C" int bnerv_dense_gemm_fwd(void* stream, const float* x, const float* w, const float* b, float* y, float* aux, int B, int I, int O, int act) {
+    BNERV_REQUIRE(x && w && y && B > 0 && I > 0 && O > 0, "dense_gemm_fwd: bad args");
+    BNERV_REQUIRE(act == BNERV_ACT_NONE || act == BNERV_ACT_RELU || act == BNERV_ACT_SIN, "dense_gemm_fwd: bad activation %d", act);
+    GemmArgs g{};
+    g.a = x; g.b = w; g.bias = b; g.c = y; g.c2 = aux;
+    g.M = B; g.N = O; g.K = I;
+    g.sam = I; g.sak = 1; g.sbk = 1; g.sbn = I; g.ldc = O;
+    g.pro = PRO_NONE;
+    g.epi = act == BNERV_ACT_RELU ? EPI_BIAS_RELU : (act == BNERV_ACT_SIN ? EPI_BIAS_SIN : EPI_BIAS);
+    return launch_gemm(reinterpret_cast<hipStream_t>(stream), g);
+}
+
+// dy [B, O]; y (relu mask) / aux (cos) [B, O] as the activation needs; dx [B, I] (may be NULL); dw [O, I]; db [O] (may be NULL)
+extern "C" int bnerv_dense_gemm_bwd(void* stream, const float* x, const float* w, const float* y, const float* aux, const float* dy,
+                                    float* dx, float* dw, float* db, int B, int I, int O, int act) {
+    BNERV_REQUIRE(x && w && dy && dw && B > 0 && I > 0 && O > 0, "dense_gemm_bwd: bad args");
+    if (act == BNERV_ACT_RELU) BNERV_REQUIRE(y, "dense_gemm_bwd: relu needs y");
+    if (act == BNERV_ACT_SIN) BNERV_REQUIRE(aux, "dense_gemm_bwd: sin needs aux");
+    const int pro = act == BNERV_ACT_RELU ? PRO_RELU : (act == BNERV_ACT_SIN ? PRO_COS : PRO_NONE);
+    const float* a_aux = act == BNERV_ACT_RELU ? y : aux;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // dW[o][i] (+ db[o] as the virtual last column) = sum_b dpre[b][o] * x[b][i]
+    GemmArgs g{};
+    g.a = dy; g.a_aux = a_aux; g.b = x; g.c = dw; g.c2 = db;
+    g.M = O; g.N = I + 1; g.K = B;
+    g.sam = 1; g.sak = O; g.sbk = I; g.sbn = 1; g.ldc = I;
+    g.pro = pro; g.epi = EPI_SPLIT_LAST; g.ones_col = 1;
+    int rc = launch_gemm(st, g);
+    if (rc != BNERV_OK || !dx) return rc;
+    // dx[b][i] = sum_o dpre[b][o] * w[o][i]
+    GemmArgs h{};
+    h.a = dy; h.a_aux = a_aux; h.b = w; h.c = dx;
+    h.M = B; h.N = I; h.K = O;
+    h.sam = O; h.sak = 1; h.sbk = I; h.sbn = 1; h.ldc = I;
+    h.pro = pro; h.epi = EPI_NONE;
+    return launch_gemm(st, h);
+}
+
+extern "C" int bnerv_cnx_mlp_fwd(void* stream, const float* x, const float* inp, const float* w1, const float* b1, const float* w2, const float* b2,
+                                 const float* gamma, float* out, float* hsave, int B, int C, int HW) {
+    BNERV_REQUIRE(x && inp && w1 && b1 && w2 && b2 && out && B > 0 && HW > 0, "cnx_mlp_fwd: bad args");
+    MlpArgs a{};
+    a.x = x; a.inp = inp; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.gamma = gamma; a.out = out; a.hsave = hsave;
+    a.B = B; a.C = C; a.HW = HW;
+    return launch_mlp_c(reinterpret_cast<hipStream_t>(stream), a, false);
+}
+
+// h1: [B, 4C, HW] pre-activations the forward kept (hsave); gbuf, dhbuf: [B, 4C, HW] outputs (gelu(h1) and d loss / d h1): the
+// pixel-contraction operands of the weight gradients
+extern "C" int bnerv_cnx_mlp_bwd(void* stream, const float* h1, const float* dout, const float* w1, const float* w2, const float* gamma,
+                                 float* dx, float* gbuf, float* dhbuf, int B, int C, int HW) {
+    BNERV_REQUIRE(h1 && dout && w1 && w2 && dx && gbuf && dhbuf && B > 0 && HW > 0, "cnx_mlp_bwd: bad args");
+    MlpArgs a{};
+    a.hin = h1; a.dout = dout; a.w1 = w1; a.w2 = w2; a.gamma = gamma; a.dx = dx; a.gbuf = gbuf; a.dhbuf = dhbuf;
+    a.B = B; a.C = C; a.HW = HW;
+    return launch_mlp_c(reinterpret_cast<hipStream_t>(stream), a, true);
+}

@@ -325,9 +325,14 @@ class Block(nn.Module):
 
     def forward(self, x):
         inp = x
+        if x.is_cuda and x.shape[1] in ops.CNX_MLP_DIMS:
+            # Row N3, whole block on HIP kernels, NCHW end to end (same arithmetic as the channels_last form, no permute copies):
+            # depthwise 7x7 -> channel LayerNorm -> ONE fused kernel for pwconv1 -> GELU -> pwconv2 -> gamma -> + input
+            x = ops.dwconv(x, self.dwconv.weight, self.dwconv.bias)
+            x = ops.layernorm_cf(x, self.norm.weight, self.norm.bias, self.norm.eps)
+            return ops.cnx_mlp(x, inp, self.pwconv1.weight, self.pwconv1.bias, self.pwconv2.weight, self.pwconv2.bias, self.gamma)
         if x.is_cuda and x.shape[1] <= ops.LN_CF_MAX_C:
-            # Row N3: HIP depthwise conv and channel LayerNorm, everything kept NCHW -- the pointwise linears become 1x1 convs on
-            # the same weights (no permute copies in either direction; same arithmetic as the channels_last form)
+            # other widths: HIP depthwise conv and channel LayerNorm, the pointwise linears as 1x1 convs on the same weights
             dim = x.shape[1]
             x = ops.dwconv(x, self.dwconv.weight, self.dwconv.bias)
             x = ops.layernorm_cf(x, self.norm.weight, self.norm.bias, self.norm.eps)
@@ -383,13 +388,14 @@ class ConvNeXt(nn.Module):
 
 def patchify_conv(x, conv):
     """nn.Conv2d with kernel_size == stride and no padding (every ConvNeXt down-sampling layer, model_blocks.py:250-262 of the
-    reference) as a GEMM over non-overlapping patches: im2col is a pure reshape here.  Same parameters / state_dict; on ROCm this
-    replaces MIOpen's naive fp32 fallback for these shapes by rocBLAS."""
+    reference) as a GEMM over non-overlapping patches: im2col is a pure reshape here.  Same parameters / state_dict; the GEMM
+    runs on the MFMA kernel of csrc/gemm.hip (ops.dense_gemm)."""
     s = conv.stride[0]
     if conv.kernel_size != (s, s) or conv.stride != (s, s) or conv.padding != (0, 0) or conv.groups != 1 or conv.dilation != (1, 1):
         return conv(x)
     B, C, H, W = x.shape
     Ho, Wo = H // s, W // s
     xp = x[:, :, :Ho * s, :Wo * s].reshape(B, C, Ho, s, Wo, s).permute(0, 2, 4, 1, 3, 5).reshape(B * Ho * Wo, C * s * s)
-    y = F.linear(xp, conv.weight.reshape(conv.out_channels, C * s * s), conv.bias)
+    w2d = conv.weight.reshape(conv.out_channels, C * s * s)
+    y = ops.dense_gemm(xp, w2d, conv.bias) if xp.is_cuda else F.linear(xp, w2d, conv.bias)     # (CPU branch: the patchify equivalence test)
     return y.reshape(B, Ho, Wo, conv.out_channels).permute(0, 3, 1, 2)

@@ -210,19 +210,51 @@ class _DenseGrouped(torch.autograd.Function):
 DENSE_GEMM_MIN_B = 16
 
 
+class _DenseGemm(torch.autograd.Function):
+    """y = act(x W^T + b) for many rows on the MFMA GEMM kernel (bnerv_dense_gemm_fwd / _bwd, csrc/gemm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x2 = L.f32c(L.require_device(x, "x")).reshape(x.shape[0], -1)
+        w2 = L.f32c(w).reshape(w.shape[0], -1)
+        b2 = None if b is None else L.f32c(b)
+        B, I = x2.shape
+        O = w2.shape[0]
+        assert w2.shape[1] == I, (x.shape, w.shape)
+        y = torch.empty(B, O, dtype=torch.float32, device=x2.device)
+        aux = torch.empty(B, O, dtype=torch.float32, device=x2.device) if act == L.ACT_SIN else None
+        L.check(L.load().bnerv_dense_gemm_fwd(L.stream(), L.ptr(x2), L.ptr(w2), L.ptr(b2), L.ptr(y), L.ptr(aux), B, I, O, act), "bnerv_dense_gemm_fwd")
+        ctx.save_for_backward(x2, w2, y, aux)
+        ctx.act, ctx.has_b, ctx.xshape, ctx.wshape = act, b is not None, tuple(x.shape), tuple(w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w2, y, aux = ctx.saved_tensors
+        B, I = x2.shape
+        O = w2.shape[0]
+        dy = L.f32c(dy).reshape(B, O)
+        dw = torch.empty(O, I, dtype=torch.float32, device=x2.device)
+        db = torch.empty(O, dtype=torch.float32, device=x2.device) if ctx.has_b else None
+        dx = torch.empty(B, I, dtype=torch.float32, device=x2.device) if ctx.needs_input_grad[0] else None
+        L.check(L.load().bnerv_dense_gemm_bwd(L.stream(), L.ptr(x2), L.ptr(w2), L.ptr(y), L.ptr(aux), L.ptr(dy), L.ptr(dx), L.ptr(dw), L.ptr(db),
+                                              B, I, O, ctx.act), "bnerv_dense_gemm_bwd")
+        return (None if dx is None else dx.reshape(ctx.xshape)), dw.reshape(ctx.wshape), db, None
+
+
+def dense_gemm(x, w, b, act="none"):
+    """act(x [rows, I] w[O, I]^T + b) -> [rows, O] on the MFMA GEMM kernel (any row count; meant for >= 16 rows)."""
+    return _DenseGemm.apply(x, w, b, _ACT[act])
+
+
 def dense_grouped(xs, ws, bs, acts):
-    """Evaluate n independent dense layers y_i = act_i(W_i x_i + b_i) in one launch.
+    """Evaluate n independent dense layers y_i = act_i(W_i x_i + b_i).
     xs[i]: [B, I_i(,1,1)], ws[i]: [O_i, I_i(,1,1)], bs[i]: [O_i] or None, acts[i] in {'none','relu','sin'}.
-    Returns a list of [B, O_i] tensors."""
+    Returns a list of [B, O_i] tensors.  B = 1 per GPU (the reference's batch) is a set of GEMVs and goes to the grouped kernel in
+    ONE launch; layers applied to 16 or more rows (E-NeRV's 144-token MLPs) are GEMMs and go to the MFMA GEMM kernel."""
     n = len(xs)
     if xs[0].shape[0] >= DENSE_GEMM_MIN_B:
-        # token MLPs (E-NeRV: B = 144 positions): a GEMM, not the GEMV the grouped kernel is built for (one wave per output
-        # row walking B serially: 36 / 70 us per launch at C4) -> the library GEMM with the activation as a stock op
-        outs = []
-        for x, w, b, act in zip(xs, ws, bs, acts):
-            y = F.linear(x.flatten(1), w.flatten(1), b)
-            outs.append(torch.relu(y) if act == "relu" else torch.sin(y) if act == "sin" else y)
-        return outs
+        return [dense_gemm(x, w, b, act if act is not None else "none") for x, w, b, act in zip(xs, ws, bs, acts)]
     a = tuple(_ACT[x] for x in acts)
     return list(_DenseGrouped.apply(a, n, *xs, *ws, *bs))
 
@@ -586,6 +618,57 @@ class _LayerNormCF(torch.autograd.Function):
 def layernorm_cf(x, w, b, eps):
     """LayerNorm over dim 1 of an NCHW tensor, C <= 64 (model_blocks.py:250-270 `LayerNorm`, data_format channels_first)."""
     return _LayerNormCF.apply(x, w, b, eps)
+
+
+CNX_MLP_DIMS = (16, 32, 48, 64)
+
+
+class _CnxMlp(torch.autograd.Function):
+    """inp + gamma * pwconv2(gelu(pwconv1(x))) on NCHW tensors (ConvNeXt Block tail, model_blocks.py:245-258): one fused forward
+    kernel; backward = one fused kernel (dx and the two pixel-contraction operands) + two k = 1 weight-gradient launches."""
+
+    @staticmethod
+    def forward(ctx, x, inp, w1, b1, w2, b2, gamma):
+        x = L.f32c(L.require_device(x, "x")); inp = L.f32c(inp)
+        w1, b1, w2, b2 = (L.f32c(t) for t in (w1, b1, w2, b2))
+        gm = None if gamma is None else L.f32c(gamma)
+        B, Cc, H, W = x.shape
+        train = any(ctx.needs_input_grad)
+        out = torch.empty_like(x)
+        h1 = torch.empty(B, 4 * Cc, H, W, dtype=torch.float32, device=x.device) if train else None
+        L.check(L.load().bnerv_cnx_mlp_fwd(L.stream(), L.ptr(x), L.ptr(inp), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(gm), L.ptr(out),
+                                           L.ptr(h1), B, Cc, H * W), "bnerv_cnx_mlp_fwd")
+        if train:
+            ctx.save_for_backward(x, h1, w1, w2, b2, gm)
+        ctx.has_gamma = gamma is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h1, w1, w2, b2, gm = ctx.saved_tensors
+        dout = L.f32c(dout)
+        B, Cc, H, W = x.shape
+        dev = x.device
+        dx = torch.empty_like(x)
+        gbuf, dhbuf = torch.empty_like(h1), torch.empty_like(h1)
+        L.check(L.load().bnerv_cnx_mlp_bwd(L.stream(), L.ptr(h1), L.ptr(dout), L.ptr(w1), L.ptr(w2), L.ptr(gm), L.ptr(dx), L.ptr(gbuf), L.ptr(dhbuf),
+                                           B, Cc, H * W), "bnerv_cnx_mlp_bwd")
+        dw1 = torch.empty(4 * Cc, Cc, 1, 1, dtype=torch.float32, device=dev); db1 = torch.empty(4 * Cc, dtype=torch.float32, device=dev)
+        _wgrad(x, dhbuf, dw1, db1, B=B, Cin=Cc, Cout=4 * Cc, H=H, W=W, k=1, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE)
+        S = torch.empty(Cc, 4 * Cc, 1, 1, dtype=torch.float32, device=dev); t = torch.empty(Cc, dtype=torch.float32, device=dev)
+        _wgrad(gbuf, dout, S, t, B=B, Cin=4 * Cc, Cout=Cc, H=H, W=W, k=1, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE)
+        S = S.reshape(Cc, 4 * Cc)
+        if ctx.has_gamma:      # [C x 4C] bookkeeping: dw2 = gamma S, db2 = gamma t, dgamma = rowsum(w2 * S) + b2 t
+            dgamma = (w2 * S).sum(1) + b2 * t
+            dw2, db2 = gm[:, None] * S, gm * t
+        else:
+            dgamma, dw2, db2 = None, S, t
+        return dx, dout, dw1.reshape(4 * Cc, Cc), db1, dw2, db2, dgamma
+
+
+def cnx_mlp(x, inp, w1, b1, w2, b2, gamma):
+    """inp + gamma * (w2 gelu(w1 x + b1) + b2) per pixel; x, inp [B, C, H, W], w1 [4C, C], w2 [C, 4C]; C in CNX_MLP_DIMS."""
+    return _CnxMlp.apply(x, inp, w1, b1, w2, b2, gamma)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -240,7 +240,6 @@ def train(local_rank, args):
         seed_fn(args.manualSeed)
     if not torch.cuda.is_available():
         raise RuntimeError("train_nerv_all: no ROCm GPU visible -- the decoder path has no CPU fallback")
-    torch.backends.cudnn.benchmark = True   # as the reference (on ROCm: MIOpen solver search for the encoder's stock convs)
     world, device = _join_process_group(local_rank, args)
     is_main = local_rank in (0, None)
     args.metric_names = list(rt.METRIC_NAMES)

@@ -232,6 +232,29 @@ int bnerv_cem_scale_fwd(void* stream, const bnerv_cem_chunk* chunk, float* stats
 int bnerv_cem_scale_bwd(void* stream, const bnerv_cem_chunk_bwd* chunk, const float* stats, const float* d_bits, float* dscale);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * GEMM-shaped dense work on v_mfma_f32_16x16x4_f32 (csrc/gemm.hip).
+ *
+ * Dense layers applied to many rows (B >= 16: the token MLPs of E-NeRV's transformer stem, NeRV_MLP at larger batches;
+ * reference model_blocks.py:66-71, model_enerv.py:22-60) -- same arguments as one group of bnerv_dense_grouped_*:
+ *   fwd: y [B,O] = act(x [B,I] w[O,I]^T + b), aux [B,O] = cos(pre) for BNERV_ACT_SIN (may be NULL)
+ *   bwd: dw [O,I], db [O] (may be NULL), dx [B,I] (may be NULL) from dy [B,O]; y (relu) / aux (sin) as the activation needs. */
+int bnerv_dense_gemm_fwd(void* stream, const float* x, const float* w, const float* b, float* y, float* aux, int B, int I, int O, int act);
+int bnerv_dense_gemm_bwd(void* stream, const float* x, const float* w, const float* y, const float* aux, const float* dy,
+                         float* dx, float* dw, float* db, int B, int I, int O, int act);
+
+/* Pointwise MLP of the ConvNeXt encoder block (reference model_blocks.py:245-258, channels_last form:
+ *   x = pwconv2(gelu(pwconv1(x))); x = gamma * x; return input + x ) on NCHW tensors, C in {16, 32, 48, 64}:
+ *   fwd: out [B,C,HW] = inp + gamma * (w2 [C,4C] gelu(w1 [4C,C] x + b1) + b2);  hsave [B,4C,HW] (may be NULL) keeps w1 x + b1
+ *   bwd: from h1 (= hsave) and dout: dx [B,C,HW] = d loss / d x, and the two pixel-contraction operands of the weight gradients,
+ *        gbuf = gelu(h1), dhbuf = d loss / d h1 ([B,4C,HW] each).  The weight / bias / gamma gradients follow from two
+ *        bnerv_conv_wgrad (k = 1) calls: (x, dhbuf) -> dw1, db1 and (gbuf, dout) -> S, t with dw2 = gamma S, db2 = gamma t,
+ *        dgamma = rowsum(w2 * S) + b2 * t.  (d loss / d inp is dout itself.) */
+int bnerv_cnx_mlp_fwd(void* stream, const float* x, const float* inp, const float* w1, const float* b1, const float* w2, const float* b2,
+                      const float* gamma, float* out, float* hsave, int B, int C, int HW);
+int bnerv_cnx_mlp_bwd(void* stream, const float* h1, const float* dout, const float* w1, const float* w2, const float* gamma,
+                      float* dx, float* gbuf, float* dhbuf, int B, int C, int HW);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Range-ANS entropy coder of the compression report (HOST buffers; csrc/ans.cpp).  Replaces constriction's AnsCoder +
  * QuantizedGaussian / Categorical models behind `real_bitrate` (lib/entropy_model.py:46-62, :65-81; consumed at
  * train_nerv_compression.py:484-512, 560-577): rANS, 64-bit state, 32-bit words, 24-bit probabilities, symbols pushed in

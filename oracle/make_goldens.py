@@ -134,6 +134,33 @@ def gen_blocks(R):
     np.savez_compressed(os.path.join(OUT, "blocks.npz"), **out)
 
 
+def gen_convnext_blocks(R):
+    """ConvNeXt `Block` of the HNeRV_Boost encoder (model_blocks.py:223-247: dwconv 7x7 -> LayerNorm -> pwconv1 -> GELU -> pwconv2 ->
+    gamma -> + input, channels_last inside) at the widths the recipes use (64, 16) and two more the fused kernel is built for,
+    with a layer scale large enough for the MLP branch to matter in the comparison, plus the channels_first LayerNorm + patchify
+    down-sampling pair of the stem (model_blocks.py:305-312)."""
+    out = {}
+    mb = R.model_blocks
+    for i, (dim, B, H, W) in enumerate(((64, 1, 11, 19), (16, 2, 9, 16), (32, 1, 8, 8), (48, 1, 5, 7))):
+        torch.manual_seed(60 + i)
+        blk = mb.Block(dim=dim, drop_path=0.0, layer_scale_init_value=0.5)
+        with torch.no_grad():                               # (the reference initialises with trunc_normal(0.02) / zero biases through
+            for p_ in blk.parameters():                     #  ConvNeXt._init_weights; here every parameter gets signal)
+                if p_.dim() > 0 and p_ is not blk.gamma:
+                    p_.normal_(0.0, 0.2)
+            blk.gamma.uniform_(0.2, 0.9)
+        x = torch.randn(B, dim, H, W).requires_grad_(True)
+        y = blk(x)
+        cot, gs = _grads(y, [x], list(blk.parameters()), 70 + i)
+        name = f"cnx{dim}"
+        out[f"{name}/x"], out[f"{name}/y"], out[f"{name}/cot"], out[f"{name}/dx"] = npf(x), npf(y), npf(cot), npf(gs[0])
+        for (pn, _), g in zip(blk.named_parameters(), gs[1:]):
+            out[f"{name}/grad/{pn}"] = npf(g)
+        for k, v in sd_np(blk).items():
+            out[f"{name}/sd/{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "blocks_cnx.npz"), **out)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def _model(R, args):
     if args.model == "NeRV_Boost":
@@ -409,8 +436,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = ref_harness.load_reference()
-    which = sys.argv[1:] or ["pe", "blocks", "tiny", "full", "full1080", "loss", "optim", "host", "cem", "cem_model"]
-    fns = dict(pe=gen_pe, blocks=gen_blocks, tiny=gen_tiny_models, full=gen_full_models, full1080=gen_full_1080, loss=gen_loss, optim=gen_optim, host=gen_host, cem=gen_cem, cem_model=gen_cem_model)
+    which = sys.argv[1:] or ["pe", "blocks", "cnx", "tiny", "full", "full1080", "loss", "optim", "host", "cem", "cem_model"]
+    fns = dict(pe=gen_pe, blocks=gen_blocks, cnx=gen_convnext_blocks, tiny=gen_tiny_models, full=gen_full_models, full1080=gen_full_1080, loss=gen_loss, optim=gen_optim, host=gen_host, cem=gen_cem, cem_model=gen_cem_model)
     for w in which:
         print("generating", w, flush=True)
         fns[w](R)

@@ -514,3 +514,46 @@ def test_cem_fused_quantise_rate_vs_oracle(ops, training):
     got = torch.autograd.grad(loss, wg + sg)
     for i, (x, r) in enumerate(zip(got, ref_g)):
         close(x, r, rtol=2e-3, atol=2e-3 * float(r.abs().max()) + 1e-6, msg=f"cem grad {i}")
+
+
+@pytest.mark.parametrize("dim", [64, 16, 32, 48])
+def test_convnext_block_against_reference_golden(dim):
+    """Row N3: the whole ConvNeXt Block on HIP kernels (depthwise 7x7, channel LayerNorm, ONE fused pwconv1 -> GELU -> pwconv2 ->
+    gamma -> + input kernel; backward through the fused data-gradient kernel and two k = 1 weight-gradient launches) against the
+    REFERENCE's channels_last Block (tests/golden/blocks_cnx.npz, oracle/make_goldens.py gen_convnext_blocks): output, dx and
+    every parameter gradient."""
+    from boosting_nerv_amd import model_blocks as mb
+    npz = load_golden("blocks_cnx.npz")
+    b = group(npz, f"cnx{dim}/")
+    blk = mb.Block(dim=dim, drop_path=0.0, layer_scale_init_value=0.5)
+    blk.load_state_dict({k[3:]: v for k, v in b.items() if k.startswith("sd/")})
+    blk.to(DEV)
+    x = b["x"].to(DEV).requires_grad_(True)
+    y = blk(x)
+    close(y, b["y"], msg=f"cnx{dim} fwd")
+    params = dict(blk.named_parameters())
+    gs = torch.autograd.grad(y, [x] + list(params.values()), b["cot"].to(DEV))
+    close(gs[0], b["dx"], msg=f"cnx{dim} dx")
+    for (pn, _), gval in zip(params.items(), gs[1:]):
+        close(gval, b[f"grad/{pn}"], msg=f"cnx{dim} grad {pn}")
+    with torch.no_grad():                                   # decode-style call: nothing saved, same values
+        assert torch.equal(blk(x.detach()), y.detach())
+
+
+def test_dense_gemm_shapes(ops):
+    """The MFMA GEMM behind dense layers with >= 16 rows and the patchify convs: ragged sizes (no multiple of the 32 x 32 block
+    tile, K not a multiple of 16), every activation, with and without bias / input gradient."""
+    g = torch.Generator().manual_seed(21)
+    for (B, I, O, act, bias) in ((144, 128, 128, "relu", True), (17, 75, 64, "none", True), (300, 33, 5, "sin", False), (64, 16, 1152, "sin", True), (16, 1, 3, "none", True)):
+        x = torch.randn(B, I, generator=g).requires_grad_(True)
+        w = (torch.randn(O, I, generator=g) / math.sqrt(I)).requires_grad_(True)
+        b = torch.randn(O, generator=g).requires_grad_(True) if bias else None
+        ref = cpu_ref._act(F.linear(x, w, b), act)
+        cot = torch.randn(B, O, generator=g)
+        leaves = [x, w] + ([b] if bias else [])
+        rg = torch.autograd.grad(ref, leaves, cot)
+        gl = [gpu(t) for t in leaves]
+        out = ops.dense_gemm(gl[0], gl[1], gl[2] if bias else None, act)
+        close(out, ref, msg=f"gemm fwd {B}x{I}x{O}")
+        for n, a, r in zip("xwb", torch.autograd.grad(out, gl, cot.to(DEV)), rg):
+            close(a, r, msg=f"gemm d{n} {B}x{I}x{O}")
