@@ -115,7 +115,8 @@ SYMBOLS = {
     "bnerv_cem_scale_fwd": (_I, [_V, C.POINTER(CemChunk), _V]),
     "bnerv_cem_scale_bwd": (_I, [_V, C.POINTER(CemChunkBwd), _V, _V, _V]),
     "bnerv_dense_gemm_fwd": (_I, [_V, _V, _V, _V, _V, _V, _I, _I, _I, _I]),
-    "bnerv_dense_gemm_bwd": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _I]),
+    "bnerv_dense_gemm_bwd_ws_bytes": (_Z, [_I, _I, _I]),
+    "bnerv_dense_gemm_bwd": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _Z, _I, _I, _I, _I]),
     "bnerv_cnx_mlp_fwd": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I]),
     "bnerv_cnx_mlp_bwd": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I]),
     "bnerv_ans_encode_gaussian": (C.c_long, [_V, _Z, _I, _I, C.c_double, C.c_double, _V, _Z]),

@@ -27,6 +27,7 @@ struct GemmArgs {
     long sam, sak, sbk, sbn;
     int ldc;              // row stride of c (EPI_SPLIT_LAST: N - 1 real columns)
     int pro, epi, ones_col;
+    int kchunk;           // > 0: split K -- block z handles k in [z * kchunk, (z + 1) * kchunk) and writes slab z of c ([z][M][ldc], EPI_NONE)
 };
 
 __global__ __launch_bounds__(256) void dense_gemm_kernel(const GemmArgs g) {
@@ -37,12 +38,15 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(const GemmArgs g) {
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int mt = wave & 1, nt = wave >> 1;
     f32x4 acc{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
+    const int kbeg = g.kchunk > 0 ? (int)blockIdx.z * g.kchunk : 0;
+    const int kend = g.kchunk > 0 ? min(g.K, kbeg + g.kchunk) : g.K;
+    float* cbase = g.c + (g.kchunk > 0 ? (size_t)blockIdx.z * g.M * g.ldc : 0);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
         // stage A: 32 x 16 and B: 16 x 32 (two elements of each per thread), zero outside the matrix
         for (int e = tid; e < 512; e += 256) {
             const int m = e >> 4, k = e & 15;
             float v = 0.f;
-            if (m0 + m < g.M && k0 + k < g.K) {
+            if (m0 + m < g.M && k0 + k < kend) {
                 const long idx = (long)(m0 + m) * g.sam + (long)(k0 + k) * g.sak;
                 v = g.a[idx];
                 if (g.pro == PRO_RELU) v = g.a_aux[idx] > 0.f ? v : 0.f;
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(const GemmArgs g) {
             s_a[m][k] = v;
             const int kb = e >> 5, n = e & 31;
             float u = 0.f;
-            if (k0 + kb < g.K && n0 + n < g.N)
+            if (k0 + kb < kend && n0 + n < g.N)
                 u = (g.ones_col && n0 + n == g.N - 1) ? 1.0f : g.b[(long)(k0 + kb) * g.sbk + (long)(n0 + n) * g.sbn];
             s_b[kb][n] = u;
         }
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(const GemmArgs g) {
         float v = acc[r] + bias;
         if (g.epi == EPI_SPLIT_LAST) {
             if (n == g.N - 1) { if (g.c2) g.c2[m] = v; }
-            else g.c[(long)m * g.ldc + n] = v;
+            else cbase[(long)m * g.ldc + n] = v;
             continue;
         }
         if (g.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
@@ -82,15 +86,31 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(const GemmArgs g) {
             v = sv;
             if (g.c2) g.c2[(long)m * g.ldc + n] = cv;
         }
-        g.c[(long)m * g.ldc + n] = v;
+        cbase[(long)m * g.ldc + n] = v;
     }
 }
 
-int launch_gemm(hipStream_t st, const GemmArgs& g) {
-    hipLaunchKernelGGL(dense_gemm_kernel, dim3(cdiv(g.N, 32), cdiv(g.M, 32)), dim3(256), 0, st, g);
+// out[m][n] = sum_z slab[z][m][n] in a fixed order; column N-1 goes to c2 (bias gradient)
+__global__ __launch_bounds__(256) void gemm_splitk_finish_kernel(const float* slab, int nz, int M, int N, float* c, float* c2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * N) return;
+    float s0 = 0.f, s1 = 0.f;
+    int z = 0;
+    for (; z + 1 < nz; z += 2) { s0 += slab[(size_t)z * M * N + i]; s1 += slab[(size_t)(z + 1) * M * N + i]; }
+    if (z < nz) s0 += slab[(size_t)z * M * N + i];
+    const int m = i / N, n = i - m * N;
+    if (n == N - 1) { if (c2) c2[m] = s0 + s1; }
+    else c[(size_t)m * (N - 1) + n] = s0 + s1;
+}
+
+int launch_gemm(hipStream_t st, const GemmArgs& g, int nz = 1) {
+    hipLaunchKernelGGL(dense_gemm_kernel, dim3(cdiv(g.N, 32), cdiv(g.M, 32), nz), dim3(256), 0, st, g);
     BNERV_LAUNCH_CHECK("dense_gemm");
     return BNERV_OK;
 }
+
+constexpr int GEMM_SPLITK_MIN_ROWS = 4096;               // weight gradients over more rows than this are split along the rows
+int dw_splits(int B) { return B < GEMM_SPLITK_MIN_ROWS ? 1 : (cdiv(B, 1024) > 512 ? 512 : cdiv(B, 1024)); }
 
 // ---------------------------------------------------------------------------------------------------------------- ConvNeXt MLP
 // x, inp, out, dout, dx: [B, C, HW];  w1 [4C, C], b1 [4C], w2 [C, 4C], b2 [C], gamma [C] (may be NULL: no layer scale).
@@ -335,9 +355,16 @@ extern "C" int bnerv_dense_gemm_fwd(void* stream, const float* x, const float* w
     return launch_gemm(reinterpret_cast<hipStream_t>(stream), g);
 }
 
-// dy [B, O]; y (relu mask) / aux (cos) [B, O] as the activation needs; dx [B, I] (may be NULL); dw [O, I]; db [O] (may be NULL)
+extern "C" size_t bnerv_dense_gemm_bwd_ws_bytes(int B, int I, int O) {
+    if (B <= 0 || I <= 0 || O <= 0) return 0;
+    const int nz = dw_splits(B);
+    return nz > 1 ? (size_t)nz * O * (I + 1) * sizeof(float) : 0;
+}
+
+// dy [B, O]; y (relu mask) / aux (cos) [B, O] as the activation needs; dx [B, I] (may be NULL); dw [O, I]; db [O] (may be NULL);
+// ws: bnerv_dense_gemm_bwd_ws_bytes (row-split partial weight gradients when B is large: the patchify convs have B = pixels)
 extern "C" int bnerv_dense_gemm_bwd(void* stream, const float* x, const float* w, const float* y, const float* aux, const float* dy,
-                                    float* dx, float* dw, float* db, int B, int I, int O, int act) {
+                                    float* dx, float* dw, float* db, void* ws, size_t ws_bytes, int B, int I, int O, int act) {
     BNERV_REQUIRE(x && w && dy && dw && B > 0 && I > 0 && O > 0, "dense_gemm_bwd: bad args");
     if (act == BNERV_ACT_RELU) BNERV_REQUIRE(y, "dense_gemm_bwd: relu needs y");
     if (act == BNERV_ACT_SIN) BNERV_REQUIRE(aux, "dense_gemm_bwd: sin needs aux");
@@ -350,7 +377,21 @@ extern "C" int bnerv_dense_gemm_bwd(void* stream, const float* x, const float* w
     g.M = O; g.N = I + 1; g.K = B;
     g.sam = 1; g.sak = O; g.sbk = I; g.sbn = 1; g.ldc = I;
     g.pro = pro; g.epi = EPI_SPLIT_LAST; g.ones_col = 1;
-    int rc = launch_gemm(st, g);
+    const int nz = dw_splits(B);
+    int rc;
+    if (nz > 1) {
+        const size_t need = bnerv_dense_gemm_bwd_ws_bytes(B, I, O);
+        if (!ws || ws_bytes < need) return bnerv_set_error(BNERV_E_WS, "dense_gemm_bwd: workspace %zu < %zu", ws_bytes, need);
+        g.c = reinterpret_cast<float*>(ws); g.c2 = nullptr;
+        g.ldc = I + 1; g.epi = EPI_NONE;
+        g.kchunk = ((cdiv(B, nz) + 15) / 16) * 16;
+        rc = launch_gemm(st, g, cdiv(B, g.kchunk));
+        if (rc != BNERV_OK) return rc;
+        hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3(cdiv(O * (I + 1), 256)), dim3(256), 0, st, reinterpret_cast<const float*>(ws), cdiv(B, g.kchunk), O, I + 1, dw, db);
+        BNERV_LAUNCH_CHECK("gemm_splitk_finish");
+    } else {
+        rc = launch_gemm(st, g);
+    }
     if (rc != BNERV_OK || !dx) return rc;
     // dx[b][i] = sum_o dpre[b][o] * w[o][i]
     GemmArgs h{};

@@ -237,8 +237,11 @@ class _DenseGemm(torch.autograd.Function):
         dw = torch.empty(O, I, dtype=torch.float32, device=x2.device)
         db = torch.empty(O, dtype=torch.float32, device=x2.device) if ctx.has_b else None
         dx = torch.empty(B, I, dtype=torch.float32, device=x2.device) if ctx.needs_input_grad[0] else None
-        L.check(L.load().bnerv_dense_gemm_bwd(L.stream(), L.ptr(x2), L.ptr(w2), L.ptr(y), L.ptr(aux), L.ptr(dy), L.ptr(dx), L.ptr(dw), L.ptr(db),
-                                              B, I, O, ctx.act), "bnerv_dense_gemm_bwd")
+        lib = L.load()
+        nbytes = lib.bnerv_dense_gemm_bwd_ws_bytes(B, I, O)
+        ws = _ws(nbytes, x2.device) if nbytes else None
+        L.check(lib.bnerv_dense_gemm_bwd(L.stream(), L.ptr(x2), L.ptr(w2), L.ptr(y), L.ptr(aux), L.ptr(dy), L.ptr(dx), L.ptr(dw), L.ptr(db),
+                                         L.ptr(ws), nbytes, B, I, O, ctx.act), "bnerv_dense_gemm_bwd")
         return (None if dx is None else dx.reshape(ctx.xshape)), dw.reshape(ctx.wshape), db, None
 
 

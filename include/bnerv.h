@@ -239,8 +239,9 @@ int bnerv_cem_scale_bwd(void* stream, const bnerv_cem_chunk_bwd* chunk, const fl
  *   fwd: y [B,O] = act(x [B,I] w[O,I]^T + b), aux [B,O] = cos(pre) for BNERV_ACT_SIN (may be NULL)
  *   bwd: dw [O,I], db [O] (may be NULL), dx [B,I] (may be NULL) from dy [B,O]; y (relu) / aux (sin) as the activation needs. */
 int bnerv_dense_gemm_fwd(void* stream, const float* x, const float* w, const float* b, float* y, float* aux, int B, int I, int O, int act);
+size_t bnerv_dense_gemm_bwd_ws_bytes(int B, int I, int O);      /* 0 for small B; row-split partial weight gradients otherwise */
 int bnerv_dense_gemm_bwd(void* stream, const float* x, const float* w, const float* y, const float* aux, const float* dy,
-                         float* dx, float* dw, float* db, int B, int I, int O, int act);
+                         float* dx, float* dw, float* db, void* ws, size_t ws_bytes, int B, int I, int O, int act);
 
 /* Pointwise MLP of the ConvNeXt encoder block (reference model_blocks.py:245-258, channels_last form:
  *   x = pwconv2(gelu(pwconv1(x))); x = gamma * x; return input + x ) on NCHW tensors, C in {16, 32, 48, 64}:

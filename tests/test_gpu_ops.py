@@ -544,7 +544,8 @@ def test_dense_gemm_shapes(ops):
     """The MFMA GEMM behind dense layers with >= 16 rows and the patchify convs: ragged sizes (no multiple of the 32 x 32 block
     tile, K not a multiple of 16), every activation, with and without bias / input gradient."""
     g = torch.Generator().manual_seed(21)
-    for (B, I, O, act, bias) in ((144, 128, 128, "relu", True), (17, 75, 64, "none", True), (300, 33, 5, "sin", False), (64, 16, 1152, "sin", True), (16, 1, 3, "none", True)):
+    for (B, I, O, act, bias) in ((144, 128, 128, "relu", True), (17, 75, 64, "none", True), (300, 33, 5, "sin", False), (64, 16, 1152, "sin", True), (16, 1, 3, "none", True),
+                                  (9000, 75, 64, "none", True)):       # rows beyond the split threshold: row-split weight gradient (patchify conv)
         x = torch.randn(B, I, generator=g).requires_grad_(True)
         w = (torch.randn(O, I, generator=g) / math.sqrt(I)).requires_grad_(True)
         b = torch.randn(O, generator=g).requires_grad_(True) if bias else None

@@ -1,4 +1,4 @@
-"""Run ONE hot kernel a few times (for rocprofv3 --pmc runs).  usage: kone.py conv|wgrad|conv38|wgrad38 [reps]
+"""Run ONE hot kernel a few times (for rocprofv3 --pmc runs).  usage: kone.py conv|conv_k2s|wgrad|conv38|wgrad38 [reps]
 conv / wgrad: the 12->12 3x3 layer at 720x1280 (C1); conv38 / wgrad38: the 38->38 3x3 layer at 1080x1920 (C3)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,9 @@ w, b = torch.randn(C, C, 3, 3, device=dev) / 10, torch.randn(C, device=dev)
 sc, sh = torch.randn(B, C, device=dev) * 0.1, torch.randn(B, C, device=dev) * 0.1
 out = torch.empty_like(x); dw, db = torch.empty_like(w), torch.empty_like(b)
 for _ in range(reps):
-    if which.startswith("conv"):
+    if which == "conv_k2s":       # the TAT conv0 forward the train step launches: affine -> conv -> bias -> gelu, gelu'
+        ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=sc, shift=sh, out2=g)
+    elif which.startswith("conv"):
         ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS, scale=sc, shift=sh)
     else:
         ops._wgrad(x, g, dw, db, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE)
