@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # PMC passes (one counter group per pass) over tools/kone.py for one kernel name pattern.  usage: tools/pmc_bf.sh <kone mode> <kernel pattern> <out file>
 set -u
-R=$PWD; MODE=$1; PAT=$2; OUT=$3
+R=$(cd "$(dirname "$0")/.." && pwd); MODE=$1; PAT=$2; OUT=$3
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_x
 i=0

@@ -1,0 +1,73 @@
+"""Turn the files tools/round2_evidence.sh left in gpurun_out/e2_* into the tracked summaries under profiles/r02_*.
+usage: python tools/write_profiles_r02.py"""
+import json
+import os
+import re
+import shutil
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O, P = os.path.join(R, "gpurun_out", "e2_"), os.path.join(R, "profiles", "r02_")
+rd = lambda name: open(O + name).read()
+for c in ("c1", "c3", "c4", "c5"):
+    shutil.copy(O + f"bench_{c}.json", P + f"bench_{c}.json")
+b = {c: json.load(open(O + f"bench_{c}.json")) for c in ("c1", "c3", "c4", "c5")}
+
+
+def counters(txt):
+    return {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+([A-Z_0-9a-z]+)\s+(\d+)\s+\(n=", txt, re.M)}
+
+
+k2s, wg = counters(rd("pmc_k2s.txt")), counters(rd("pmc_wgrad.txt"))
+hbm = (2 * k2s["FETCH_SIZE"] + k2s["WRITE_SIZE"]) * 1024
+json.dump({"kernel": "conv_lean_kernel<3,IN_AFFINE,EP_BIAS_GELU,3> (K2s: TAT conv0 forward) 12->12 3x3 @720x1280", "fetch_size_kb": k2s["FETCH_SIZE"], "fetch_correction": 2,
+           "write_size_kb": k2s["WRITE_SIZE"], "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 132715584,
+           "source": "profiles/r02_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction)"}, open(P + "traffic.json", "w"), indent=1)
+mb = lambda kb: kb * 1024 / 1e6
+open(P + "pmc.md", "w").write(f"""# Round 2 -- PMC counters of the step's dominant kernels, rocprofv3 --pmc, one counter group per pass, MI355X
+
+Command per pass: `rocprofv3 --kernel-trace --output-format csv --pmc <counters> -- python tools/kone.py conv_k2s|wgrad 4` (tools/pmc_bf.sh; chip-wide sums per
+dispatch, 4 dispatches averaged).  FETCH_SIZE / WRITE_SIZE in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section).  Shape: 12->12 3x3 @720x1280 (C1).
+
+| kernel (as the train step launches it) | FETCH_SIZE x2 | WRITE_SIZE | HBM bytes / launch | algorithmic bytes / launch |
+|---|---|---|---|---|
+| K2s `conv_lean_kernel<3,IN_AFFINE,EP_BIAS_GELU,3>` (conv0 fwd, writes gelu and gelu') | 2 x {k2s['FETCH_SIZE']:.0f} KB = {mb(2 * k2s['FETCH_SIZE']):.1f} MB | {mb(k2s['WRITE_SIZE']):.1f} MB | {hbm / 1e6:.1f} MB | 132.7 MB (1 plane in, 2 out) -> {hbm / 132715584:.3f}x |
+| `wgrad_lean_kernel<3,IN_PLAIN,0>` (weight gradient) | 2 x {wg['FETCH_SIZE']:.0f} KB = {mb(2 * wg['FETCH_SIZE']):.1f} MB | {mb(wg['WRITE_SIZE']):.1f} MB | {mb(2 * wg['FETCH_SIZE'] + wg['WRITE_SIZE']):.1f} MB | 88.5 MB + slabs |
+
+K2s issue mix (chip-wide sums per dispatch): MFMA {k2s.get('SQ_INSTS_MFMA', 0):.0f}, VALU incl. MFMA {k2s.get('SQ_INSTS_VALU', 0):.0f}, SALU {k2s.get('SQ_INSTS_SALU', 0):.0f},
+LDS {k2s.get('SQ_INSTS_LDS', 0):.0f}; SQ_VALU_MFMA_BUSY_CYCLES {k2s.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.0f} over GRBM_GUI_ACTIVE {k2s.get('GRBM_GUI_ACTIVE', 0):.0f} / 8 XCDs x 1024 SIMDs
+= {k2s.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(k2s.get('GRBM_GUI_ACTIVE', 1) / 8 * 1024, 1) * 100:.0f} % matrix-pipe occupancy (12 -> 16 padding included); per MFMA: {(k2s.get('SQ_INSTS_VALU', 0) - k2s.get('SQ_INSTS_MFMA', 0)) / max(k2s.get('SQ_INSTS_MFMA', 1), 1):.2f} other VALU + {k2s.get('SQ_INSTS_SALU', 0) / max(k2s.get('SQ_INSTS_MFMA', 1), 1):.2f} SALU.
+
+```
+{rd('pmc_k2s.txt')}
+{rd('pmc_wgrad.txt')}```
+""")
+r = b["c1"]["roofline"]
+hdr = lambda title, cmd, extra="": f"# Round 2 -- {title}\n\nCommand: `{cmd}`.\n{extra}\n"
+open(P + "c1_step_kerneltrace.md", "w").write(hdr("C1 train step; rocprofv3 --kernel-trace --stats (eager, 40+6 steps incl. setup), MI355X",
+    "rocprofv3 --kernel-trace --stats -d /tmp/ks_c1 -- python bench.py --steps 40 --warmup 6 --no_cpu_baseline --no_graph` (tools/round2_evidence.sh",
+    f"Bench line of the same build (profiles/r02_bench_c1.json): {b['c1']['value']} frames/s, {b['c1']['ms_per_step']} ms/step (hipGraph).  Final-stage conv family "
+    f"(flop-weighted over the step's 14 launches): {r['achieved']} TFLOP/s = {100 * r['frac']:.1f} % of the fp32 MFMA peak, slowest member {r['slowest']['kernel']} "
+    f"{r['slowest']['achieved']} TF; whole step {100 * b['c1']['step_roofline']['frac_of_t_roof']:.1f} % of its roofline time; eval PSNR {b['c1']['eval_psnr_db']} dB; CPU oracle "
+    f"{b['c1']['cpu_baseline']['value']} frames/s on {b['c1']['cpu_baseline']['cores']} threads ({b['c1']['cpu_baseline']['cpu']}).  Rows `at::native::*` are the synthetic-clip generator (setup).\n")
+    + rd("c1_trace.md"))
+for c, name in (("c3", "HNeRV-boost 3M, 1080x1920"), ("c4", "E-NeRV-boost 3M, 1080x1920")):
+    open(P + f"{c}_step_kerneltrace.md", "w").write(hdr(f"{c.upper()} train step ({name}); rocprofv3 --kernel-trace --stats (20+5 steps incl. graph capture warm-up), MI355X",
+        f"rocprofv3 --kernel-trace --stats -d /tmp/ks_{c} -- python bench.py --config {c} --steps 20 --warmup 5 --no_cpu_baseline",
+        f"Bench line of the same build (profiles/r02_bench_{c}.json): {b[c]['value']} frames/s, {b[c]['ms_per_step']} ms/step; final-stage family {b[c]['roofline']['achieved']} TF "
+        f"({100 * b[c]['roofline']['frac']:.1f} %); CPU oracle {b[c]['cpu_baseline']['value']} frames/s.  No MIOpen / rocBLAS kernel is left in the trace: the ConvNeXt encoder "
+        f"(depthwise, LayerNorm, fused pointwise MLP, patchify GEMMs) and the token MLPs run on the kernels of this library; `at::native::*` rows are reshapes / permute copies and the synthetic clip.\n") + rd(f"{c}_trace.md"))
+for c in ("c1", "c3"):
+    open(P + f"timeline_{c}.md", "w").write(f"# Round 2 -- per-launch timeline of one eager {c.upper()} train step (tools/ktimeline.py over `rocprofv3 --kernel-trace --output-format csv -- python bench.py "
+                                            f"--config {c} --steps 4 --warmup 5 --no_cpu_baseline --no_graph`), MI355X\n\nColumns: index, start, duration, gap to the previous launch (eager launch gaps: absent under graph replay), "
+                                            f"grid / wg as reported by the tracer, kernel.\n\n" + rd(f"timeline_{c}.md"))
+open(P + "kernel_microbench.md", "w").write("# Round 2 -- hot kernels through the C-ABI (HIP events), MI355X\n\n## f32 MFMA kernels at the C1 shapes (tools/kbench.py 30; default build)\n\n```\n" + rd("kbench.txt") + "```\n")
+open(P + "split_kernels.md", "w").write(
+    "# Round 2 -- the split 16-bit conv kernels (csrc/convbf.hip, opt-in through BNERV_SPLIT) against the f32 lean kernels, MI355X\n\n"
+    "Same shapes, same C-ABI calls, `BNERV_SPLIT=<mode> python tools/kbench.py 30`; columns: f32 lean (default) | bf16x6 | f16x3 (scaled) | bf16x3.\n\n```\n"
+    + "\n".join(a[:78] + "  | " + b_[58:78] + " | " + c_[58:78] + " | " + d_[58:78] for a, b_, c_, d_ in zip(rd("kbench.txt").splitlines()[1:20], rd("kbench_bf16x6.txt").splitlines()[:19],
+                                                                                                     rd("kbench_f16x3.txt").splitlines()[:19], rd("kbench_bf16x3.txt").splitlines()[:19]))
+    + "\n```\n\n## PMC of conv_bf_kernel<3,IN_AFFINE,EP_BIAS,bf16x6> (12->12 @720x1280)\n\n```\n" + rd("pmc_bf16x6.txt")
+    + "```\n\n## tools/ubench/mfma_interleave: VALU work beside the f32 MFMA (16x16x4) -- interleaved in the wave or phased, 1 / 2 / 4 waves per SIMD\n\n```\n" + rd("ub_interleave.txt")
+    + "```\n\n## tools/ubench/bf16_split: VALU beside the bf16 MFMA (16x16x32), and accuracy of split products against fp64\n\n```\n" + rd("ub_bf16split.txt") + "```\n")
+for c in ("c1", "c3", "c4", "c5"):
+    print(c, b[c]["value"], b[c]["ms_per_step"], b[c]["roofline"]["achieved"], (b[c].get("cpu_baseline") or {}).get("value"))
