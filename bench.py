@@ -349,6 +349,12 @@ def main():
                # frames/s of one video and value(N) / value(1) is north_star's strong-scaling factor of an epoch
                "scaling": "weak",
                "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+               # tensors, accumulators and every elementwise op are fp32.  The 3x3 convs with more than 16 input or output channels
+               # (none in C1 above 45x80; the 22..95-channel stages of C3 / C4) form their products on the 16-bit matrix pipe from
+               # THREE bf16 pieces per fp32 operand and six partial products accumulated in fp32 -- measured error 7.9e-8 * sum|a b|,
+               # below the 1.3e-7 of the f32 MFMA's own k-ordered chain (profiles/r02_split_kernels.md); BNERV_SPLIT_WIDE=off keeps
+               # them on v_mfma_f32_16x16x4_f32
+               "arithmetic": "fp32 storage / accumulation; wide convs: exact 3-piece bf16 split products (bf16x6) on v_mfma_f32_16x16x32_bf16" if a.config != "c1" else "fp32 (v_mfma_f32_16x16x4_f32 convs); the 30-channel 45x80 stage is below the wide kernel's tile threshold",
                "config": {"workload": f"{r['name']} ({n_params} params, fc_dim {args.fc_dim}) train step on a synthetic "
                                       f"{'Bunny' if a.config == 'c1' else 'UVG'}-shaped clip {r['n']}x3x{r['h']}x{r['w']}: "
                                       f"{'quantise + rate term (CEM) + ' if a.config == 'c5' else ''}decoder fwd + {args.loss} + bwd + "

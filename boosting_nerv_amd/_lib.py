@@ -103,6 +103,8 @@ SYMBOLS = {
     "bnerv_reduce_slabs": (_I, [_V, _V, _I, _I, _V]),
     "bnerv_ctx_create": (_I, [C.POINTER(C.c_void_p)]),
     "bnerv_ctx_destroy": (None, [_V]),
+    "bnerv_ctx_scratch_bytes": (_Z, [_V]),
+    "bnerv_ctx_reserve": (_I, [_V, _Z]),
     "bnerv_reduce_slabs_deferred": (_I, [_V, _V, _V, _I, _I, _V]),
     "bnerv_flush_deferred": (_I, [_V, _V]),
     "bnerv_deferred_pending": (_I, [_V]),
@@ -218,10 +220,15 @@ _contexts = {}
 
 
 def ctx():
-    """Context of torch's current stream (created on first use; one per (device, stream))."""
+    """Context of torch's current stream (created on first use; one per (device, stream)).  A new context reserves the scratch
+    the other contexts of its device have grown to: a stream that is about to be captured into a graph cannot allocate, so whoever
+    captures touches ctx() on that stream first (engine.TrainStep._capture does)."""
     st = torch.cuda.current_stream()
     key = (st.device_index, st.cuda_stream)
     c = _contexts.get(key)
     if c is None:
+        want = max([load().bnerv_ctx_scratch_bytes(o.handle) for (dev, _), o in _contexts.items() if dev == st.device_index] or [0])
         c = _contexts[key] = StreamContext()
+        if want:
+            check(load().bnerv_ctx_reserve(c.handle, want), "bnerv_ctx_reserve")
     return c

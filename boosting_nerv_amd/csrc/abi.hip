@@ -21,10 +21,6 @@ extern "C" const char* bnerv_build_arch(void) { return "gfx950"; }
 #include <new>
 #include <vector>
 
-struct bnerv_ctx {
-    std::vector<SideJob> queue;          // deferred slab reductions of ONE stream, in issue order
-};
-
 namespace {
 __global__ __launch_bounds__(256) void side_flush_kernel(const SidePack sp) {
     __shared__ float red[256];
@@ -90,7 +86,40 @@ extern "C" int bnerv_ctx_create(bnerv_ctx** out) {
     *out = new (std::nothrow) bnerv_ctx();
     return *out ? BNERV_OK : bnerv_set_error(BNERV_E_ARG, "ctx_create: out of memory");
 }
-extern "C" void bnerv_ctx_destroy(bnerv_ctx* ctx) { delete ctx; }
+extern "C" void bnerv_ctx_destroy(bnerv_ctx* ctx) {
+    if (ctx && ctx->scratch) (void)hipFree(ctx->scratch);
+    delete ctx;
+}
+
+extern "C" size_t bnerv_ctx_scratch_bytes(const bnerv_ctx* ctx) { return ctx ? ctx->scratch_bytes : 0; }
+
+extern "C" int bnerv_ctx_reserve(bnerv_ctx* ctx, size_t bytes) {
+    BNERV_REQUIRE(ctx != nullptr, "ctx_reserve: null context");
+    if (ctx->scratch_bytes >= bytes) return BNERV_OK;
+    if (hipDeviceSynchronize() != hipSuccess) return bnerv_set_error(BNERV_E_LAUNCH, "ctx_reserve: device synchronize failed");
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    if (hipMalloc(&ctx->scratch, bytes) != hipSuccess) { ctx->scratch = nullptr; return bnerv_set_error(BNERV_E_WS, "ctx_reserve: cannot allocate %zu bytes", bytes); }
+    ctx->scratch_bytes = bytes;
+    return BNERV_OK;
+}
+
+void* bnerv_ctx_scratch(bnerv_ctx* ctx, size_t bytes, hipStream_t st) {
+    if (!ctx) return nullptr;
+    if (ctx->scratch_bytes >= bytes) return ctx->scratch;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    // grow (rare: the largest layer of the model sizes it once).  Work already queued on the stream may still read the old buffer.
+    if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    const size_t want = bytes + bytes / 2;
+    if (hipMalloc(&ctx->scratch, want) != hipSuccess) { ctx->scratch = nullptr; return nullptr; }
+    ctx->scratch_bytes = want;
+    return ctx->scratch;
+}
 
 extern "C" int bnerv_reduce_slabs_deferred(bnerv_ctx* ctx, void* stream, const float* slabs, int n_slabs, int count, float* out) {
     BNERV_REQUIRE(slabs && out && n_slabs > 0 && count > 0, "reduce_slabs_deferred: bad args");

@@ -158,8 +158,10 @@ __device__ __forceinline__ float pow2_inv(float s) {                      // 1 /
 template <int KS> struct BfGeo {
     using G = Geo<KS>;
     static constexpr int NP = (KS == 3) ? 34 : 32;                 // pixels per tile row kept in LDS (planar columns COL0 .. COL0 + NP - 1)
-    static constexpr int SPR = ((NP + 3) / 4) * 8;                 // 16-B slots per row: 72 / 64
-    static constexpr int PIECE = G::ROWS * SPR * 16;               // bytes per piece: 11520 / 8192
+    // 16-B slots per row: 68 / 64.  (3x3: 8 full groups of 4 pixels + pixels 32, 33, whose group index 8 rotates by 0, so they use the
+    // first four slots of the ninth group only -- the 4 spare slots are what lets the wide kernel keep two blocks per CU)
+    static constexpr int SPR = (NP / 4) * 8 + (NP % 4) * 2;
+    static constexpr int PIECE = G::ROWS * SPR * 16;               // bytes per piece: 10880 / 8192
     static constexpr int STEPS = (G::T + 1) / 2;                   // 5 / 1
     static constexpr int HSLOT = G::ROWS * G::SEGS;                // staging slots per channel half: 100 / 64
     static_assert(HSLOT <= 128, "one slot per thread of a wave pair");
@@ -623,6 +625,356 @@ int launch_bf(hipStream_t st, KArgs& ka) {
     return BNERV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- wide split kernel
+// The same split core for the layers with MORE than 16 input or output channels (3x3, stride-1 output: the TAT convolutions,
+// stride-1 block convs and every data gradient of the 22..95-channel stages of C3 / C4 -- conv.hip's lean2 scope without the
+// unshuffle / tanh-grad prologues).  Here the staged input tile of one 16-channel K chunk feeds NTB cout tiles, so the staging work
+// that sets the pace of the one-tile kernel above is amortised over NTB times the matrix work -- this is where the 16-bit pipe pays.
+//   * work item = (cout group of NTB tiles, sample, 8x32 tile); pipeline stage = (item, K chunk): the loads of the next stage --
+//     the input chunk AND its B fragments -- fly in registers under the MFMA phase of the current one;
+//   * B fragments come PRE-SPLIT from a scratch buffer of the stream context (bf_wprep_kernel, one small launch per call in front
+//     of this kernel: the weight tensor -> [group][chunk][tile][step][piece][lane] 16-B fragments), because the fragments of all
+//     chunks do not fit LDS and splitting them again per (tile, chunk) would cost as much as the chunk's MFMAs;
+//   * channels beyond Cin inside the last chunk are never loaded: their A slots keep finite stale data and meet zero weights.
+// Modes: bf16x6 (default when enabled) and bf16x3; the scaled f16 mode is not built for this kernel.
+constexpr int AFF_MAX = 128;
+
+template <int NS>
+__global__ __launch_bounds__(256) void bf_wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ frag, int wCo, int wCi, int transposed,
+                                                       int Cin, int Cout, int nck, int ntb) {
+    // element i of the OIHW array -> 16-bit slot of fragment (group, chunk, tile, step, piece, lane (q, n), k e)
+    const int nw = wCo * wCi * 9;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nw; i += gridDim.x * 256) {
+        const int pair = i / 9, t = i - pair * 9;
+        const int wa_ = pair / wCi, wb_ = pair - wa_ * wCi;
+        const int co = transposed ? wb_ : wa_, ci = transposed ? wa_ : wb_;
+        if (co >= Cout || ci >= Cin) continue;
+        const int tg = transposed ? 8 - t : t;
+        const int nt = co >> 4, n = co & 15, g = nt / ntb, nl = nt - g * ntb;
+        const int c = ci >> 4, cl = ci & 15;
+        const int st = tg >> 1, q = ((tg & 1) << 1) | (cl >> 3), e = cl & 7;
+        float r = w[i];
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+            const __bf16 hv = (__bf16)r;
+            const size_t slot = ((((size_t)(g * nck + c) * ntb + nl) * 5 + st) * NS + p) * 64 + q * 16 + n;
+            frag[slot * 8 + e] = __builtin_bit_cast(unsigned short, hv);
+            r -= (float)hv;
+        }
+    }
+}
+
+struct WItem { int g, b, ty, tx; };
+
+template <int IN, int EP, int SP, int NTB>
+__global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const u32x4* __restrict__ wfrag, const int ngroups, const SidePack side) {
+    constexpr int KS = 3;
+    using G = Geo<KS>;
+    using BG = BfGeo<KS>;
+    constexpr int NS = Split<SP>::NS;
+    static_assert(!Split<SP>::SCALED, "the wide kernel is built for the bf16 modes");
+    constexpr bool AFF = (IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE);
+    constexpr bool RED = (EP == BNERV_EP_DGELU || EP == BNERV_EP_DSIN || EP == BNERV_EP_DGELU_SAVED);
+    constexpr int SB_SLOTS = NTB * BG::STEPS * NS * 64;             // 16-B slots of one stage's B fragments
+    constexpr int NWB = (SB_SLOTS + 255) / 256;
+    const bnerv_conv_desc& d = ka.d;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* s_a = reinterpret_cast<char*>(smem);
+    char* s_b = s_a + NS * BG::PIECE;
+    float* s_red = reinterpret_cast<float*>(s_b + SB_SLOTS * 16);  // [4 waves][2][NTB * 16]
+    float* s_aff = s_red + 4 * 2 * NTB * 16;                       // [2][AFF_MAX]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
+    const int tiles_x = ka.tiles_x, tiles_y = ka.tiles_y;
+    const int nck = (Cin + 15) >> 4;
+
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const int nlb = (gridDim.x - xcd + 7) >> 3;
+    const int per = ka.total_items >> 3, extra = ka.total_items & 7;
+    const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
+    int itx = r0 + lb;
+    for (int i = tid; i < NS * BG::PIECE / 16; i += 256) reinterpret_cast<u32x4*>(s_a)[i] = u32x4{0u, 0u, 0u, 0u};   // no NaN patterns beside zero weights
+    if (itx >= r1) { side_run_hosted(side, smem); return; }
+    auto decode = [&](int i) __attribute__((always_inline)) {     // item order: tile fastest, then sample, then cout group
+        WItem w;
+        const int tiles = tiles_x * tiles_y;
+        const int rest = fast_div(i, ka.magic_tiles), t = i - rest * tiles;
+        w.ty = fast_div(t, ka.magic_tiles_x);
+        w.tx = t - w.ty * tiles_x;
+        w.g = rest / d.B;
+        w.b = rest - w.g * d.B;
+        return w;
+    };
+
+    const int s_h = wave >> 1;
+    const int sidx = tid & 127;
+    const bool has_slot = sidx < BG::HSLOT;
+    const int s_sg = sidx % G::SEGS, s_r = (sidx / G::SEGS) % G::ROWS;
+    const unsigned voff0 = has_slot ? (unsigned)((((8 * s_h) * H + s_r) * W + 4 * s_sg) * 4) : OOB;
+    const unsigned hw4 = (unsigned)(H * W * 4);
+    const unsigned shift = (unsigned)((G::PAD * W + G::XOFF) * 4);
+    const unsigned in_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
+    const unsigned out_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, in_bytes);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ro2 = make_rsrc(((EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) && d.out2) ? d.out2 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(d.aux0 ? d.aux0 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(d.aux1 ? d.aux1 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ra2 = make_rsrc(d.aux2 ? d.aux2 : d.out, 0, out_bytes);
+    int w_addr[4];
+    bool w_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = 4 * s_sg + j - G::COL0;
+        w_ok[j] = has_slot && p >= 0 && p < BG::NP;
+        w_addr[j] = bf_slot(s_r, w_ok[j] ? p : 0, s_h, BG::SPR) * 16;
+    }
+
+    f32x4 ra[8];
+    u32x4 rb[NWB];
+    int ra_valid = 0;                                      // channels of this thread's half that the loaded chunk really has
+    auto issue = [&](const WItem& a, int c) __attribute__((always_inline)) {
+        const int ty0 = a.ty * TH, tx0 = a.tx * TW;
+        unsigned sb = (unsigned)((((a.b * Cin + 16 * c) * H + ty0) * W + tx0) * 4);
+        const int gy = ty0 + s_r - G::PAD, gx = tx0 + 4 * s_sg - G::XOFF;
+        const unsigned vo = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? voff0 : OOB;
+        int nv = Cin - 16 * c - 8 * s_h;
+        nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
+        ra_valid = nv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (e < nv) ra[e] = bload(rx, vo, sb);
+            else ra[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+            sb += hw4;
+        }
+        const u32x4* src = wfrag + (size_t)(a.g * nck + c) * SB_SLOTS;
+#pragma unroll
+        for (int k = 0; k < NWB; ++k) {
+            const int i = tid + k * 256;
+            rb[k] = i < SB_SLOTS ? src[i] : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto commit = [&](const WItem& a, int c) __attribute__((always_inline)) {
+        if constexpr (IN != BNERV_IN_PLAIN) {
+            const int ty0 = a.ty * TH, tx0 = a.tx * TW;
+            const int gy = ty0 + s_r - G::PAD, gx = tx0 + 4 * s_sg - G::XOFF;
+            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;     // zero padding applies AFTER the prologue
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ci = 16 * c + 8 * s_h + e;
+                const bool on = AFF && inside && e < ra_valid;
+                const float sc = on ? s_aff[ci & (AFF_MAX - 1)] : 0.f, sh = on ? s_aff[AFF_MAX + (ci & (AFF_MAX - 1))] : 0.f;
+                ra[e].x = xform1<IN>(ra[e].x, sc, sh, 0.f);
+                ra[e].y = xform1<IN>(ra[e].y, sc, sh, 0.f);
+                ra[e].z = xform1<IN>(ra[e].z, sc, sh, 0.f);
+                ra[e].w = xform1<IN>(ra[e].w, sc, sh, 0.f);
+            }
+        }
+        if (ra_valid > 0) {                                // (a half without channels in this chunk keeps its stale slots: zero weights)
+            float xs[4][8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xs[0][e] = ra[e].x; xs[1][e] = ra[e].y; xs[2][e] = ra[e].z; xs[3][e] = ra[e].w; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x4 pc[NS];
+                split8<SP, 8>(xs[j], pc);
+                if (w_ok[j]) {
+#pragma unroll
+                    for (int p = 0; p < NS; ++p) *reinterpret_cast<u32x4*>(s_a + p * BG::PIECE + w_addr[j]) = pc[p];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NWB; ++k) {
+            const int i = tid + k * 256;
+            if (i < SB_SLOTS) reinterpret_cast<u32x4*>(s_b)[i] = rb[k];
+        }
+    };
+    auto load_affine = [&](int b) __attribute__((always_inline)) {                 // s_aff[c] = 1 + scale[b][c], s_aff[AFF_MAX + c] = shift[b][c]
+        for (int i = tid; i < 2 * AFF_MAX; i += 256) {
+            const int c = i & (AFF_MAX - 1);
+            float v = 0.f;
+            if (c < Cin) v = i < AFF_MAX ? 1.0f + d.scale[b * Cin + c] : d.shift[b * Cin + c];
+            s_aff[i] = v;
+        }
+    };
+    auto flush_partials = [&](const WItem& a) __attribute__((always_inline)) {
+        if (wave == 0) {
+            for (int i = lane; i < 2 * NTB * 16; i += 64) {
+                const int q = i / (NTB * 16), c = i - q * (NTB * 16);
+                const float sm = ((s_red[(0 * 2 + q) * NTB * 16 + c] + s_red[(1 * 2 + q) * NTB * 16 + c]) + s_red[(2 * 2 + q) * NTB * 16 + c]) + s_red[(3 * 2 + q) * NTB * 16 + c];
+                const int co = a.g * NTB * 16 + c;
+                const size_t row = (size_t)(a.ty * tiles_x + a.tx) * d.B + a.b;
+                if (co < Cout) d.partial[(row * 2 + q) * Cout + co] = sm;
+            }
+        }
+    };
+
+    int a_addr[BG::STEPS][2];
+#pragma unroll
+    for (int s = 0; s < BG::STEPS; ++s) {
+        int t = 2 * s + (kq >> 1);
+        if (t > G::T - 1) t = G::T - 1;
+        const int ky = t / KS, kx = t - ky * KS;
+#pragma unroll
+        for (int xh = 0; xh < 2; ++xh) a_addr[s][xh] = bf_slot(2 * wave + ky, xh * 16 + li + kx, kq & 1, BG::SPR) * 16;
+    }
+    const int b_addr = lane * 16;
+
+    WItem it = decode(itx);
+    int aff_b = -1, ep_b = -1;
+    float scl[NTB];
+#pragma unroll
+    for (int n = 0; n < NTB; ++n) scl[n] = 0.f;
+    if constexpr (AFF) { load_affine(it.b); aff_b = it.b; }
+    issue(it, 0);
+    lds_barrier();                                         // zeroed s_a and the affine table visible
+    commit(it, 0);
+    WItem prev = it;
+    bool have_prev = false;
+    while (itx < r1) {
+        f32x4 acc[4][NTB];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < NTB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool has_next_item = itx + nlb < r1;
+        WItem nxt = it;
+        if (has_next_item) nxt = decode(itx + nlb);
+        for (int c = 0; c < nck; ++c) {
+            const bool last_chunk = c == nck - 1;
+            const bool more = !last_chunk || has_next_item;
+            lds_barrier();                                 // (A) this stage's s_a / s_b (and s_red of the previous item) visible
+            if (more) issue(last_chunk ? nxt : it, last_chunk ? 0 : c + 1);
+            if constexpr (RED) { if (c == 0 && have_prev) flush_partials(prev); }
+#pragma unroll
+            for (int s = 0; s < BG::STEPS; ++s) {
+                u32x4 bfr[NTB][NS];
+#pragma unroll
+                for (int n = 0; n < NTB; ++n)
+#pragma unroll
+                    for (int p = 0; p < NS; ++p) bfr[n][p] = *reinterpret_cast<const u32x4*>(s_b + ((n * BG::STEPS + s) * NS + p) * 1024 + b_addr);
+#pragma unroll
+                for (int m0 = 0; m0 < 4; m0 += 2) {
+                    u32x4 afr[2][NS];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int p = 0; p < NS; ++p)
+                            afr[m][p] = *reinterpret_cast<const u32x4*>(s_a + p * BG::PIECE + a_addr[s][(m0 + m) & 1] + ((m0 + m) >> 1) * (BG::SPR * 16));
+#define BNERV_BF_PROD(pa, pb) _Pragma("unroll") for (int n = 0; n < NTB; ++n) _Pragma("unroll") for (int m = 0; m < 2; ++m) \
+                        acc[m0 + m][n] = mfma16<SP>(afr[m][pa], bfr[n][pb], acc[m0 + m][n]);
+                    if constexpr (NS == 3) {
+                        BNERV_BF_PROD(2, 0)
+                        BNERV_BF_PROD(0, 2)
+                        BNERV_BF_PROD(1, 1)
+                    }
+                    BNERV_BF_PROD(1, 0)
+                    BNERV_BF_PROD(0, 1)
+                    BNERV_BF_PROD(0, 0)
+#undef BNERV_BF_PROD
+                }
+            }
+            lds_barrier();                                 // (B) every wave is done reading this stage
+            if (more) {
+                if constexpr (AFF) {
+                    if (last_chunk && nxt.b != aff_b) { load_affine(nxt.b); lds_barrier(); aff_b = nxt.b; }
+                }
+                commit(last_chunk ? nxt : it, last_chunk ? 0 : c + 1);
+            }
+        }
+        // ---- epilogue straight from the accumulators, one cout tile after the other
+        {
+            const int ty0 = it.ty * TH, tx0 = it.tx * TW;
+            const int co_base = it.g * NTB * 16;
+            const bool full = ty0 + TH <= H && tx0 + TW <= W;
+            unsigned so[4];
+            bool okm[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                so[m] = (unsigned)((((it.b * Cout) * H + ty0 + 2 * wave + (m >> 1)) * W + tx0 + (m & 1) * 16) * 4);
+                okm[m] = full || (ty0 + 2 * wave + (m >> 1) < H && tx0 + (m & 1) * 16 + 4 * kq < W);
+            }
+            float ps[NTB], pt[NTB];
+#pragma unroll
+            for (int n = 0; n < NTB; ++n) {
+                const int co = co_base + 16 * n + li;
+                const unsigned ovoff = co < Cout ? (unsigned)(((co * H) * W + 4 * kq) * 4) : OOB;
+                const float bias_l = (EP != BNERV_EP_PLAIN && !RED && d.bias && co < Cout) ? d.bias[co] : 0.f;
+                if constexpr (RED) { if (it.b != ep_b) scl[n] = co < Cout ? 1.0f + d.scale[it.b * Cout + co] : 0.f; }
+                ps[n] = 0.f; pt[n] = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const unsigned vo = okm[m] ? ovoff : OOB;
+                    f32x4 v = acc[m][n];
+                    if constexpr (RED) { if (!okm[m]) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    if constexpr (EP == BNERV_EP_BIAS || EP == BNERV_EP_PLAIN) {
+                        bstore(ro, vo, so[m], v + bias_l);
+                    } else if constexpr (EP == BNERV_EP_BIAS_SIN) {
+                        f32x4 sv, cv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(v[e] + bias_l, &s_, &c_); sv[e] = s_; cv[e] = c_; }
+                        bstore(ro, vo, so[m], sv);
+                        if (d.out2) bstore(ro2, vo, so[m], cv);
+                    } else if constexpr (EP == BNERV_EP_BIAS_GELU) {
+                        f32x4 hv, gv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { float h_, g_; gelu_pair_f(v[e] + bias_l, &h_, &g_); hv[e] = h_; gv[e] = g_; }
+                        bstore(ro, vo, so[m], hv);
+                        if (d.out2) bstore(ro2, vo, so[m], gv);
+                    } else if constexpr (EP == BNERV_EP_BIAS_TANH) {
+                        f32x4 r;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[e] = tanhf(v[e] + bias_l) * 0.5f + 0.5f;
+                        bstore(ro, vo, so[m], r);
+                    } else if constexpr (EP == BNERV_EP_BIAS_RES) {
+                        const f32x4 a0 = bload(ra0, vo, so[m]);
+                        bstore(ro, vo, so[m], v + bias_l + a0);
+                    } else {                               // DGELU / DSIN
+                        const f32x4 a0 = bload(ra0, vo, so[m]);
+                        f32x4 a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = f32x4{1.f, 1.f, 1.f, 1.f}, r;
+                        if constexpr (EP == BNERV_EP_DGELU_SAVED || EP == BNERV_EP_DSIN) a1 = bload(ra1, vo, so[m]);
+                        if constexpr (EP == BNERV_EP_DSIN) { if (d.aux2) a2 = bload(ra2, vo, so[m]); }
+                        if constexpr (EP == BNERV_EP_DGELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { r[e] = v[e] * scl[n] * gelu_grad_f(a0[e]); ps[n] = fmaf(v[e], gelu_f(a0[e]), ps[n]); pt[n] += v[e]; }
+                        } else if constexpr (EP == BNERV_EP_DGELU_SAVED) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { r[e] = v[e] * scl[n] * a0[e]; ps[n] = fmaf(v[e], a1[e], ps[n]); pt[n] += v[e]; }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { r[e] = (a1[e] + v[e] * scl[n]) * a2[e]; ps[n] = fmaf(v[e], a0[e], ps[n]); pt[n] += v[e]; }
+                        }
+                        bstore(ro, vo, so[m], r);
+                    }
+                }
+            }
+            if constexpr (RED) {
+                ep_b = it.b;
+#pragma unroll
+                for (int n = 0; n < NTB; ++n) {
+                    float a = ps[n], b2 = pt[n];
+                    a += __shfl_xor(a, 16, 64); b2 += __shfl_xor(b2, 16, 64);
+                    a += __shfl_xor(a, 32, 64); b2 += __shfl_xor(b2, 32, 64);
+                    if (lane < 16) { s_red[(wave * 2 + 0) * NTB * 16 + n * 16 + lane] = a; s_red[(wave * 2 + 1) * NTB * 16 + n * 16 + lane] = b2; }
+                }
+            }
+        }
+        prev = it;
+        have_prev = true;
+        it = nxt;
+        itx += nlb;
+    }
+    if constexpr (RED) {
+        lds_barrier();
+        flush_partials(prev);
+    }
+    side_run_hosted(side, smem);
+}
+
 constexpr size_t LEAN_MAX_BYTES = 0x7ff00000;            // every tensor view must stay below the OOB marker offset
 
 template <int KS, int IN, int EP, int SP>
@@ -659,6 +1011,84 @@ int launch_mode(hipStream_t st, KArgs& ka) {
     return -1;
 }
 
+// ---- wide kernel: mode switch, launch, dispatch
+static int wide_mode() {                                   // BNERV_SPLIT_WIDE = bf16x6 (default) | bf16x3 | off
+    static const int v = [] {
+        const char* e = getenv("BNERV_SPLIT_WIDE");
+        if (!e) return (int)SP_BF16X6;
+        if (!strcmp(e, "off") || !strcmp(e, "0")) return -1;
+        if (!strcmp(e, "bf16x3")) return (int)SP_BF16X3;
+        return (int)SP_BF16X6;
+    }();
+    return v;
+}
+
+template <int IN, int EP, int SP, int NTB>
+int launch_bfw(hipStream_t st, KArgs& ka) {
+    using BG = BfGeo<3>;
+    constexpr int NS = Split<SP>::NS;
+    const bnerv_conv_desc& d = ka.d;
+    const int nck = cdiv(d.Cin, 16), ngroups = cdiv(cdiv(d.Cout, 16), NTB);
+    const size_t slots = (size_t)ngroups * nck * NTB * BG::STEPS * NS * 64;
+    void* scratch = bnerv_ctx_scratch(d.ctx, slots * 16, st);
+    if (!scratch) return -1;                               // no context, or it would have to grow inside a graph capture: f32 kernels
+    if (hipMemsetAsync(scratch, 0, slots * 16, st) != hipSuccess) return bnerv_set_error(BNERV_E_LAUNCH, "conv_bfw: memset failed");
+    const int nw = d.wCo * d.wCi * 9;
+    hipLaunchKernelGGL(bf_wprep_kernel<NS>, dim3(cdiv(nw, 256) > 512 ? 512 : cdiv(nw, 256)), dim3(256), 0, st, d.w, reinterpret_cast<unsigned short*>(scratch),
+                       d.wCo, d.wCi, d.transposed, d.Cin, d.Cout, nck, NTB);
+    BNERV_LAUNCH_CHECK("bf_wprep");
+    ka.total_items = ngroups * d.B * ka.tiles_x * ka.tiles_y;
+    ka.magic_tiles = div_magic(ka.tiles_x * ka.tiles_y);
+    ka.magic_tiles_x = div_magic(ka.tiles_x);
+    const size_t lds = (size_t)NS * BG::PIECE + (size_t)NTB * BG::STEPS * NS * 1024 + (size_t)(4 * 2 * NTB * 16 + 2 * AFF_MAX) * sizeof(float);
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bfw_kernel<IN, EP, SP, NTB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_bfw_kernel<IN, EP, SP, NTB>), 256, lds) != hipSuccess || nb < 1) nb = 1;
+        blocks_per_cu = nb > 2 ? 2 : nb;
+    }
+    int grid = 256 * blocks_per_cu;
+    if (grid > ka.total_items) grid = ka.total_items;
+    SidePack side;
+    bnerv_side_take(d.ctx, &side, 2 * grid);
+    hipLaunchKernelGGL((conv_bfw_kernel<IN, EP, SP, NTB>), dim3(grid), dim3(256), lds, st, ka, reinterpret_cast<const u32x4*>(scratch), ngroups, side);
+    BNERV_LAUNCH_CHECK("conv_bfw");
+    return BNERV_OK;
+}
+
+template <int IN, int EP, int SP>
+int launch_bfw_ntb(hipStream_t st, KArgs& ka) {
+    const int nt = cdiv(ka.d.Cout, 16);
+    const int ntb = nt <= 3 ? nt : (nt == 4 ? 2 : 3);
+    if (ntb == 1) return launch_bfw<IN, EP, SP, 1>(st, ka);
+    if (ntb == 2) return launch_bfw<IN, EP, SP, 2>(st, ka);
+    return launch_bfw<IN, EP, SP, 3>(st, ka);
+}
+
+template <int IN, int EP>
+int launch_bfw_sp(hipStream_t st, KArgs& ka) {
+    return wide_mode() == SP_BF16X3 ? launch_bfw_ntb<IN, EP, SP_BF16X3>(st, ka) : launch_bfw_ntb<IN, EP, SP_BF16X6>(st, ka);
+}
+
+int launch_wide_mode(hipStream_t st, KArgs& ka) {
+    const int in = ka.d.in_mode, ep = ka.d.ep_mode;
+#define BNERV_CASE(I, E) if (in == I && ep == E) return launch_bfw_sp<I, E>(st, ka);
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS_SIN)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS_TANH)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_PLAIN)
+    BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS)
+    BNERV_CASE(BNERV_IN_GELU_AFFINE, BNERV_EP_BIAS_RES)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DGELU)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DSIN)
+    BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_GELU)
+    BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_RES)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DGELU_SAVED)
+#undef BNERV_CASE
+    return -1;
+}
+
 }  // namespace
 
 #ifdef BNERV_TRACE
@@ -668,13 +1098,24 @@ extern "C" int bnerv_debug_trace_read_bf(void* host) { return (int)hipMemcpyFrom
 // Called by bnerv_conv_igemm (conv.hip) after argument validation.  Returns -1 when the shape / mode is not this kernel's
 // (the caller then takes its f32-MFMA kernels), otherwise the launch status.
 int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec) {
-    if (split_mode() < 0 || !vec || d.out_s != 1 || d.Cout > 16 || d.Cin > 16 || d.Cin <= 8 || d.wCo > 16 || d.wCi > 16) return -1;
-    if (d.in_mode == BNERV_IN_UNSHUFFLE || d.in_mode == BNERV_IN_TANHGRAD) return -1;
+    if (!vec || d.out_s != 1 || d.in_mode == BNERV_IN_UNSHUFFLE || d.in_mode == BNERV_IN_TANHGRAD) return -1;
     const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
     if ((size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 >= LEAN_MAX_BYTES) return -1;
     KArgs ka;
     ka.d = d;
     ka.tiles_x = cdiv(d.W, TW);
     ka.tiles_y = cdiv(d.H, TH);
-    return d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);
+    const bool narrow = d.Cout <= 16 && d.Cin <= 16;
+    if (narrow) {                                          // one cout tile, one K chunk: opt-in (see split_mode)
+        if (split_mode() < 0 || d.Cin <= 8 || d.wCo > 16 || d.wCi > 16) return -1;
+        return d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);
+    }
+    // several cout tiles and / or K chunks: the wide kernel, where the image is big enough to fill the chip with its work items
+    if (wide_mode() < 0 || d.k != 3 || !d.ctx) return -1;
+    const bool affine = d.in_mode == BNERV_IN_AFFINE || d.in_mode == BNERV_IN_GELU_AFFINE;
+    if (affine && d.Cin > AFF_MAX) return -1;
+    int min_tiles = 256;                                   // (low-resolution stages stay on the f32 kernels' split policies)
+    if (const char* e = getenv("BNERV_SPLIT_WIDE_MIN_TILES")) min_tiles = atoi(e);     // tests lower it to reach the kernel with small shapes
+    if (d.B * ka.tiles_x * ka.tiles_y < min_tiles) return -1;
+    return launch_wide_mode(st, ka);
 }

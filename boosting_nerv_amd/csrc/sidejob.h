@@ -29,6 +29,17 @@ struct SidePack {
     int n_jobs, n_slices;
 };
 
+// the caller-owned context of one stream (include/bnerv.h): the deferred-reduction queue and a scratch buffer in device memory
+#include <vector>
+struct bnerv_ctx {
+    std::vector<SideJob> queue;          // deferred slab reductions of ONE stream, in issue order
+    void* scratch = nullptr;             // pre-split weight fragments of the wide split conv kernels (reused call after call:
+    size_t scratch_bytes = 0;            //  stream order keeps a call's fragments alive until its kernel has read them)
+};
+// >= `bytes` of device scratch owned by the context, or nullptr when there is no context / the buffer would have to grow while
+// `st` is being captured into a graph (allocation is illegal there: the first, eager calls size it)
+void* bnerv_ctx_scratch(bnerv_ctx* ctx, size_t bytes, hipStream_t st);
+
 // host side (abi.hip).  The queue belongs to the caller's bnerv_ctx; ctx == NULL means "no queue": nothing to take, and a push
 // runs the reduction at once on `st`.
 void bnerv_side_push(bnerv_ctx* ctx, hipStream_t st, const void* src, int n_slabs, int count, int ncols, float* out, float* out2);

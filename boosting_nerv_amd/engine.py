@@ -73,12 +73,20 @@ class TrainStep:
         backend whose collectives cannot be captured (gloo), or a failed capture fall back to graph A -> eager all-reduce -> graph B)."""
         import os
         import torch.distributed as dist
+        from . import _lib as L
         torch.cuda.synchronize()
         self._opt_epoch = getattr(self.opt, "state_epoch", 0)
         pool = torch.cuda.graph_pool_handle()
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), None
+        # capture on a stream of our own whose library context exists -- and has its scratch reserved -- BEFORE the capture starts
+        # (nothing may allocate inside it; the eager warm-up steps on the current stream sized the scratch)
+        if getattr(self, "_cap_stream", None) is None:
+            self._cap_stream = torch.cuda.Stream(device=self.dev)
+        with torch.cuda.stream(self._cap_stream):
+            L.ctx()
+        cap = dict(pool=pool, stream=self._cap_stream)
         if self.bucket is None:
-            with torch.cuda.graph(self.graph_a, pool=pool):
+            with torch.cuda.graph(self.graph_a, **cap):
                 self._fwd_bwd()
                 self.opt.launch_step()
             return
@@ -96,7 +104,7 @@ class TrainStep:
         backend = dist.get_backend(self.bucket.group) if dist.is_initialized() else ""
         if backend == "nccl" and os.environ.get("BNERV_DP_INGRAPH", "1") != "0":
             try:
-                with torch.cuda.graph(self.graph_a, pool=pool):
+                with torch.cuda.graph(self.graph_a, **cap):
                     head()
                     dist.all_reduce(self.bucket.bucket, op=dist.ReduceOp.SUM, group=self.bucket.group)
                     tail()
@@ -108,10 +116,10 @@ class TrainStep:
                 torch.cuda.synchronize()
                 self.graph_a = torch.cuda.CUDAGraph()
         self.collective_in_graph = False
-        with torch.cuda.graph(self.graph_a, pool=pool):
+        with torch.cuda.graph(self.graph_a, **cap):
             head()
         self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b, pool=pool):
+        with torch.cuda.graph(self.graph_b, **cap):
             tail()
 
     # ---- one step ------------------------------------------------------------------------------------------------------

@@ -120,6 +120,12 @@ int bnerv_reduce_slabs(void* stream, const float* slabs, int n_slabs, int count,
 typedef struct bnerv_ctx bnerv_ctx;
 int bnerv_ctx_create(bnerv_ctx** out);
 void bnerv_ctx_destroy(bnerv_ctx* ctx);
+/* The context also owns a device scratch buffer (pre-split weight fragments of the wide split conv kernels).  It grows on demand,
+ * except while its stream is being captured into a graph (allocation is illegal there: such a call falls back to the f32 kernels).
+ * A caller that is about to capture on a fresh stream reserves what the eager steps needed:  bnerv_ctx_reserve(new_ctx,
+ * bnerv_ctx_scratch_bytes(old_ctx)). */
+size_t bnerv_ctx_scratch_bytes(const bnerv_ctx* ctx);
+int bnerv_ctx_reserve(bnerv_ctx* ctx, size_t bytes);
 int bnerv_reduce_slabs_deferred(bnerv_ctx* ctx, void* stream, const float* slabs, int n_slabs, int count, float* out);
 int bnerv_flush_deferred(bnerv_ctx* ctx, void* stream);
 int bnerv_deferred_pending(const bnerv_ctx* ctx);

@@ -558,3 +558,41 @@ def test_dense_gemm_shapes(ops):
         close(out, ref, msg=f"gemm fwd {B}x{I}x{O}")
         for n, a, r in zip("xwb", torch.autograd.grad(out, gl, cot.to(DEV)), rg):
             close(a, r, msg=f"gemm d{n} {B}x{I}x{O}")
+
+
+@pytest.mark.parametrize("shape", [(1, 38, 24, 64), (2, 55, 17, 36), (1, 95, 10, 44), (2, 22, 9, 40), (1, 30, 16, 32)])
+def test_wide_split_conv_kernel_tat_block(ops, shape, monkeypatch):
+    """The wide split-16-bit conv kernel (csrc/convbf.hip conv_bfw_kernel: several cout tiles / K chunks per staged input tile,
+    bf16x6 products with f32 accumulation) on the TAT block -- its four launches cover the affine -> gelu-pair, affine -> residual,
+    dGELU-saved and dSIN modes -- against the oracle, with the tile-count threshold lowered so that small shapes reach it."""
+    monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    x0, mods, w0, b0, w1, b1, g = _tat_inputs(*shape, seed=7)
+    ref = _tat_ref(x0, mods, w0, b0, w1, b1)
+    cot = torch.randn(ref.shape, generator=g)
+    leaves = [x0] + mods + [w0, b0, w1, b1]
+    rg = torch.autograd.grad(ref, leaves, cot)
+    gl = [gpu(t) for t in leaves]
+    out = ops.tat_block(*gl)
+    close(out, ref, msg="wide tat fwd")
+    for n, a, r in zip(["x0", "s0", "t0", "s1", "t1", "w0", "b0", "w1", "b1"], torch.autograd.grad(out, gl, cot.to(DEV)), rg):
+        close(a, r, msg=f"wide tat d{n}")
+
+
+@pytest.mark.parametrize("case", [(1, 38, 38, 24, 64), (1, 70, 18, 8, 32), (2, 55, 55, 17, 36), (1, 20, 95, 9, 32), (1, 95, 12, 16, 32)])
+def test_wide_split_conv_kernel_plain(ops, case, monkeypatch):
+    """Same kernel through conv2d_ps (plain -> bias forward, plain data gradient) and the sin block conv, incl. Cout <= 16 with several
+    K chunks and Cin <= 16 with several cout tiles."""
+    monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    B, Cin, Ct, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(Ct, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).requires_grad_(True)
+    b = torch.randn(Ct, generator=g).requires_grad_(True)
+    ref = cpu_ref.upconv(x, w, b, 1)
+    cot = torch.randn(ref.shape, generator=g)
+    rg = torch.autograd.grad(ref, [x, w, b], cot)
+    xg, wg, bg = gpu(x), gpu(w), gpu(b)
+    out = ops.conv2d_ps(xg, wg, bg, 1)
+    close(out, ref, msg="wide conv fwd")
+    for n, a, r in zip("xwb", torch.autograd.grad(out, [xg, wg, bg], cot.to(DEV)), rg):
+        close(a, r, msg=f"wide conv d{n}")
