@@ -666,9 +666,13 @@ __global__ __launch_bounds__(256) void bf_wprep_kernel(const float* __restrict__
 
 struct WItem { int g, b, ty, tx; };
 
-template <int IN, int EP, int SP, int NTB>
+// PS2: the output goes through PixelShuffle(2) (conv channel 4c + 2i + j at (y, x) -> out[c][2y + i][2x + j]; the up-convs).
+// IN_UNSHUFFLE: the input is read through the inverse map from the shuffled tensor (data gradient of an up-conv; in_s == 2).
+template <int IN, int EP, int SP, int NTB, bool PS2>
 __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const u32x4* __restrict__ wfrag, const int ngroups, const SidePack side) {
     constexpr int KS = 3;
+    constexpr bool UNSH = (IN == BNERV_IN_UNSHUFFLE);
+    static_assert(!PS2 || EP == BNERV_EP_BIAS || EP == BNERV_EP_BIAS_SIN, "pixel-shuffle epilogues");
     using G = Geo<KS>;
     using BG = BfGeo<KS>;
     constexpr int NS = Split<SP>::NS;
@@ -713,9 +717,13 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
     const int sidx = tid & 127;
     const bool has_slot = sidx < BG::HSLOT;
     const int s_sg = sidx % G::SEGS, s_r = (sidx / G::SEGS) % G::ROWS;
-    const unsigned voff0 = has_slot ? (unsigned)((((8 * s_h) * H + s_r) * W + 4 * s_sg) * 4) : OOB;
+    // plain input: thread offset inside channel 8h of the tile, one plane further per channel.  Unshuffled input (UNSH): the
+    // conv-space pair (4c + 2i, 4c + 2i + 1) at 4 pixels is 8 consecutive floats of row 2y + i of du[c]; thread offset in units of
+    // the shuffled tensor, the (c, i) row added per pair.
+    const int W2 = 2 * W, H2 = 2 * H;
+    const unsigned voff0 = !has_slot ? OOB : (UNSH ? (unsigned)(((2 * s_r) * W2 + 8 * s_sg) * 4) : (unsigned)((((8 * s_h) * H + s_r) * W + 4 * s_sg) * 4));
     const unsigned hw4 = (unsigned)(H * W * 4);
-    const unsigned shift = (unsigned)((G::PAD * W + G::XOFF) * 4);
+    const unsigned shift = UNSH ? (unsigned)((2 * G::PAD * W2 + 2 * G::XOFF) * 4) : (unsigned)((G::PAD * W + G::XOFF) * 4);
     const unsigned in_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
     const unsigned out_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, in_bytes);
@@ -738,17 +746,30 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
     int ra_valid = 0;                                      // channels of this thread's half that the loaded chunk really has
     auto issue = [&](const WItem& a, int c) __attribute__((always_inline)) {
         const int ty0 = a.ty * TH, tx0 = a.tx * TW;
-        unsigned sb = (unsigned)((((a.b * Cin + 16 * c) * H + ty0) * W + tx0) * 4);
         const int gy = ty0 + s_r - G::PAD, gx = tx0 + 4 * s_sg - G::XOFF;
         const unsigned vo = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? voff0 : OOB;
         int nv = Cin - 16 * c - 8 * s_h;
         nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
         ra_valid = nv;
+        if constexpr (UNSH) {
+            const int cd0 = (16 * c + 8 * s_h) >> 2;       // first du channel of this half (two per half: (cd0, i), (cd0 + 1, i))
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (e < nv) ra[e] = bload(rx, vo, sb);
-            else ra[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-            sb += hw4;
+            for (int e = 0; e < 8; e += 2) {
+                const int cd = cd0 + (e >> 2), i = (e >> 1) & 1;
+                const unsigned sb = (unsigned)(((((a.b * (Cin >> 2) + cd) * H2) + 2 * ty0 + i) * W2 + 2 * tx0) * 4);
+                f32x4 l0 = f32x4{0.f, 0.f, 0.f, 0.f}, l1 = l0;
+                if (e < nv) { l0 = bload(rx, vo, sb); l1 = bload(rx, vo == OOB ? OOB : vo + 16u, sb); }
+                ra[e] = f32x4{l0.x, l0.z, l1.x, l1.z};     // j = 0
+                ra[e + 1] = f32x4{l0.y, l0.w, l1.y, l1.w}; // j = 1
+            }
+        } else {
+            unsigned sb = (unsigned)((((a.b * Cin + 16 * c) * H + ty0) * W + tx0) * 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (e < nv) ra[e] = bload(rx, vo, sb);
+                else ra[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sb += hw4;
+            }
         }
         const u32x4* src = wfrag + (size_t)(a.g * nck + c) * SB_SLOTS;
 #pragma unroll
@@ -758,7 +779,7 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
         }
     };
     auto commit = [&](const WItem& a, int c) __attribute__((always_inline)) {
-        if constexpr (IN != BNERV_IN_PLAIN) {
+        if constexpr (IN != BNERV_IN_PLAIN && !UNSH) {
             const int ty0 = a.ty * TH, tx0 = a.tx * TW;
             const int gy = ty0 + s_r - G::PAD, gx = tx0 + 4 * s_sg - G::XOFF;
             const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;     // zero padding applies AFTER the prologue
@@ -911,7 +932,29 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
                     const unsigned vo = okm[m] ? ovoff : OOB;
                     f32x4 v = acc[m][n];
                     if constexpr (RED) { if (!okm[m]) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                    if constexpr (EP == BNERV_EP_BIAS || EP == BNERV_EP_PLAIN) {
+                    if constexpr (PS2) {
+                        // lane pair (j = 0 / 1 = even / odd conv channel) owns 8 consecutive output columns of row 2y + i: the even
+                        // lane keeps pixels 0, 1 of both and stores columns 0..3, the odd lane pixels 2, 3 and columns 4..7
+                        const bool odd = li & 1;
+                        const int cps = co >> 2, ips = (co >> 1) & 1;
+                        const unsigned pvo = (okm[m] && co < Cout) ? (unsigned)((((cps * H2 + ips) * W2) + 8 * kq + (odd ? 4 : 0)) * 4) : OOB;
+                        const unsigned pso = (unsigned)(((((it.b * (Cout >> 2)) * H2) + 2 * (ty0 + 2 * wave + (m >> 1))) * W2 + 2 * (tx0 + (m & 1) * 16)) * 4);
+                        auto pair_up = [&](f32x4 q) __attribute__((always_inline)) {
+                            const float s0 = odd ? q.x : q.z, s1 = odd ? q.y : q.w;          // what the partner needs
+                            const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, false));
+                            const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, false));
+                            return odd ? f32x4{r0, q.z, r1, q.w} : f32x4{q.x, r0, q.y, r1};
+                        };
+                        if constexpr (EP == BNERV_EP_BIAS) {
+                            bstore(ro, pvo, pso, pair_up(v + bias_l));
+                        } else {
+                            f32x4 sv, cv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(v[e] + bias_l, &s_, &c_); sv[e] = s_; cv[e] = c_; }
+                            bstore(ro, pvo, pso, pair_up(sv));
+                            if (d.out2) bstore(ro2, pvo, pso, pair_up(cv));
+                        }
+                    } else if constexpr (EP == BNERV_EP_BIAS || EP == BNERV_EP_PLAIN) {
                         bstore(ro, vo, so[m], v + bias_l);
                     } else if constexpr (EP == BNERV_EP_BIAS_SIN) {
                         f32x4 sv, cv;
@@ -1023,7 +1066,7 @@ static int wide_mode() {                                   // BNERV_SPLIT_WIDE =
     return v;
 }
 
-template <int IN, int EP, int SP, int NTB>
+template <int IN, int EP, int SP, int NTB, bool PS2 = false>
 int launch_bfw(hipStream_t st, KArgs& ka) {
     using BG = BfGeo<3>;
     constexpr int NS = Split<SP>::NS;
@@ -1043,36 +1086,42 @@ int launch_bfw(hipStream_t st, KArgs& ka) {
     const size_t lds = (size_t)NS * BG::PIECE + (size_t)NTB * BG::STEPS * NS * 1024 + (size_t)(4 * 2 * NTB * 16 + 2 * AFF_MAX) * sizeof(float);
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bfw_kernel<IN, EP, SP, NTB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bfw_kernel<IN, EP, SP, NTB, PS2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_bfw_kernel<IN, EP, SP, NTB>), 256, lds) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_bfw_kernel<IN, EP, SP, NTB, PS2>), 256, lds) != hipSuccess || nb < 1) nb = 1;
         blocks_per_cu = nb > 2 ? 2 : nb;
     }
     int grid = 256 * blocks_per_cu;
     if (grid > ka.total_items) grid = ka.total_items;
     SidePack side;
     bnerv_side_take(d.ctx, &side, 2 * grid);
-    hipLaunchKernelGGL((conv_bfw_kernel<IN, EP, SP, NTB>), dim3(grid), dim3(256), lds, st, ka, reinterpret_cast<const u32x4*>(scratch), ngroups, side);
+    hipLaunchKernelGGL((conv_bfw_kernel<IN, EP, SP, NTB, PS2>), dim3(grid), dim3(256), lds, st, ka, reinterpret_cast<const u32x4*>(scratch), ngroups, side);
     BNERV_LAUNCH_CHECK("conv_bfw");
     return BNERV_OK;
 }
 
-template <int IN, int EP, int SP>
+template <int IN, int EP, int SP, bool PS2 = false>
 int launch_bfw_ntb(hipStream_t st, KArgs& ka) {
     const int nt = cdiv(ka.d.Cout, 16);
     const int ntb = nt <= 3 ? nt : (nt == 4 ? 2 : 3);
-    if (ntb == 1) return launch_bfw<IN, EP, SP, 1>(st, ka);
-    if (ntb == 2) return launch_bfw<IN, EP, SP, 2>(st, ka);
-    return launch_bfw<IN, EP, SP, 3>(st, ka);
+    if (ntb == 1) return launch_bfw<IN, EP, SP, 1, PS2>(st, ka);
+    if (ntb == 2) return launch_bfw<IN, EP, SP, 2, PS2>(st, ka);
+    return launch_bfw<IN, EP, SP, 3, PS2>(st, ka);
 }
 
-template <int IN, int EP>
+template <int IN, int EP, bool PS2 = false>
 int launch_bfw_sp(hipStream_t st, KArgs& ka) {
-    return wide_mode() == SP_BF16X3 ? launch_bfw_ntb<IN, EP, SP_BF16X3>(st, ka) : launch_bfw_ntb<IN, EP, SP_BF16X6>(st, ka);
+    return wide_mode() == SP_BF16X3 ? launch_bfw_ntb<IN, EP, SP_BF16X3, PS2>(st, ka) : launch_bfw_ntb<IN, EP, SP_BF16X6, PS2>(st, ka);
 }
 
 int launch_wide_mode(hipStream_t st, KArgs& ka) {
     const int in = ka.d.in_mode, ep = ka.d.ep_mode;
+    if (ka.d.out_s == 2) {                                 // up-conv forward: conv -> bias -> PixelShuffle(2) [-> sin, cos]
+        if (in == BNERV_IN_PLAIN && ep == BNERV_EP_BIAS_SIN) return launch_bfw_sp<BNERV_IN_PLAIN, BNERV_EP_BIAS_SIN, true>(st, ka);
+        if (in == BNERV_IN_PLAIN && ep == BNERV_EP_BIAS) return launch_bfw_sp<BNERV_IN_PLAIN, BNERV_EP_BIAS, true>(st, ka);
+        return -1;
+    }
+    if (in == BNERV_IN_UNSHUFFLE) return ep == BNERV_EP_PLAIN ? launch_bfw_sp<BNERV_IN_UNSHUFFLE, BNERV_EP_PLAIN>(st, ka) : -1;
 #define BNERV_CASE(I, E) if (in == I && ep == E) return launch_bfw_sp<I, E>(st, ka);
     BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS)
     BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS_SIN)
@@ -1080,7 +1129,6 @@ int launch_wide_mode(hipStream_t st, KArgs& ka) {
     BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_PLAIN)
     BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS)
     BNERV_CASE(BNERV_IN_GELU_AFFINE, BNERV_EP_BIAS_RES)
-    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DGELU)
     BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DSIN)
     BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_GELU)
     BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_RES)
@@ -1098,14 +1146,17 @@ extern "C" int bnerv_debug_trace_read_bf(void* host) { return (int)hipMemcpyFrom
 // Called by bnerv_conv_igemm (conv.hip) after argument validation.  Returns -1 when the shape / mode is not this kernel's
 // (the caller then takes its f32-MFMA kernels), otherwise the launch status.
 int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec) {
-    if (!vec || d.out_s != 1 || d.in_mode == BNERV_IN_UNSHUFFLE || d.in_mode == BNERV_IN_TANHGRAD) return -1;
+    if (!vec || d.in_mode == BNERV_IN_TANHGRAD) return -1;
+    const bool shuffled = d.out_s != 1 || d.in_mode == BNERV_IN_UNSHUFFLE;                // up-conv forward / its data gradient
+    if (d.out_s != 1 && (d.out_s != 2 || d.Cout % 4 != 0)) return -1;
+    if (d.in_mode == BNERV_IN_UNSHUFFLE && (d.in_s != 2 || d.Cin % 4 != 0 || d.out_s != 1)) return -1;
     const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
     if ((size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 >= LEAN_MAX_BYTES) return -1;
     KArgs ka;
     ka.d = d;
     ka.tiles_x = cdiv(d.W, TW);
     ka.tiles_y = cdiv(d.H, TH);
-    const bool narrow = d.Cout <= 16 && d.Cin <= 16;
+    const bool narrow = d.Cout <= 16 && d.Cin <= 16 && !shuffled;
     if (narrow) {                                          // one cout tile, one K chunk: opt-in (see split_mode)
         if (split_mode() < 0 || d.Cin <= 8 || d.wCo > 16 || d.wCi > 16) return -1;
         return d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);

@@ -596,3 +596,34 @@ def test_wide_split_conv_kernel_plain(ops, case, monkeypatch):
     close(out, ref, msg="wide conv fwd")
     for n, a, r in zip("xwb", torch.autograd.grad(out, [xg, wg, bg], cot.to(DEV)), rg):
         close(a, r, msg=f"wide conv d{n}")
+
+
+@pytest.mark.parametrize("case", [(1, 12, 48, 16, 32), (2, 38, 152, 9, 32), (1, 20, 36, 17, 40), (1, 46, 184, 8, 32)])
+def test_wide_split_conv_kernel_upconv_ps2(ops, case, monkeypatch):
+    """Up-conv + PixelShuffle(2) through the wide split kernel: forward with the pair-up epilogue (plain and sin/cos), data gradient
+    through the unshuffle(2) prologue; whole SNeRV block as well (its up-conv, TAT convs and every gradient)."""
+    monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    B, Cin, Ct, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(Ct, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).requires_grad_(True)
+    b = torch.randn(Ct, generator=g).requires_grad_(True)
+    ref = cpu_ref.upconv(x, w, b, 2)
+    cot = torch.randn(ref.shape, generator=g)
+    rg = torch.autograd.grad(ref, [x, w, b], cot)
+    xg, wg, bg = gpu(x), gpu(w), gpu(b)
+    out = ops.conv2d_ps(xg, wg, bg, 2)
+    close(out, ref, msg="ps2 conv fwd")
+    for n, a, r in zip("xwb", torch.autograd.grad(out, [xg, wg, bg], cot.to(DEV)), rg):
+        close(a, r, msg=f"ps2 conv d{n}")
+    Cc = Ct // 4
+    x0, mods, w0, b0, w1, b1, g2 = _tat_inputs(B, Cc, 2 * H, 2 * W, seed=11)
+    ref2 = _tat_ref(torch.sin(cpu_ref.upconv(x, w, b, 2)), mods, w0, b0, w1, b1)
+    cot2 = torch.randn(ref2.shape, generator=g2)
+    leaves = [x, w, b] + mods + [w0, b0, w1, b1]
+    rg2 = torch.autograd.grad(ref2, leaves, cot2)
+    gl = [gpu(t) for t in leaves]
+    out2 = ops.snerv_block(*gl, 2)
+    close(out2, ref2, msg="ps2 snerv fwd")
+    for n, a, r in zip(["x", "wu", "bu", "s0", "t0", "s1", "t1", "w0", "b0", "w1", "b1"], torch.autograd.grad(out2, gl, cot2.to(DEV)), rg2):
+        close(a, r, msg=f"ps2 snerv d{n}")
