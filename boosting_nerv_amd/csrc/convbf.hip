@@ -7,6 +7,7 @@
 // split into bf16 pieces (see below), f32 accumulation.
 #include "common.h"
 #include "sidejob.h"
+#include "split16.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -94,58 +95,6 @@ __device__ unsigned long long g_trace_bf[1024 * 4 * 6 * 8];
 //   * B fragments live in LDS in lane order (one ds_read_b128 per (step, piece), shared by the wave's 4 M tiles), built once per
 //     block from a coalesced read of the weight tensor.  Channels >= Cin and tap 9 carry zero weights, so whatever finite value
 //     the A side holds there contributes nothing.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-enum { SP_BF16X6 = 0, SP_BF16X3 = 1, SP_F16X3 = 2 };
-template <int SP> struct Split {
-    static constexpr int NS = (SP == SP_BF16X6) ? 3 : 2;
-    static constexpr bool SCALED = (SP == SP_F16X3);
-};
-
-template <int SP>
-__device__ __forceinline__ unsigned pk16(float a, float b) {
-    if constexpr (SP == SP_F16X3) {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, h2));
-    } else {
-        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, b2));
-    }
-}
-template <int SP>
-__device__ __forceinline__ f32x2 unpk16(unsigned pk) {
-    if constexpr (SP == SP_F16X3) {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        return __builtin_convertvector(__builtin_bit_cast(h2, pk), f32x2);
-    } else {
-        return f32x2{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
-    }
-}
-// NE (<= 8, even) floats -> NS packed 8-element pieces, round to nearest even at every level (the residuals are exact in f32);
-// elements NE..7 of every piece are zero
-template <int SP, int NE>
-__device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[Split<SP>::NS]) {
-    constexpr int NS = Split<SP>::NS;
-    f32x2 r[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = f32x2{x[2 * e], x[2 * e + 1]};
-#pragma unroll
-    for (int p = 0; p < NS; ++p) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (2 * e < NE) {
-                const unsigned pk = pk16<SP>(r[e][0], r[e][1]);
-                out[p][e] = pk;
-                if (p + 1 < NS) r[e] -= unpk16<SP>(pk);
-            } else {
-                out[p][e] = 0u;
-            }
-        }
-    }
-}
 // exact power of two that moves max_abs into [2^14, 2^15); 1 for 0 / non-finite input
 __device__ __forceinline__ float pow2_scale(float max_abs) {
     const unsigned e = (__builtin_bit_cast(unsigned, max_abs) >> 23) & 0xffu;
@@ -167,12 +116,6 @@ template <int KS> struct BfGeo {
     static_assert(HSLOT <= 128, "one slot per thread of a wave pair");
 };
 __device__ __forceinline__ int bf_slot(int r, int p, int h, int spr) { return r * spr + 8 * (p >> 2) + ((2 * (p & 3) + h + (p >> 2)) & 7); }
-
-template <int SP>
-__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
-    if constexpr (SP == SP_F16X3) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 template <int KS, int IN, int EP, int SP, int CB>
 __global__ __launch_bounds__(256, 3) void conv_bf_kernel(const KArgs ka, const SidePack side) {
@@ -1165,7 +1108,7 @@ int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec) {
     if (wide_mode() < 0 || d.k != 3 || !d.ctx) return -1;
     const bool affine = d.in_mode == BNERV_IN_AFFINE || d.in_mode == BNERV_IN_GELU_AFFINE;
     if (affine && d.Cin > AFF_MAX) return -1;
-    int min_tiles = 256;                                   // (low-resolution stages stay on the f32 kernels' split policies)
+    int min_tiles = 64;                                    // (measured: 64 beats 256 on C3 / C4 and 16 loses on C1; below it the f32 kernels' split policies win)
     if (const char* e = getenv("BNERV_SPLIT_WIDE_MIN_TILES")) min_tiles = atoi(e);     // tests lower it to reach the kernel with small shapes
     if (d.B * ka.tiles_x * ka.tiles_y < min_tiles) return -1;
     return launch_wide_mode(st, ka);

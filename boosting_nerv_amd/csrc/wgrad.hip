@@ -17,6 +17,9 @@
 // before the MFMA phase of tile t and committed to LDS after it.
 #include "common.h"
 #include "sidejob.h"
+#include "split16.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -1143,6 +1146,298 @@ static int launch_wide_modes(hipStream_t st, const WArgs& wa, const WidePlan& p)
     return launch_wide_shape<BNERV_IN_AFFINE, 0>(st, wa, p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------- split wide kernel
+// The weight gradient of the 3x3 stride-1 layers with more than 16 output or 12 input channels (plain gradient: the TAT convs and the
+// stride-1 block convs of the 22..95-channel stages) on the 16-bit matrix pipe with f32 operands split into bf16 pieces (split16.h;
+// convbf.hip explains the scheme: bf16x6 is exact to below the f32 MFMA's own rounding).  K = pixels, 32 per MFMA:
+//   * tile = 4 rows x 32 px; wave w owns row w (one K step per tile); block = MTW cout tiles x 8 column tiles (128 (ci, tap) columns);
+//   * A = the gradient: lane (cout, kq) needs 8 consecutive pixels of ONE channel -- loaded straight from global into registers (two
+//     16-B loads of a 128-B row segment shared by the 4 kq lanes), split there: no LDS for g, no staging redundancy across waves;
+//   * B = the input window: 8 consecutive pixels shifted by (ky - 1, kx - 1).  A 16-bit vector read must be 16-B aligned, so LDS holds
+//     THREE copies of the (prologue-transformed, split) input tile, one per kx, each stored pre-shifted: copy kx at position x is
+//     a[x + kx - 1]; the ky shift is a whole row.  Rows are 80 B apart (conflict spread), [piece][kx][channel][6 rows];
+//   * the bias gradient is the column after the last weight column: its B operand reads a row of ones; columns beyond read zeros;
+//   * accumulators stay in registers over the block's tiles; the waves add theirs one after the other into ONE LDS area, the block
+//     writes its 128 columns of one slab -- slabs, finish and deferred reduction exactly as the f32 wide kernel.
+constexpr int BW_TH = 4, BW_NTW = 8, BW_NPL = (BW_NTW * 16 + 7) / 9 + 1;      // 16 channels span 128 consecutive columns
+constexpr int BW_ROW = 80, BW_PLANE = 6 * BW_ROW;                             // bytes
+
+template <int IN, int SP, int MTW>
+__global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const int slots, const int ngroups_n, const int ngroups_m, const SidePack side) {
+    constexpr int NS = Split<SP>::NS;
+    constexpr bool AFF = (IN == BNERV_IN_AFFINE);
+    constexpr int PIECE = (3 * BW_NPL + 2) * BW_PLANE;                        // + a plane of ones (piece 0) / zeros and a plane of zeros
+    const bnerv_wgrad_desc& d = wa.d;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* s_a = reinterpret_cast<char*>(smem);                                // [NS][PIECE]
+    float* s_aff = reinterpret_cast<float*>(s_a + NS * PIECE);                // [2][BW_NPL]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
+    const int nW = Cin * 9;
+    const int tiles_x = (W + 31) >> 5, tiles_y = (H + BW_TH - 1) / BW_TH;
+
+    const int ngroups = ngroups_n * ngroups_m;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int slot = q / ngroups, grp = q - slot * ngroups;
+    const int mg = grp / ngroups_n;
+    const int co_base = mg * MTW * 16;
+    const int n_base = (grp - mg * ngroups_n) * BW_NTW * 16;
+    const int ci_lo = min(n_base, nW - 1) / 9, ci_hi = min(n_base + BW_NTW * 16 - 1, nW - 1) / 9;
+    const int npl = ci_hi - ci_lo + 1;
+    const int total = d.B * tiles_x * tiles_y;
+    const int per = total >> 3, extra = total & 7;
+    const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
+
+    // constant planes: ones (as bf16 1.0 in piece 0, zero in the other pieces) and zeros
+    for (int i = tid; i < NS * 2 * BW_PLANE / 4; i += 256) {
+        const int p = i / (2 * BW_PLANE / 4), w = i - p * (2 * BW_PLANE / 4);
+        reinterpret_cast<unsigned*>(s_a + p * PIECE + 3 * BW_NPL * BW_PLANE)[w] = (p == 0 && w < BW_PLANE / 4) ? 0x3f803f80u : 0u;
+    }
+
+    // staging slots of the input copies: (kx, channel, row, 4-px segment) -> one float4 at x = tx0 + 4 seg + kx - 1
+    constexpr int NSLOT = 3 * BW_NPL * 6 * 8, NXS = (NSLOT + 255) / 256;
+    const unsigned x_shift = (unsigned)((W + 4) * 4);                         // row -1, column -1 stay at non-negative offsets
+    const unsigned x_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + x_shift;
+    const unsigned g_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, x_shift, x_bytes);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(d.g, 0, g_bytes);
+    auto xslot = [&](int k, int& kx, int& c, int& r, int& sg) __attribute__((always_inline)) {
+        const int sidx = tid + k * 256;
+        sg = sidx & 7;
+        r = (sidx >> 3) % 6;
+        const int rest = (sidx >> 3) / 6;
+        c = rest % BW_NPL;
+        kx = rest / BW_NPL;
+    };
+    auto stage_a = [&](const LTile& a) __attribute__((always_inline)) {
+        const int ty0 = a.ty * BW_TH, tx0 = a.tx * 32;
+        f32x4 v[NXS];
+        bool live[NXS];
+#pragma unroll
+        for (int k = 0; k < NXS; ++k) {
+            int kx, c, r, sg;
+            xslot(k, kx, c, r, sg);
+            const int gy = ty0 + r - 1, gx = tx0 + 4 * sg + kx - 1;
+            live[k] = tid + k * 256 < NSLOT && c < npl && (unsigned)gy < (unsigned)H && gx > -4 && gx < W;
+            const unsigned vo = live[k] ? (unsigned)((((a.b * Cin + ci_lo + c) * H + gy) * W + gx) * 4) + x_shift : OOB;
+            v[k] = bload(rx, vo, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < NXS; ++k) {
+            int kx, c, r, sg;
+            xslot(k, kx, c, r, sg);
+            if (tid + k * 256 >= NSLOT) continue;
+            const int gx = tx0 + 4 * sg + kx - 1;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = live[k] && (unsigned)(gx + e) < (unsigned)W;  // zero padding applies AFTER the prologue
+                float t = v[k][e];
+                if constexpr (AFF) t = t * s_aff[c] + s_aff[BW_NPL + c];
+                x[e] = ok ? t : 0.f;
+                x[4 + e] = 0.f;
+            }
+            u32x4 pc[NS];
+            split8<SP, 4>(x, pc);
+            char* dst = s_a + ((kx * BW_NPL + c) * 6 + r) * BW_ROW + sg * 8;
+#pragma unroll
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(dst + p * PIECE) = uint2{pc[p][0], pc[p][1]};
+        }
+    };
+    auto load_affine = [&](int b) __attribute__((always_inline)) {
+        if (tid < 2 * BW_NPL) {
+            const int c = tid % BW_NPL;
+            float v = 0.f;
+            if (c < npl) v = tid < BW_NPL ? 1.0f + d.scale[b * Cin + ci_lo + c] : d.shift[b * Cin + ci_lo + c];
+            s_aff[tid] = v;
+        }
+    };
+    // gradient fragments of this wave's row: lane (cout co_base + 16 m + li, pixels 8 kq .. 8 kq + 7)
+    f32x4 ga[MTW][2];
+    auto issue_g = [&](const LTile& a) __attribute__((always_inline)) {
+        const int gy = a.ty * BW_TH + wave, gx = a.tx * 32 + 8 * kq;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int co = co_base + 16 * m + li;
+            const bool ok = co < Cout && gy < H;
+            const unsigned base = (unsigned)((((a.b * Cout + co) * H + gy) * W + gx) * 4);
+            ga[m][0] = bload(rg, (ok && gx < W) ? base : OOB, 0u);
+            ga[m][1] = bload(rg, (ok && gx + 4 < W) ? base + 16u : OOB, 0u);
+        }
+    };
+
+    int bbase[BW_NTW];
+#pragma unroll
+    for (int nt = 0; nt < BW_NTW; ++nt) {
+        const int n = n_base + nt * 16 + li;
+        int off;
+        if (n < nW) {
+            const int ci = n / 9, tap = n - ci * 9, ky = tap / 3, kx = tap - ky * 3;
+            off = ((kx * BW_NPL + (ci - ci_lo)) * 6 + ky) * BW_ROW;
+        } else {
+            off = (3 * BW_NPL + (n == nW ? 0 : 1)) * BW_PLANE;                // ones / zeros
+        }
+        bbase[nt] = off + wave * BW_ROW + kq * 16;
+    }
+
+    f32x4 acc[MTW][BW_NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int n = 0; n < BW_NTW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int itx = r0 + slot;
+    LTile it{0, 0, 0};
+    auto decode = [&](int i) __attribute__((always_inline)) {
+        LTile t;
+        const int tiles = tiles_x * tiles_y;
+        t.b = i / tiles;
+        const int rem = i - t.b * tiles;
+        t.ty = rem / tiles_x;
+        t.tx = rem - t.ty * tiles_x;
+        return t;
+    };
+    int aff_b = -1;
+    if (itx < r1) {
+        it = decode(itx);
+        issue_g(it);
+        if constexpr (AFF) { load_affine(it.b); aff_b = it.b; }
+        lds_barrier();
+        stage_a(it);
+    }
+    for (; itx < r1; itx += slots) {
+        const bool has_next = itx + slots < r1;
+        LTile nxt = it;
+        if (has_next) nxt = decode(itx + slots);
+        // split this wave's gradient row (registers only), then prefetch the next tile's
+        u32x4 afr[MTW][NS];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            float x[8] = {ga[m][0].x, ga[m][0].y, ga[m][0].z, ga[m][0].w, ga[m][1].x, ga[m][1].y, ga[m][1].z, ga[m][1].w};
+            split8<SP, 8>(x, afr[m]);
+        }
+        if (has_next) issue_g(nxt);
+        lds_barrier();                                     // (A) the input copies of this tile are in LDS
+#pragma unroll
+        for (int nt = 0; nt < BW_NTW; ++nt) {
+            u32x4 bfr[NS];
+#pragma unroll
+            for (int p = 0; p < NS; ++p) bfr[p] = *reinterpret_cast<const u32x4*>(s_a + p * PIECE + bbase[nt]);
+#define BNERV_BW_PROD(pa, pb) _Pragma("unroll") for (int m = 0; m < MTW; ++m) acc[m][nt] = mfma16<SP>(afr[m][pa], bfr[pb], acc[m][nt]);
+            if constexpr (NS == 3) {
+                BNERV_BW_PROD(2, 0)
+                BNERV_BW_PROD(0, 2)
+                BNERV_BW_PROD(1, 1)
+            }
+            BNERV_BW_PROD(1, 0)
+            BNERV_BW_PROD(0, 1)
+            BNERV_BW_PROD(0, 0)
+#undef BNERV_BW_PROD
+        }
+        lds_barrier();                                     // (B) everyone done reading
+        if (has_next) {
+            if constexpr (AFF) { if (nxt.b != aff_b) { load_affine(nxt.b); lds_barrier(); aff_b = nxt.b; } }
+            stage_a(nxt);
+        }
+        it = nxt;
+    }
+
+    // cross-wave reduction, one wave after the other into one area (fixed order), then this block's columns of the slot's slab
+    __syncthreads();
+    float* s_red = smem;
+    constexpr int RW = BW_NTW * 16, RSZ = MTW * 16 * RW;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int n = 0; n < BW_NTW; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // D fragment: column (N) = li, row (M) = 4 kq + r  ->  cout 16 m + 4 kq + r, column 16 n + li
+                        float* qd = s_red + (m * 16 + 4 * kq + r) * RW + n * 16 + li;
+                        *qd = (w == 0) ? acc[m][n][r] : *qd + acc[m][n][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* slab = wa.slab + (size_t)(xcd * slots + slot) * Cout * wa.ncols;
+    for (int idx = tid; idx < RSZ; idx += 256) {
+        const int row = idx / RW, colq = idx - row * RW;
+        const int col = n_base + colq;
+        if (co_base + row < Cout && col < wa.ncols) slab[(size_t)(co_base + row) * wa.ncols + col] = s_red[idx];
+    }
+    side_run_hosted(side, smem);
+}
+
+struct BwPlan { int mtw, ngroups_n, ngroups_m, slots; };
+static int bw_mode() {                                     // BNERV_SPLIT_WIDE = bf16x6 (default) | bf16x3 | off   (shared with convbf.hip)
+    static const int v = [] {
+        const char* e = getenv("BNERV_SPLIT_WIDE");
+        if (!e) return (int)SP_BF16X6;
+        if (!strcmp(e, "off") || !strcmp(e, "0")) return -1;
+        if (!strcmp(e, "bf16x3")) return (int)SP_BF16X3;
+        return (int)SP_BF16X6;
+    }();
+    return v;
+}
+static bool bw_ok(const WArgs& wa) {
+    const bnerv_wgrad_desc& d = wa.d;
+    if (bw_mode() < 0 || !wa.vec || d.k != 3 || d.g_s != 1 || d.g_mode == BNERV_IN_TANHGRAD) return false;
+    if (d.in_mode != BNERV_IN_PLAIN && d.in_mode != BNERV_IN_AFFINE) return false;
+    if (d.Cout <= 16 && d.Cin <= 12) return false;         // (one cout tile, few columns: the lean f32 kernel's shapes)
+    int min_tiles = 64;
+    if (const char* e = getenv("BNERV_SPLIT_WIDE_MIN_TILES")) min_tiles = atoi(e);
+    if (d.B * cdiv(d.H, TH) * cdiv(d.W, TW) < min_tiles) return false;
+    const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
+    return (size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 8) * 4 < WLEAN_MAX_BYTES;
+}
+static BwPlan bw_plan(const bnerv_wgrad_desc& d) {
+    BwPlan p;
+    const int mt = cdiv(d.Cout, 16);
+    p.mtw = mt <= 3 ? mt : (mt == 4 ? 2 : 3);
+    p.ngroups_m = cdiv(mt, p.mtw);
+    p.ngroups_n = cdiv(d.Cin * 9 + 1, BW_NTW * 16);
+    const int total = d.B * cdiv(d.H, BW_TH) * cdiv(d.W, 32);
+    int s = (256 * 2) / (8 * p.ngroups_n * p.ngroups_m);   // slots per XCD with every block resident (2 per CU)
+    const int want = cdiv(total, 8);
+    if (s > want) s = want;
+    if (s < 1) s = 1;
+    p.slots = s;
+    return p;
+}
+template <int IN, int SP, int MTW>
+int launch_bw(hipStream_t st, const WArgs& wa, const BwPlan& p) {
+    constexpr int NS = Split<SP>::NS;
+    size_t lds = (size_t)NS * (3 * BW_NPL + 2) * BW_PLANE + 2 * BW_NPL * sizeof(float);
+    const size_t red = (size_t)MTW * 16 * BW_NTW * 16 * sizeof(float);
+    if (lds < red) lds = red;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bfw_kernel<IN, SP, MTW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int grid = 8 * p.slots * p.ngroups_n * p.ngroups_m;
+    SidePack side;
+    bnerv_side_take(wa.d.ctx, &side, 2 * grid);
+    hipLaunchKernelGGL((wgrad_bfw_kernel<IN, SP, MTW>), dim3(grid), dim3(256), lds, st, wa, p.slots, p.ngroups_n, p.ngroups_m, side);
+    BNERV_LAUNCH_CHECK("wgrad_bfw");
+    return BNERV_OK;
+}
+template <int IN, int SP>
+int launch_bw_m(hipStream_t st, const WArgs& wa, const BwPlan& p) {
+    if (p.mtw == 1) return launch_bw<IN, SP, 1>(st, wa, p);
+    if (p.mtw == 2) return launch_bw<IN, SP, 2>(st, wa, p);
+    return launch_bw<IN, SP, 3>(st, wa, p);
+}
+static int launch_bw_modes(hipStream_t st, const WArgs& wa, const BwPlan& p) {
+    const bool x3 = bw_mode() == SP_BF16X3;
+    if (wa.d.in_mode == BNERV_IN_AFFINE) return x3 ? launch_bw_m<BNERV_IN_AFFINE, SP_BF16X3>(st, wa, p) : launch_bw_m<BNERV_IN_AFFINE, SP_BF16X6>(st, wa, p);
+    return x3 ? launch_bw_m<BNERV_IN_PLAIN, SP_BF16X3>(st, wa, p) : launch_bw_m<BNERV_IN_PLAIN, SP_BF16X6>(st, wa, p);
+}
+
 struct Plan { int mtw, ntw, n_mgroups, n_ngroups, nsplit; };
 
 Plan make_plan(int B, int Cin, int Cout, int H, int W, int k) {
@@ -1231,6 +1526,8 @@ extern "C" size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int
         t.Cin = Cin; t.Cout = Cout;
         const WidePlan wp = wide_plan(t);
         if (8 * wp.slots > nb) nb = 8 * wp.slots;
+        const BwPlan bp = bw_plan(t);
+        if (8 * bp.slots > nb) nb = 8 * bp.slots;
     }
     return (size_t)nb * Cout * (Cin * k * k + 1) * sizeof(float);
 }
@@ -1262,6 +1559,11 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
     if (wlean_ok(wa)) {
         rc = d.k == 1 ? launch_wlean_modes<1>(st, wa) : launch_wlean_modes<3>(st, wa);
         if (rc == BNERV_OK) n_slabs = wlean_blocks(d);
+    }
+    if (rc == -1 && bw_ok(wa)) {                          // split 16-bit kernel for the multi-tile plain gradients
+        const BwPlan bp = bw_plan(d);
+        rc = launch_bw_modes(st, wa, bp);
+        if (rc == BNERV_OK) n_slabs = 8 * bp.slots;
     }
     if (rc == -1 && wide_ok(wa)) {
         const WidePlan wp = wide_plan(d);

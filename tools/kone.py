@@ -6,13 +6,15 @@ from boosting_nerv_amd import _lib as L, ops
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "conv"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-B, C, H, W = (1, 38, 1080, 1920) if which.endswith("38") else (1, 12, 720, 1280)
+B, C, H, W = (1, 38, 1080, 1920) if "38" in which else (1, 12, 720, 1280)
 x, g = torch.randn(B, C, H, W, device=dev), torch.randn(B, C, H, W, device=dev)
 w, b = torch.randn(C, C, 3, 3, device=dev) / 10, torch.randn(C, device=dev)
 sc, sh = torch.randn(B, C, device=dev) * 0.1, torch.randn(B, C, device=dev) * 0.1
 out = torch.empty_like(x); dw, db = torch.empty_like(w), torch.empty_like(b)
 for _ in range(reps):
-    if which == "conv_k2s":       # the TAT conv0 forward the train step launches: affine -> conv -> bias -> gelu, gelu'
+    if which == "conv38_k2s":     # wide layer, TAT conv0 forward: the wide split kernel (or lean2 with BNERV_SPLIT_WIDE=off)
+        ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=sc, shift=sh, out2=g)
+    elif which == "conv_k2s":       # the TAT conv0 forward the train step launches: affine -> conv -> bias -> gelu, gelu'
         ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=sc, shift=sh, out2=g)
     elif which.startswith("conv"):
         ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS, scale=sc, shift=sh)
