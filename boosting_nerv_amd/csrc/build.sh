@@ -8,7 +8,9 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p _obj
 pids=()
 for f in abi conv convbf wgrad gemm dense optim loss dwconv cem lnorm; do
-  if [ ! -f _obj/$f.o ] || [ $f.hip -nt _obj/$f.o ] || [ common.h -nt _obj/$f.o ] || [ ../../include/bnerv.h -nt _obj/$f.o ]; then
+  stale=0
+  for h in *.h ../../include/bnerv.h; do [ $h -nt _obj/$f.o ] && stale=1; done
+  if [ ! -f _obj/$f.o ] || [ $f.hip -nt _obj/$f.o ] || [ $stale = 1 ]; then
     $HIPCC $FLAGS -c $f.hip -o _obj/$f.o &
     pids+=($!)
   fi

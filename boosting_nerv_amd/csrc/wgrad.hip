@@ -404,8 +404,15 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 
 struct LTile { int b, ty, tx; };
 
-#ifdef BNERV_TRACE   // debug variant only (tools/ktrace_w.py): s_memtime phase stamps of wgrad_lean_kernel
+#if defined(BNERV_TRACE) || defined(BNERV_TRACE_BW)   // debug variants only (tools/ktrace_w.py, ktrace_bw.py): s_memtime phase stamps
 __device__ unsigned long long g_trace_w[1024 * 4 * 8 * 8];
+#endif
+#ifdef BNERV_TRACE_BW
+#define BTRACE(it_, slot) do { if (lane == 0 && blockIdx.x < 1024 && (unsigned)(it_) < 8u) g_trace_w[((blockIdx.x * 4 + wave) * 8 + (it_)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BTRACE(it_, slot) do {} while (0)
+#endif
+#ifdef BNERV_TRACE
 #define WTRACE(it_, slot) do { if (lane == 0 && blockIdx.x < 1024 && (it_) < 8) g_trace_w[((blockIdx.x * 4 + wave) * 8 + (it_)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WTRACE(it_, slot) do {} while (0)
@@ -1151,22 +1158,27 @@ static int launch_wide_modes(hipStream_t st, const WArgs& wa, const WidePlan& p)
 // stride-1 block convs of the 22..95-channel stages) on the 16-bit matrix pipe with f32 operands split into bf16 pieces (split16.h;
 // convbf.hip explains the scheme: bf16x6 is exact to below the f32 MFMA's own rounding).  K = pixels, 32 per MFMA:
 //   * tile = 4 rows x 32 px; wave w owns row w (one K step per tile); block = MTW cout tiles x 8 column tiles (128 (ci, tap) columns);
-//   * A = the gradient: lane (cout, kq) needs 8 consecutive pixels of ONE channel -- loaded straight from global into registers (two
-//     16-B loads of a 128-B row segment shared by the 4 kq lanes), split there: no LDS for g, no staging redundancy across waves;
+//   * A = the gradient: lane (cout, kq) holds 8 pixels of ONE channel -- loaded straight from global into registers (two 16-B loads
+//     of the 128-B row segment shared by the 4 kq lanes), split there: no LDS for g, no staging redundancy across waves;
 //   * B = the input window: 8 consecutive pixels shifted by (ky - 1, kx - 1).  A 16-bit vector read must be 16-B aligned, so LDS holds
 //     THREE copies of the (prologue-transformed, split) input tile, one per kx, each stored pre-shifted: copy kx at position x is
-//     a[x + kx - 1]; the ky shift is a whole row.  Rows are 80 B apart (conflict spread), [piece][kx][channel][6 rows];
+//     a[x + kx - 1]; the ky shift is a whole row.  [piece][kx][channel][6 rows], padded against bank conflicts (BW_* below);
 //   * the bias gradient is the column after the last weight column: its B operand reads a row of ones; columns beyond read zeros;
 //   * accumulators stay in registers over the block's tiles; the waves add theirs one after the other into ONE LDS area, the block
 //     writes its 128 columns of one slab -- slabs, finish and deferred reduction exactly as the f32 wide kernel.
 constexpr int BW_TH = 4, BW_NTW = 8, BW_NPL = (BW_NTW * 16 + 7) / 9 + 1;      // 16 channels span 128 consecutive columns
-constexpr int BW_ROW = 80, BW_PLANE = 6 * BW_ROW;                             // bytes
+// LDS image of one piece (bytes): rows of 32 px x 2 B, 6 rows + 32 B per channel plane, the three kx copies 16 planes + 192 B apart.
+// With these strides the 16 lanes of a ds_read_b128 service group (16 consecutive (ci, ky, kx) columns, two kq) spread over the 16
+// 16-B slots of the bank row almost evenly (exhaustive search over paddings <= this size: 1.9 accesses per slot-cycle on average
+// against 3.0 for the unpadded image; the only conflict-free layout needs 800-B planes, i.e. one block per CU).
+constexpr int BW_ROW = 64, BW_PLANE = 6 * BW_ROW + 32, BW_COPY = BW_NPL * BW_PLANE + 192, BW_CONST = 4 * BW_ROW;
+constexpr int BW_PIECE = 3 * BW_COPY + 2 * BW_CONST;                          // + a plane of ones (piece 0 only) and a plane of zeros
 
 template <int IN, int SP, int MTW>
 __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const int slots, const int ngroups_n, const int ngroups_m, const SidePack side) {
     constexpr int NS = Split<SP>::NS;
     constexpr bool AFF = (IN == BNERV_IN_AFFINE);
-    constexpr int PIECE = (3 * BW_NPL + 2) * BW_PLANE;                        // + a plane of ones (piece 0) / zeros and a plane of zeros
+    constexpr int PIECE = BW_PIECE;
     const bnerv_wgrad_desc& d = wa.d;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* s_a = reinterpret_cast<char*>(smem);                                // [NS][PIECE]
@@ -1190,60 +1202,122 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
     const int per = total >> 3, extra = total & 7;
     const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
 
-    // constant planes: ones (as bf16 1.0 in piece 0, zero in the other pieces) and zeros
-    for (int i = tid; i < NS * 2 * BW_PLANE / 4; i += 256) {
-        const int p = i / (2 * BW_PLANE / 4), w = i - p * (2 * BW_PLANE / 4);
-        reinterpret_cast<unsigned*>(s_a + p * PIECE + 3 * BW_NPL * BW_PLANE)[w] = (p == 0 && w < BW_PLANE / 4) ? 0x3f803f80u : 0u;
+    // constant planes: ones (bf16 1.0 in piece 0, zero in the other pieces) and zeros
+    for (int i = tid; i < NS * 2 * BW_CONST / 4; i += 256) {
+        const int p = i / (2 * BW_CONST / 4), w = i - p * (2 * BW_CONST / 4);
+        reinterpret_cast<unsigned*>(s_a + p * PIECE + 3 * BW_COPY)[w] = (p == 0 && w < BW_CONST / 4) ? 0x3f803f80u : 0u;
     }
 
-    // staging slots of the input copies: (kx, channel, row, 4-px segment) -> one float4 at x = tx0 + 4 seg + kx - 1
-    constexpr int NSLOT = 3 * BW_NPL * 6 * 8, NXS = (NSLOT + 255) / 256;
-    const unsigned x_shift = (unsigned)((W + 4) * 4);                         // row -1, column -1 stay at non-negative offsets
-    const unsigned x_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + x_shift;
+    // staging slots: (channel, row, 4-px segment) -> the aligned float4 at x = tx0 + 4 sg plus its two neighbours x - 1 and x + 4.
+    // The six values are split ONCE as the pairs (v0, v1) (v2, v3) (L, R): copy kx = 1 is the first two pairs as they are, copies
+    // kx = 0 (a[x - 1]) and kx = 2 (a[x + 1]) share the middle pair (v1, v2) = one alignbit and take one byte-permute each.
+    // Addresses: per-lane offsets are constants of the block, the tile enters through the scalar offset of the buffer loads; only the
+    // tiles on the image border (a few per cent) compute per-slot validity.
+    constexpr int NXS = BW_NPL * 6 * 8 / 256;                                 // = 3 slots per thread, no idle ones
+    static_assert(BW_NPL * 6 * 8 == NXS * 256, "staging slots must fill the block");
+    const unsigned x_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4);
     const unsigned g_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, x_shift, x_bytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, 0, x_bytes);
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(d.g, 0, g_bytes);
-    auto xslot = [&](int k, int& kx, int& c, int& r, int& sg) __attribute__((always_inline)) {
+    int xs_c[NXS], xs_r[NXS], xs_lds[NXS];
+    unsigned xs_off[NXS], gs_off[MTW];
+    const int xs_sg = tid & 7;
+#pragma unroll
+    for (int k = 0; k < NXS; ++k) {
         const int sidx = tid + k * 256;
-        sg = sidx & 7;
-        r = (sidx >> 3) % 6;
-        const int rest = (sidx >> 3) / 6;
-        c = rest % BW_NPL;
-        kx = rest / BW_NPL;
+        xs_r[k] = (sidx >> 3) % 6;
+        xs_c[k] = (sidx >> 3) / 6;
+        xs_lds[k] = xs_c[k] * BW_PLANE + xs_r[k] * BW_ROW + (xs_sg & 3) * 16 + (xs_sg >> 2) * 8;   // K order of the fragments, see gs_off
+        xs_off[k] = xs_c[k] < npl ? (unsigned)(((xs_c[k] * H + xs_r[k]) * W + 4 * xs_sg) * 4) : OOB;
+    }
+#pragma unroll
+    // K order inside a 32-px step: lane kq holds pixels 4 kq .. 4 kq + 3 and 16 + 4 kq .. 16 + 4 kq + 3, so that each of the two loads
+    // of a fragment reads 64 contiguous bytes per channel row (the LDS rows of the input are stored in the same order)
+    for (int m = 0; m < MTW; ++m) gs_off[m] = co_base + 16 * m + li < Cout ? (unsigned)((((16 * m + li) * H + wave) * W + 4 * kq) * 4) : OOB;
+    f32x4 xv[NXS];
+    float xl[NXS], xr[NXS];
+    f32x4 ga[MTW][2];                                                         // gradient fragments of this wave's row: lane (cout co_base + 16 m + li,
+                                                                              // pixels 8 kq .. 8 kq + 7)
+    unsigned xmask = 0;                                                       // border tiles: bit 3k: slot live, 3k + 1: left neighbour, 3k + 2: right
+    auto tile_interior = [&](const LTile& a) __attribute__((always_inline)) {
+        return a.ty > 0 && a.ty * BW_TH + BW_TH + 1 <= H && a.tx > 0 && a.tx * 32 + 32 < W;
     };
-    auto stage_a = [&](const LTile& a) __attribute__((always_inline)) {
+    auto issue_loads = [&](const LTile& a) __attribute__((always_inline)) {
         const int ty0 = a.ty * BW_TH, tx0 = a.tx * 32;
-        f32x4 v[NXS];
-        bool live[NXS];
+        if (tile_interior(a)) {
+            const unsigned sx = (unsigned)((((a.b * Cin + ci_lo) * H + ty0 - 1) * W + tx0) * 4);
+            const unsigned sg = (unsigned)((((a.b * Cout + co_base) * H + ty0) * W + tx0) * 4);
 #pragma unroll
-        for (int k = 0; k < NXS; ++k) {
-            int kx, c, r, sg;
-            xslot(k, kx, c, r, sg);
-            const int gy = ty0 + r - 1, gx = tx0 + 4 * sg + kx - 1;
-            live[k] = tid + k * 256 < NSLOT && c < npl && (unsigned)gy < (unsigned)H && gx > -4 && gx < W;
-            const unsigned vo = live[k] ? (unsigned)((((a.b * Cin + ci_lo + c) * H + gy) * W + gx) * 4) + x_shift : OOB;
-            v[k] = bload(rx, vo, 0u);
+            for (int m = 0; m < MTW; ++m) {
+                ga[m][0] = bload(rg, gs_off[m], sg);
+                ga[m][1] = bload(rg, gs_off[m], sg + 64u);
+            }
+#pragma unroll
+            for (int k = 0; k < NXS; ++k) {
+                xv[k] = bload(rx, xs_off[k], sx);
+                xl[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)xs_off[k], (int)(sx - 4u), 0));
+                xr[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)xs_off[k], (int)(sx + 16u), 0));
+            }
+            return;
         }
+        {
+            const int gy = ty0 + wave, gx = tx0 + 4 * kq;
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int co = co_base + 16 * m + li;
+                const bool ok = co < Cout && gy < H;
+                const unsigned base = (unsigned)((((a.b * Cout + co) * H + gy) * W + gx) * 4);
+                ga[m][0] = bload(rg, (ok && gx < W) ? base : OOB, 0u);
+                ga[m][1] = bload(rg, (ok && gx + 16 < W) ? base + 64u : OOB, 0u);
+            }
+        }
+        const int gx = tx0 + 4 * xs_sg;
+        xmask = 0;
 #pragma unroll
         for (int k = 0; k < NXS; ++k) {
-            int kx, c, r, sg;
-            xslot(k, kx, c, r, sg);
-            if (tid + k * 256 >= NSLOT) continue;
-            const int gx = tx0 + 4 * sg + kx - 1;
-            float x[8];
+            const int gy = ty0 + xs_r[k] - 1;
+            const bool live = xs_c[k] < npl && (unsigned)gy < (unsigned)H && gx < W;
+            const bool hl = live && gx > 0, hr = live && gx + 4 < W;
+            const unsigned vo = (unsigned)((((a.b * Cin + ci_lo + xs_c[k]) * H + gy) * W + gx) * 4);
+            xv[k] = bload(rx, live ? vo : OOB, 0u);
+            xl[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(hl ? vo - 4u : OOB), 0, 0));
+            xr[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(hr ? vo + 16u : OOB), 0, 0));
+            xmask |= (live ? 1u : 0u) << (3 * k) | (hl ? 2u : 0u) << (3 * k) | (hr ? 4u : 0u) << (3 * k);
+        }
+    };
+    float a_sc[NXS], a_sh[NXS];                                               // this thread's slots' affine parameters (per batch item)
+    auto fetch_affine = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool ok = live[k] && (unsigned)(gx + e) < (unsigned)W;  // zero padding applies AFTER the prologue
-                float t = v[k][e];
-                if constexpr (AFF) t = t * s_aff[c] + s_aff[BW_NPL + c];
-                x[e] = ok ? t : 0.f;
-                x[4 + e] = 0.f;
+        for (int k = 0; k < NXS; ++k) { a_sc[k] = s_aff[xs_c[k]]; a_sh[k] = s_aff[BW_NPL + xs_c[k]]; }
+    };
+    auto store_x = [&](const bool interior) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NXS; ++k) {
+            float x[8] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w, xl[k], xr[k], 0.f, 0.f};
+            if constexpr (AFF) {                                              // zero padding applies AFTER the prologue; dead channels carry
+                const float sc = a_sc[k], sh = a_sh[k];                       // scale = shift = 0, so an interior tile needs no mask at all
+#pragma unroll
+                for (int e = 0; e < 6; ++e) x[e] = x[e] * sc + sh;
+                if (!interior) {
+                    const bool live = (xmask >> (3 * k)) & 1u, hl = (xmask >> (3 * k)) & 2u, hr = (xmask >> (3 * k)) & 4u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = live ? x[e] : 0.f;
+                    x[4] = hl ? x[4] : 0.f;
+                    x[5] = hr ? x[5] : 0.f;
+                }
             }
             u32x4 pc[NS];
-            split8<SP, 4>(x, pc);
-            char* dst = s_a + ((kx * BW_NPL + c) * 6 + r) * BW_ROW + sg * 8;
+            split8<SP, 6>(x, pc);
+            char* dst = s_a + xs_lds[k];
 #pragma unroll
-            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(dst + p * PIECE) = uint2{pc[p][0], pc[p][1]};
+            for (int p = 0; p < NS; ++p) {
+                const unsigned mid = __builtin_amdgcn_alignbit(pc[p][1], pc[p][0], 16);                  // (v1, v2)
+                const unsigned lft = __builtin_amdgcn_perm(pc[p][0], pc[p][2], 0x05040100u);            // (L, v0)
+                const unsigned rgt = __builtin_amdgcn_perm(pc[p][2], pc[p][1], 0x07060302u);            // (v3, R)
+                *reinterpret_cast<uint2*>(dst + p * PIECE) = uint2{lft, mid};
+                *reinterpret_cast<uint2*>(dst + p * PIECE + BW_COPY) = uint2{pc[p][0], pc[p][1]};
+                *reinterpret_cast<uint2*>(dst + p * PIECE + 2 * BW_COPY) = uint2{mid, rgt};
+            }
         }
     };
     auto load_affine = [&](int b) __attribute__((always_inline)) {
@@ -1254,19 +1328,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
             s_aff[tid] = v;
         }
     };
-    // gradient fragments of this wave's row: lane (cout co_base + 16 m + li, pixels 8 kq .. 8 kq + 7)
-    f32x4 ga[MTW][2];
-    auto issue_g = [&](const LTile& a) __attribute__((always_inline)) {
-        const int gy = a.ty * BW_TH + wave, gx = a.tx * 32 + 8 * kq;
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            const int co = co_base + 16 * m + li;
-            const bool ok = co < Cout && gy < H;
-            const unsigned base = (unsigned)((((a.b * Cout + co) * H + gy) * W + gx) * 4);
-            ga[m][0] = bload(rg, (ok && gx < W) ? base : OOB, 0u);
-            ga[m][1] = bload(rg, (ok && gx + 4 < W) ? base + 16u : OOB, 0u);
-        }
-    };
 
     int bbase[BW_NTW];
 #pragma unroll
@@ -1275,9 +1336,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
         int off;
         if (n < nW) {
             const int ci = n / 9, tap = n - ci * 9, ky = tap / 3, kx = tap - ky * 3;
-            off = ((kx * BW_NPL + (ci - ci_lo)) * 6 + ky) * BW_ROW;
+            off = kx * BW_COPY + (ci - ci_lo) * BW_PLANE + ky * BW_ROW;
         } else {
-            off = (3 * BW_NPL + (n == nW ? 0 : 1)) * BW_PLANE;                // ones / zeros
+            off = 3 * BW_COPY + (n == nW ? 0 : BW_CONST);                     // ones / zeros
         }
         bbase[nt] = off + wave * BW_ROW + kq * 16;
     }
@@ -1302,30 +1363,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
     int aff_b = -1;
     if (itx < r1) {
         it = decode(itx);
-        issue_g(it);
+        issue_loads(it);
         if constexpr (AFF) { load_affine(it.b); aff_b = it.b; }
         lds_barrier();
-        stage_a(it);
+        if constexpr (AFF) fetch_affine();
+        store_x(tile_interior(it));
     }
-    for (; itx < r1; itx += slots) {
+    int bt = -3;                                          // (trace: tiles 3..9 of the block)
+    for (; itx < r1; itx += slots, ++bt) {
+        BTRACE(bt, 0);
         const bool has_next = itx + slots < r1;
         LTile nxt = it;
         if (has_next) nxt = decode(itx + slots);
-        // split this wave's gradient row (registers only), then prefetch the next tile's
+        // split this wave's gradient row (registers only), then prefetch the next tile's gradient and input
         u32x4 afr[MTW][NS];
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             float x[8] = {ga[m][0].x, ga[m][0].y, ga[m][0].z, ga[m][0].w, ga[m][1].x, ga[m][1].y, ga[m][1].z, ga[m][1].w};
             split8<SP, 8>(x, afr[m]);
         }
-        if (has_next) issue_g(nxt);
+        BTRACE(bt, 1);
+        if (has_next) issue_loads(nxt);
+        BTRACE(bt, 2);
         lds_barrier();                                     // (A) the input copies of this tile are in LDS
+        BTRACE(bt, 3);
+        // B fragments one column tile ahead of their products (two register sets); the scheduler is pinned so that the reads of
+        // tile nt + 1 are issued BEFORE the 6 x MTW products of tile nt and their latency never shows
+        u32x4 bfr[2][NS];
+#pragma unroll
+        for (int p = 0; p < NS; ++p) bfr[0][p] = *reinterpret_cast<const u32x4*>(s_a + p * PIECE + bbase[0]);
 #pragma unroll
         for (int nt = 0; nt < BW_NTW; ++nt) {
-            u32x4 bfr[NS];
+            if (nt + 1 < BW_NTW) {
 #pragma unroll
-            for (int p = 0; p < NS; ++p) bfr[p] = *reinterpret_cast<const u32x4*>(s_a + p * PIECE + bbase[nt]);
-#define BNERV_BW_PROD(pa, pb) _Pragma("unroll") for (int m = 0; m < MTW; ++m) acc[m][nt] = mfma16<SP>(afr[m][pa], bfr[pb], acc[m][nt]);
+                for (int p = 0; p < NS; ++p) bfr[(nt + 1) & 1][p] = *reinterpret_cast<const u32x4*>(s_a + p * PIECE + bbase[nt + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#define BNERV_BW_PROD(pa, pb) _Pragma("unroll") for (int m = 0; m < MTW; ++m) acc[m][nt] = mfma16<SP>(afr[m][pa], bfr[nt & 1][pb], acc[m][nt]);
             if constexpr (NS == 3) {
                 BNERV_BW_PROD(2, 0)
                 BNERV_BW_PROD(0, 2)
@@ -1335,12 +1409,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
             BNERV_BW_PROD(0, 1)
             BNERV_BW_PROD(0, 0)
 #undef BNERV_BW_PROD
+            __builtin_amdgcn_sched_barrier(0);
         }
+        BTRACE(bt, 4);
         lds_barrier();                                     // (B) everyone done reading
+        BTRACE(bt, 5);
         if (has_next) {
-            if constexpr (AFF) { if (nxt.b != aff_b) { load_affine(nxt.b); lds_barrier(); aff_b = nxt.b; } }
-            stage_a(nxt);
+            if constexpr (AFF) { if (nxt.b != aff_b) { load_affine(nxt.b); lds_barrier(); fetch_affine(); aff_b = nxt.b; } }
+            if (tile_interior(nxt)) store_x(true);
+            else store_x(false);
         }
+        BTRACE(bt, 6);
         it = nxt;
     }
 
@@ -1411,7 +1490,7 @@ static BwPlan bw_plan(const bnerv_wgrad_desc& d) {
 template <int IN, int SP, int MTW>
 int launch_bw(hipStream_t st, const WArgs& wa, const BwPlan& p) {
     constexpr int NS = Split<SP>::NS;
-    size_t lds = (size_t)NS * (3 * BW_NPL + 2) * BW_PLANE + 2 * BW_NPL * sizeof(float);
+    size_t lds = (size_t)NS * BW_PIECE + 2 * BW_NPL * sizeof(float);
     const size_t red = (size_t)MTW * 16 * BW_NTW * 16 * sizeof(float);
     if (lds < red) lds = red;
     static bool attr = false;
@@ -1513,7 +1592,7 @@ int launch_modes(hipStream_t st, const WArgs& wa, const Plan& p) {
 
 }  // namespace
 
-#ifdef BNERV_TRACE
+#if defined(BNERV_TRACE) || defined(BNERV_TRACE_BW)
 extern "C" int bnerv_debug_trace_read_w(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_w), sizeof(g_trace_w)); }
 #endif
 extern "C" size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int k) {

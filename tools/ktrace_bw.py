@@ -1,0 +1,26 @@
+"""Phase timeline of wgrad_bfw_kernel from a -DBNERV_TRACE_BW build (debug variant; BNERV_LIB points at it).  s_memtime ticks = 100 MHz
+constant clock on gfx950 -> printed in ns."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from boosting_nerv_amd import _lib as L, ops
+dev = torch.device("cuda:0")
+B, Cc, H, W = 1, int(os.environ.get("KT_C", 38)), 1080, 1920
+x, g = torch.randn(B, Cc, H, W, device=dev), torch.randn(B, Cc, H, W, device=dev)
+w, b = torch.empty(Cc, Cc, 3, 3, device=dev), torch.empty(Cc, device=dev)
+sc, sh = torch.randn(B, Cc, device=dev) * 0.1, torch.randn(B, Cc, device=dev) * 0.1
+for _ in range(4):
+    ops._wgrad(x, g, w, b, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=sc, shift=sh)
+torch.cuda.synchronize()
+lib = L.load()
+buf = np.zeros(1024 * 4 * 8 * 8, dtype=np.uint64)
+fn = lib.bnerv_debug_trace_read_w; fn.restype = C.c_int; fn.argtypes = [C.c_void_p]
+assert fn(buf.ctypes.data) == 0
+t = buf.reshape(1024, 4, 8, 8).astype(np.int64)
+names = ["split g", "issue loads", "barrier A", "MFMA loop", "barrier B", "store x"]
+for it in range(7):
+    tt = t[:, :, it, :].reshape(-1, 8)
+    tt = tt[tt[:, 6] > 0]
+    if not len(tt): continue
+    d = [tt[:, i + 1] - tt[:, i] for i in range(6)]
+    print(f"tile {it + 3}: waves {len(tt):5d}  " + "  ".join(f"{n} {np.median(x_) * 10:.0f}" for n, x_ in zip(names, d)) + f"  total {np.median(tt[:, 6] - tt[:, 0]) * 10:.0f} ns")
