@@ -19,6 +19,7 @@
 #include "sidejob.h"
 #include "split16.h"
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 namespace {
@@ -1174,7 +1175,8 @@ constexpr int BW_TH = 4, BW_NTW = 8, BW_NPL = (BW_NTW * 16 + 7) / 9 + 1;      //
 constexpr int BW_ROW = 64, BW_PLANE = 6 * BW_ROW + 32, BW_COPY = BW_NPL * BW_PLANE + 192, BW_CONST = 4 * BW_ROW;
 constexpr int BW_PIECE = 3 * BW_COPY + 2 * BW_CONST;                          // + a plane of ones (piece 0 only) and a plane of zeros
 
-template <int IN, int SP, int MTW>
+// GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient of an up-conv (conv channel 4c + 2i + j at (y, x) = du[c][2y + i][2x + j])
+template <int IN, int SP, int MTW, int GM2>
 __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const int slots, const int ngroups_n, const int ngroups_m, const SidePack side) {
     constexpr int NS = Split<SP>::NS;
     constexpr bool AFF = (IN == BNERV_IN_AFFINE);
@@ -1230,10 +1232,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
         xs_lds[k] = xs_c[k] * BW_PLANE + xs_r[k] * BW_ROW + (xs_sg & 3) * 16 + (xs_sg >> 2) * 8;   // K order of the fragments, see gs_off
         xs_off[k] = xs_c[k] < npl ? (unsigned)(((xs_c[k] * H + xs_r[k]) * W + 4 * xs_sg) * 4) : OOB;
     }
-#pragma unroll
     // K order inside a 32-px step: lane kq holds pixels 4 kq .. 4 kq + 3 and 16 + 4 kq .. 16 + 4 kq + 3, so that each of the two loads
-    // of a fragment reads 64 contiguous bytes per channel row (the LDS rows of the input are stored in the same order)
-    for (int m = 0; m < MTW; ++m) gs_off[m] = co_base + 16 * m + li < Cout ? (unsigned)((((16 * m + li) * H + wave) * W + 4 * kq) * 4) : OOB;
+    // of a fragment reads 64 contiguous bytes per channel row (the LDS rows of the input are stored in the same order).
+    // Shuffled gradient (GM2): the lane pair (j = 0, 1) of conv channels 4c + 2i + j shares 2 x 8 consecutive floats of row 2y + i of
+    // du[c] -- lane j loads the block of pixel group j (32 B), keeps its own parity and swaps the other one with its partner (DPP).
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const int cl = 16 * m + li;
+        if constexpr (GM2 == 1)
+            gs_off[m] = co_base + cl < Cout ? (unsigned)(((((cl >> 2) * 2 * H) + 2 * wave + ((cl >> 1) & 1)) * 2 * W + 8 * kq + 32 * (cl & 1)) * 4) : OOB;
+        else
+            gs_off[m] = co_base + cl < Cout ? (unsigned)(((cl * H + wave) * W + 4 * kq) * 4) : OOB;
+    }
     f32x4 xv[NXS];
     float xl[NXS], xr[NXS];
     f32x4 ga[MTW][2];                                                         // gradient fragments of this wave's row: lane (cout co_base + 16 m + li,
@@ -1246,11 +1256,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
         const int ty0 = a.ty * BW_TH, tx0 = a.tx * 32;
         if (tile_interior(a)) {
             const unsigned sx = (unsigned)((((a.b * Cin + ci_lo) * H + ty0 - 1) * W + tx0) * 4);
-            const unsigned sg = (unsigned)((((a.b * Cout + co_base) * H + ty0) * W + tx0) * 4);
+            const unsigned sg = GM2 == 1 ? (unsigned)(((((a.b * (Cout >> 2) + (co_base >> 2)) * 2 * H) + 2 * ty0) * 2 * W + 2 * tx0) * 4)
+                                         : (unsigned)((((a.b * Cout + co_base) * H + ty0) * W + tx0) * 4);
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 ga[m][0] = bload(rg, gs_off[m], sg);
-                ga[m][1] = bload(rg, gs_off[m], sg + 64u);
+                ga[m][1] = bload(rg, gs_off[m], sg + (GM2 == 1 ? 16u : 64u));
             }
 #pragma unroll
             for (int k = 0; k < NXS; ++k) {
@@ -1266,9 +1277,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
             for (int m = 0; m < MTW; ++m) {
                 const int co = co_base + 16 * m + li;
                 const bool ok = co < Cout && gy < H;
-                const unsigned base = (unsigned)((((a.b * Cout + co) * H + gy) * W + gx) * 4);
-                ga[m][0] = bload(rg, (ok && gx < W) ? base : OOB, 0u);
-                ga[m][1] = bload(rg, (ok && gx + 16 < W) ? base + 64u : OOB, 0u);
+                if constexpr (GM2 == 1) {
+                    const int px0 = gx + 16 * (co & 1);
+                    const unsigned base = (unsigned)(((((a.b * (Cout >> 2) + (co >> 2)) * 2 * H) + 2 * gy + ((co >> 1) & 1)) * 2 * W + 2 * px0) * 4);
+                    ga[m][0] = bload(rg, (ok && px0 < W) ? base : OOB, 0u);
+                    ga[m][1] = bload(rg, (ok && px0 < W) ? base + 16u : OOB, 0u);
+                } else {
+                    const unsigned base = (unsigned)((((a.b * Cout + co) * H + gy) * W + gx) * 4);
+                    ga[m][0] = bload(rg, (ok && gx < W) ? base : OOB, 0u);
+                    ga[m][1] = bload(rg, (ok && gx + 16 < W) ? base + 64u : OOB, 0u);
+                }
             }
         }
         const int gx = tx0 + 4 * xs_sg;
@@ -1377,29 +1395,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
         if (has_next) nxt = decode(itx + slots);
         // split this wave's gradient row (registers only), then prefetch the next tile's gradient and input
         u32x4 afr[MTW][NS];
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            float x[8] = {ga[m][0].x, ga[m][0].y, ga[m][0].z, ga[m][0].w, ga[m][1].x, ga[m][1].y, ga[m][1].z, ga[m][1].w};
-            split8<SP, 8>(x, afr[m]);
-        }
+        auto split_g = [&](auto mc) __attribute__((always_inline)) {          // (explicit per-m instances: a loop with DPP moves is not unrolled)
+            constexpr int m = decltype(mc)::value;
+            if constexpr (m < MTW) {
+                float x[8] = {ga[m][0].x, ga[m][0].y, ga[m][0].z, ga[m][0].w, ga[m][1].x, ga[m][1].y, ga[m][1].z, ga[m][1].w};
+                if constexpr (GM2 == 1) {
+                    // own block f0..f7: even floats belong to channel j = 0, odd ones to j = 1.  The j = 0 lane holds pixel group 0, the
+                    // j = 1 lane group 1; each keeps its parity of its own block and gets its parity of the partner's block.
+                    const bool odd = li & 1;
+                    const float k0 = odd ? x[1] : x[0], k1 = odd ? x[3] : x[2], k2 = odd ? x[5] : x[4], k3 = odd ? x[7] : x[6];
+                    const float s0 = odd ? x[0] : x[1], s1 = odd ? x[2] : x[3], s2 = odd ? x[4] : x[5], s3 = odd ? x[6] : x[7];
+                    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, false));
+                    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, false));
+                    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0xB1, 0xF, 0xF, false));
+                    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s3), 0xB1, 0xF, 0xF, false));
+                    x[0] = odd ? r0 : k0; x[1] = odd ? r1 : k1; x[2] = odd ? r2 : k2; x[3] = odd ? r3 : k3;
+                    x[4] = odd ? k0 : r0; x[5] = odd ? k1 : r1; x[6] = odd ? k2 : r2; x[7] = odd ? k3 : r3;
+                }
+                split8<SP, 8>(x, afr[m]);
+            }
+        };
+        split_g(std::integral_constant<int, 0>{});
+        split_g(std::integral_constant<int, 1>{});
+        split_g(std::integral_constant<int, 2>{});
         BTRACE(bt, 1);
         if (has_next) issue_loads(nxt);
         BTRACE(bt, 2);
         lds_barrier();                                     // (A) the input copies of this tile are in LDS
         BTRACE(bt, 3);
-        // B fragments one column tile ahead of their products (two register sets); the scheduler is pinned so that the reads of
-        // tile nt + 1 are issued BEFORE the 6 x MTW products of tile nt and their latency never shows
-        u32x4 bfr[2][NS];
-#pragma unroll
-        for (int p = 0; p < NS; ++p) bfr[0][p] = *reinterpret_cast<const u32x4*>(s_a + p * PIECE + bbase[0]);
+        // (reading the B fragments one column tile ahead through a second register set was measured: no gain -- the other resident
+        //  block covers the LDS latency -- and it costs the MTW = 3 variants their last registers)
 #pragma unroll
         for (int nt = 0; nt < BW_NTW; ++nt) {
-            if (nt + 1 < BW_NTW) {
+            u32x4 bfr[NS];
 #pragma unroll
-                for (int p = 0; p < NS; ++p) bfr[(nt + 1) & 1][p] = *reinterpret_cast<const u32x4*>(s_a + p * PIECE + bbase[nt + 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#define BNERV_BW_PROD(pa, pb) _Pragma("unroll") for (int m = 0; m < MTW; ++m) acc[m][nt] = mfma16<SP>(afr[m][pa], bfr[nt & 1][pb], acc[m][nt]);
+            for (int p = 0; p < NS; ++p) bfr[p] = *reinterpret_cast<const u32x4*>(s_a + p * PIECE + bbase[nt]);
+#define BNERV_BW_PROD(pa, pb) _Pragma("unroll") for (int m = 0; m < MTW; ++m) acc[m][nt] = mfma16<SP>(afr[m][pa], bfr[pb], acc[m][nt]);
             if constexpr (NS == 3) {
                 BNERV_BW_PROD(2, 0)
                 BNERV_BW_PROD(0, 2)
@@ -1409,7 +1440,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
             BNERV_BW_PROD(0, 1)
             BNERV_BW_PROD(0, 0)
 #undef BNERV_BW_PROD
-            __builtin_amdgcn_sched_barrier(0);
         }
         BTRACE(bt, 4);
         lds_barrier();                                     // (B) everyone done reading
@@ -1464,8 +1494,9 @@ static int bw_mode() {                                     // BNERV_SPLIT_WIDE =
 }
 static bool bw_ok(const WArgs& wa) {
     const bnerv_wgrad_desc& d = wa.d;
-    if (bw_mode() < 0 || !wa.vec || d.k != 3 || d.g_s != 1 || d.g_mode == BNERV_IN_TANHGRAD) return false;
+    if (bw_mode() < 0 || !wa.vec || d.k != 3 || d.g_s > 2 || d.g_mode == BNERV_IN_TANHGRAD) return false;
     if (d.in_mode != BNERV_IN_PLAIN && d.in_mode != BNERV_IN_AFFINE) return false;
+    if (d.g_s == 2 && d.in_mode != BNERV_IN_PLAIN) return false;
     if (d.Cout <= 16 && d.Cin <= 12) return false;         // (one cout tile, few columns: the lean f32 kernel's shapes)
     int min_tiles = 64;
     if (const char* e = getenv("BNERV_SPLIT_WIDE_MIN_TILES")) min_tiles = atoi(e);
@@ -1487,7 +1518,7 @@ static BwPlan bw_plan(const bnerv_wgrad_desc& d) {
     p.slots = s;
     return p;
 }
-template <int IN, int SP, int MTW>
+template <int IN, int SP, int MTW, int GM2>
 int launch_bw(hipStream_t st, const WArgs& wa, const BwPlan& p) {
     constexpr int NS = Split<SP>::NS;
     size_t lds = (size_t)NS * BW_PIECE + 2 * BW_NPL * sizeof(float);
@@ -1495,26 +1526,28 @@ int launch_bw(hipStream_t st, const WArgs& wa, const BwPlan& p) {
     if (lds < red) lds = red;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bfw_kernel<IN, SP, MTW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bfw_kernel<IN, SP, MTW, GM2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const int grid = 8 * p.slots * p.ngroups_n * p.ngroups_m;
     SidePack side;
     bnerv_side_take(wa.d.ctx, &side, 2 * grid);
-    hipLaunchKernelGGL((wgrad_bfw_kernel<IN, SP, MTW>), dim3(grid), dim3(256), lds, st, wa, p.slots, p.ngroups_n, p.ngroups_m, side);
+    hipLaunchKernelGGL((wgrad_bfw_kernel<IN, SP, MTW, GM2>), dim3(grid), dim3(256), lds, st, wa, p.slots, p.ngroups_n, p.ngroups_m, side);
     BNERV_LAUNCH_CHECK("wgrad_bfw");
     return BNERV_OK;
 }
-template <int IN, int SP>
+template <int IN, int SP, int GM2>
 int launch_bw_m(hipStream_t st, const WArgs& wa, const BwPlan& p) {
-    if (p.mtw == 1) return launch_bw<IN, SP, 1>(st, wa, p);
-    if (p.mtw == 2) return launch_bw<IN, SP, 2>(st, wa, p);
-    return launch_bw<IN, SP, 3>(st, wa, p);
+    if (p.mtw == 1) return launch_bw<IN, SP, 1, GM2>(st, wa, p);
+    if (p.mtw == 2) return launch_bw<IN, SP, 2, GM2>(st, wa, p);
+    return launch_bw<IN, SP, 3, GM2>(st, wa, p);
 }
 static int launch_bw_modes(hipStream_t st, const WArgs& wa, const BwPlan& p) {
     const bool x3 = bw_mode() == SP_BF16X3;
-    if (wa.d.in_mode == BNERV_IN_AFFINE) return x3 ? launch_bw_m<BNERV_IN_AFFINE, SP_BF16X3>(st, wa, p) : launch_bw_m<BNERV_IN_AFFINE, SP_BF16X6>(st, wa, p);
-    return x3 ? launch_bw_m<BNERV_IN_PLAIN, SP_BF16X3>(st, wa, p) : launch_bw_m<BNERV_IN_PLAIN, SP_BF16X6>(st, wa, p);
+    if (wa.d.g_s == 2)                                     // (the up-convs: plain input, shuffled gradient)
+        return x3 ? launch_bw_m<BNERV_IN_PLAIN, SP_BF16X3, 1>(st, wa, p) : launch_bw_m<BNERV_IN_PLAIN, SP_BF16X6, 1>(st, wa, p);
+    if (wa.d.in_mode == BNERV_IN_AFFINE) return x3 ? launch_bw_m<BNERV_IN_AFFINE, SP_BF16X3, 0>(st, wa, p) : launch_bw_m<BNERV_IN_AFFINE, SP_BF16X6, 0>(st, wa, p);
+    return x3 ? launch_bw_m<BNERV_IN_PLAIN, SP_BF16X3, 0>(st, wa, p) : launch_bw_m<BNERV_IN_PLAIN, SP_BF16X6, 0>(st, wa, p);
 }
 
 struct Plan { int mtw, ntw, n_mgroups, n_ngroups, nsplit; };

@@ -22,19 +22,27 @@ def timeit(fn):
 rn = lambda *s: torch.randn(*s, device=dev)
 print(f"mode BNERV_SPLIT_WIDE={os.environ.get('BNERV_SPLIT_WIDE', '(default)')}")
 print(f"{'kernel':58s} {'us':>9s} {'TFLOP/s':>9s}")
-for (Ci, Co, H, W) in ((38, 38, 1080, 1920), (46, 46, 540, 960), (55, 55, 270, 480), (95, 95, 135, 240), (22, 22, 1080, 1920), (16, 48, 540, 960), (64, 16, 540, 960)):
+CASES = ((38, 38, 1080, 1920, 1), (46, 46, 540, 960, 1), (55, 55, 270, 480, 1), (95, 95, 135, 240, 1), (22, 22, 1080, 1920, 1), (16, 48, 540, 960, 1),
+         (64, 16, 540, 960, 1), (46, 152, 540, 960, 2), (55, 184, 270, 480, 2), (12, 48, 360, 640, 2))
+for (Ci, Co, H, W, gs) in CASES:
     B = 1
-    x, g = rn(B, Ci, H, W), rn(B, Co, H, W)
+    x = rn(B, Ci, H, W)
+    gsh = rn(B, Co // (gs * gs), gs * H, gs * W)          # what the kernel reads (the pixel-shuffled gradient for the up-convs)
+    g = torch.nn.functional.pixel_unshuffle(gsh, gs) if gs > 1 else gsh
     sc, sh = rn(B, Ci) * 0.1, rn(B, Ci) * 0.1
     dw, db = torch.empty(Co, Ci, 3, 3, device=dev), torch.empty(Co, device=dev)
-    kw = dict(B=B, Cin=Ci, Cout=Co, H=H, W=W, k=3, g_mode=L.IN_UNSHUFFLE)
+    kw = dict(B=B, Cin=Ci, Cout=Co, H=H, W=W, k=3, g_mode=L.IN_UNSHUFFLE, g_s=gs)
     fl = 2.0 * Ci * Co * 9 * H * W
     for name, fn in {
-        "wgrad plain": lambda: ops._wgrad(x, g, dw, db, in_mode=L.IN_PLAIN, **kw),
-        "wgrad affine": lambda: ops._wgrad(x, g, dw, db, in_mode=L.IN_AFFINE, scale=sc, shift=sh, **kw),
+        "wgrad plain": lambda: ops._wgrad(x, gsh, dw, db, in_mode=L.IN_PLAIN, **kw),
+        "wgrad affine": lambda: ops._wgrad(x, gsh, dw, db, in_mode=L.IN_AFFINE, scale=sc, shift=sh, **kw),
     }.items():
+        if gs > 1 and "affine" in name:
+            continue
         t = timeit(fn)
-        print(f"{name + f' {Ci}->{Co} @{H}x{W}':58s} {t:9.1f} {fl / t / 1e6:9.2f}")
+        print(f"{name + f' {Ci}->{Co} @{H}x{W}' + (' (shuffled g)' if gs > 1 else ''):58s} {t:9.1f} {fl / t / 1e6:9.2f}")
+    if gs > 1:
+        sc, sh = sc * 0, sh * 0
     # accuracy on the whole tensor against f64
     xa = (x * (1 + sc)[:, :, None, None] + sh[:, :, None, None]).double()
     xp = torch.nn.functional.pad(xa, (1, 1, 1, 1))
