@@ -583,27 +583,30 @@ int launch_bf(hipStream_t st, KArgs& ka) {
 constexpr int AFF_MAX = 128;
 
 template <int NS>
-__global__ __launch_bounds__(256) void bf_wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ frag, int wCo, int wCi, int transposed,
-                                                       int Cin, int Cout, int nck, int ntb) {
-    // element i of the OIHW array -> 16-bit slot of fragment (group, chunk, tile, step, piece, lane (q, n), k e)
-    const int nw = wCo * wCi * 9;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nw; i += gridDim.x * 256) {
-        const int pair = i / 9, t = i - pair * 9;
-        const int wa_ = pair / wCi, wb_ = pair - wa_ * wCi;
-        const int co = transposed ? wb_ : wa_, ci = transposed ? wa_ : wb_;
-        if (co >= Cout || ci >= Cin) continue;
-        const int tg = transposed ? 8 - t : t;
-        const int nt = co >> 4, n = co & 15, g = nt / ntb, nl = nt - g * ntb;
-        const int c = ci >> 4, cl = ci & 15;
-        const int st = tg >> 1, q = ((tg & 1) << 1) | (cl >> 3), e = cl & 7;
-        float r = w[i];
+__global__ __launch_bounds__(256) void bf_wprep_kernel(const float* __restrict__ w, u32x4* __restrict__ frag, int wCo, int wCi, int transposed,
+                                                       int Cin, int Cout, int nck, int ntb, int nfrag) {
+    // one thread per 16-B fragment slot-lane (group, chunk, tile, step, lane (q, n)): gathers its 8 k-elements from the OIHW array,
+    // splits them and writes the NS pieces -- every slot is written (zeros where the layer has no channel / tap), so the scratch
+    // needs no clearing pass
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < nfrag; f += gridDim.x * 256) {
+        const int lane = f & 63, rest = f >> 6;
+        const int st = rest % 5, r2 = rest / 5;
+        const int nl = r2 % ntb, gc = r2 / ntb;
+        const int c = gc % nck, g = gc / nck;
+        const int n = lane & 15, q = lane >> 4;
+        const int co = (g * ntb + nl) * 16 + n, tg = 2 * st + (q >> 1), ci0 = 16 * c + 8 * (q & 1);
+        float x[8];
 #pragma unroll
-        for (int p = 0; p < NS; ++p) {
-            const __bf16 hv = (__bf16)r;
-            const size_t slot = ((((size_t)(g * nck + c) * ntb + nl) * 5 + st) * NS + p) * 64 + q * 16 + n;
-            frag[slot * 8 + e] = __builtin_bit_cast(unsigned short, hv);
-            r -= (float)hv;
+        for (int e = 0; e < 8; ++e) {
+            const int ci = ci0 + e;
+            float v = 0.f;
+            if (co < Cout && ci < Cin && tg < 9) v = transposed ? w[((size_t)ci * wCi + co) * 9 + (8 - tg)] : w[((size_t)co * wCi + ci) * 9 + tg];
+            x[e] = v;
         }
+        u32x4 pc[NS];
+        split8<NS == 3 ? SP_BF16X6 : SP_BF16X3, 8>(x, pc);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) frag[((size_t)rest * NS + p) * 64 + lane] = pc[p];
     }
 }
 
@@ -1018,10 +1021,9 @@ int launch_bfw(hipStream_t st, KArgs& ka) {
     const size_t slots = (size_t)ngroups * nck * NTB * BG::STEPS * NS * 64;
     void* scratch = bnerv_ctx_scratch(d.ctx, slots * 16, st);
     if (!scratch) return -1;                               // no context, or it would have to grow inside a graph capture: f32 kernels
-    if (hipMemsetAsync(scratch, 0, slots * 16, st) != hipSuccess) return bnerv_set_error(BNERV_E_LAUNCH, "conv_bfw: memset failed");
-    const int nw = d.wCo * d.wCi * 9;
-    hipLaunchKernelGGL(bf_wprep_kernel<NS>, dim3(cdiv(nw, 256) > 512 ? 512 : cdiv(nw, 256)), dim3(256), 0, st, d.w, reinterpret_cast<unsigned short*>(scratch),
-                       d.wCo, d.wCi, d.transposed, d.Cin, d.Cout, nck, NTB);
+    const int nfrag = ngroups * nck * NTB * BG::STEPS * 64;
+    hipLaunchKernelGGL(bf_wprep_kernel<NS>, dim3(cdiv(nfrag, 256)), dim3(256), 0, st, d.w, reinterpret_cast<u32x4*>(scratch),
+                       d.wCo, d.wCi, d.transposed, d.Cin, d.Cout, nck, NTB, nfrag);
     BNERV_LAUNCH_CHECK("bf_wprep");
     ka.total_items = ngroups * d.B * ka.tiles_x * ka.tiles_y;
     ka.magic_tiles = div_magic(ka.tiles_x * ka.tiles_y);
