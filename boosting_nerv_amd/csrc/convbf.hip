@@ -1110,7 +1110,7 @@ int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec) {
     if (wide_mode() < 0 || d.k != 3 || !d.ctx) return -1;
     const bool affine = d.in_mode == BNERV_IN_AFFINE || d.in_mode == BNERV_IN_GELU_AFFINE;
     if (affine && d.Cin > AFF_MAX) return -1;
-    int min_tiles = 64;                                    // (measured: 64 beats 256 on C3 / C4 and 16 loses on C1; below it the f32 kernels' split policies win)
+    int min_tiles = 16;                                    // (measured on C1 / C3 / C4: 16 >= 32 >= 64 >= 256; below it the f32 kernels' split policies win)
     if (const char* e = getenv("BNERV_SPLIT_WIDE_MIN_TILES")) min_tiles = atoi(e);     // tests lower it to reach the kernel with small shapes
     if (d.B * ka.tiles_x * ka.tiles_y < min_tiles) return -1;
     return launch_wide_mode(st, ka);

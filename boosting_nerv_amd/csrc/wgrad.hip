@@ -1498,7 +1498,7 @@ static bool bw_ok(const WArgs& wa) {
     if (d.in_mode != BNERV_IN_PLAIN && d.in_mode != BNERV_IN_AFFINE) return false;
     if (d.g_s == 2 && d.in_mode != BNERV_IN_PLAIN) return false;
     if (d.Cout <= 16 && d.Cin <= 12) return false;         // (one cout tile, few columns: the lean f32 kernel's shapes)
-    int min_tiles = 64;
+    int min_tiles = 16;
     if (const char* e = getenv("BNERV_SPLIT_WIDE_MIN_TILES")) min_tiles = atoi(e);
     if (d.B * cdiv(d.H, TH) * cdiv(d.W, TW) < min_tiles) return false;
     const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
