@@ -688,7 +688,6 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
     }
 
     f32x4 ra[8];
-    u32x4 rb[NWB];
     int ra_valid = 0;                                      // channels of this thread's half that the loaded chunk really has
     auto issue = [&](const WItem& a, int c) __attribute__((always_inline)) {
         const int ty0 = a.ty * TH, tx0 = a.tx * TW;
@@ -716,12 +715,6 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
                 else ra[e] = f32x4{0.f, 0.f, 0.f, 0.f};
                 sb += hw4;
             }
-        }
-        const u32x4* src = wfrag + (size_t)(a.g * nck + c) * SB_SLOTS;
-#pragma unroll
-        for (int k = 0; k < NWB; ++k) {
-            const int i = tid + k * 256;
-            rb[k] = i < SB_SLOTS ? src[i] : u32x4{0u, 0u, 0u, 0u};
         }
     };
     auto commit = [&](const WItem& a, int c) __attribute__((always_inline)) {
@@ -753,6 +746,15 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
                     for (int p = 0; p < NS; ++p) *reinterpret_cast<u32x4*>(s_a + p * BG::PIECE + w_addr[j]) = pc[p];
                 }
             }
+        }
+        // B fragments of the stage: global (L2-resident, shared by every block) -> LDS here, after barrier (B).  Prefetching them
+        // through registers under the MFMA phase was measured no faster, and its 48 VGPRs are worth more to the fragment pipeline.
+        const u32x4* src = wfrag + (size_t)(a.g * nck + c) * SB_SLOTS;
+        u32x4 rb[NWB];
+#pragma unroll
+        for (int k = 0; k < NWB; ++k) {
+            const int i = tid + k * 256;
+            rb[k] = i < SB_SLOTS ? src[i] : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int k = 0; k < NWB; ++k) {
@@ -817,32 +819,50 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
             lds_barrier();                                 // (A) this stage's s_a / s_b (and s_red of the previous item) visible
             if (more) issue(last_chunk ? nxt : it, last_chunk ? 0 : c + 1);
             if constexpr (RED) { if (c == 0 && have_prev) flush_partials(prev); }
-#pragma unroll
-            for (int s = 0; s < BG::STEPS; ++s) {
-                u32x4 bfr[NTB][NS];
-#pragma unroll
-                for (int n = 0; n < NTB; ++n)
-#pragma unroll
-                    for (int p = 0; p < NS; ++p) bfr[n][p] = *reinterpret_cast<const u32x4*>(s_b + ((n * BG::STEPS + s) * NS + p) * 1024 + b_addr);
-#pragma unroll
-                for (int m0 = 0; m0 < 4; m0 += 2) {
-                    u32x4 afr[2][NS];
+            {
+                // Fragment pipeline.  Phase = (K step, pair of M tiles), ten per stage.  A fragments of the next phase are read (second
+                // register set) before this phase's products are issued.  B fragments are shared by the two phases of a step and stay
+                // single-buffered: the products are ordered by the B piece they read (pieces 2, 1, 0), and in the step's second phase
+                // each piece of the NEXT step is read as soon as the last product using the old one is issued -- by the time the next
+                // phase reaches that piece it has been in flight for a dozen MFMAs.  (Order of the six products inside a step does not
+                // matter numerically: the accumulator already holds the earlier steps.)
+                u32x4 afr[2][2][NS], bfr[NTB][NS];
+                auto load_a = [&](int ph, int buf) __attribute__((always_inline)) {
+                    const int s = ph >> 1, m0 = (ph & 1) * 2;
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
                         for (int p = 0; p < NS; ++p)
-                            afr[m][p] = *reinterpret_cast<const u32x4*>(s_a + p * BG::PIECE + a_addr[s][(m0 + m) & 1] + ((m0 + m) >> 1) * (BG::SPR * 16));
+                            afr[buf][m][p] = *reinterpret_cast<const u32x4*>(s_a + p * BG::PIECE + a_addr[s][(m0 + m) & 1] + ((m0 + m) >> 1) * (BG::SPR * 16));
+                };
+                auto load_b = [&](int s, int p) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int n = 0; n < NTB; ++n) bfr[n][p] = *reinterpret_cast<const u32x4*>(s_b + ((n * BG::STEPS + s) * NS + p) * 1024 + b_addr);
+                };
+#pragma unroll
+                for (int p = NS - 1; p >= 0; --p) load_b(0, p);
+                load_a(0, 0);
+#pragma unroll
+                for (int ph = 0; ph < 2 * BG::STEPS; ++ph) {
+                    const int s = ph >> 1, m0 = (ph & 1) * 2;
+                    const bool reload = (ph & 1) && s + 1 < BG::STEPS;
+                    if (ph + 1 < 2 * BG::STEPS) load_a(ph + 1, (ph + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #define BNERV_BF_PROD(pa, pb) _Pragma("unroll") for (int n = 0; n < NTB; ++n) _Pragma("unroll") for (int m = 0; m < 2; ++m) \
-                        acc[m0 + m][n] = mfma16<SP>(afr[m][pa], bfr[n][pb], acc[m0 + m][n]);
+                        acc[m0 + m][n] = mfma16<SP>(afr[ph & 1][m][pa], bfr[n][pb], acc[m0 + m][n]);
                     if constexpr (NS == 3) {
-                        BNERV_BF_PROD(2, 0)
                         BNERV_BF_PROD(0, 2)
+                        if (reload) { load_b(s + 1, 2); __builtin_amdgcn_sched_barrier(0); }
                         BNERV_BF_PROD(1, 1)
                     }
-                    BNERV_BF_PROD(1, 0)
                     BNERV_BF_PROD(0, 1)
+                    if (reload) { load_b(s + 1, 1); __builtin_amdgcn_sched_barrier(0); }
+                    if constexpr (NS == 3) { BNERV_BF_PROD(2, 0) }
+                    BNERV_BF_PROD(1, 0)
                     BNERV_BF_PROD(0, 0)
 #undef BNERV_BF_PROD
+                    if (reload) load_b(s + 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             lds_barrier();                                 // (B) every wave is done reading this stage
