@@ -58,6 +58,7 @@ RECIPES = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA peak (no sparsity)
 
 
 def build(cfg_name):
@@ -159,7 +160,19 @@ def step_kernel_roofline(dev, Cc, H, W, reps=20):
             break
         except (OSError, KeyError, ValueError):
             continue
-    return {"kernel": f"final-stage conv family of the step ({Cc}->{Cc} 3x3 @{H}x{W}): flop-weighted over the 14 launches below", "bound": "mfma",
+    try:                                                     # the wide split kernel's PMC figure (38 -> 38 @1080x1920)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic_wide.json")))
+        if (Cc, H, W) == tuple(tj["shape"]):
+            traffic, traffic_src = float(tj["hbm_bytes_per_launch"]), tj["source"] + " [" + tj["kernel"] + "]"
+    except (OSError, KeyError, ValueError):
+        pass
+    pipe = None
+    if Cc > 16:
+        # these layers run on the 16-bit matrix pipe, six bf16 products per f32 product: the hardware roof of THAT instruction mix in
+        # f32-equivalent flops is the dense bf16 peak / 6; `peak` / `frac` stay priced against the fp32 MFMA peak of the arithmetic type
+        pipe = {"instruction": "v_mfma_f32_16x16x32_bf16, 6 products per f32 product (bf16x6)", "peak": round(PEAK_BF16_MFMA_TFLOPS / 6, 1),
+                "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS / 6), 4), "unit": "TFLOP/s (f32-equivalent)"}
+    return {"kernel": f"final-stage conv family of the step ({Cc}->{Cc} 3x3 @{H}x{W}): flop-weighted over the 14 launches below", "bound": "mfma", "split_pipe": pipe,
             "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
             "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
             "avg_launch_us": round(tt / 14 * 1e6, 2), "flops_per_launch": flops, "bytes_per_launch": k2s["bytes_per_launch"],
@@ -354,7 +367,8 @@ def main():
                # THREE bf16 pieces per fp32 operand and six partial products accumulated in fp32 -- measured error 7.9e-8 * sum|a b|,
                # below the 1.3e-7 of the f32 MFMA's own k-ordered chain (profiles/r02_split_kernels.md); BNERV_SPLIT_WIDE=off keeps
                # them on v_mfma_f32_16x16x4_f32
-               "arithmetic": "fp32 storage / accumulation; wide convs: exact 3-piece bf16 split products (bf16x6) on v_mfma_f32_16x16x32_bf16" if a.config != "c1" else "fp32 (v_mfma_f32_16x16x4_f32 convs); the 30-channel 45x80 stage is below the wide kernel's tile threshold",
+               "arithmetic": "fp32 storage / accumulation; layers with more than 16 channels (convs, data and weight gradients): exact 3-piece bf16 split products (bf16x6, error below the f32 MFMA's own) on v_mfma_f32_16x16x32_bf16"
+               if a.config != "c1" else "fp32 (v_mfma_f32_16x16x4_f32) for the 12-channel layers; the 12->48 up-convs and the 30-channel stage: exact bf16x6 split products on v_mfma_f32_16x16x32_bf16",
                "config": {"workload": f"{r['name']} ({n_params} params, fc_dim {args.fc_dim}) train step on a synthetic "
                                       f"{'Bunny' if a.config == 'c1' else 'UVG'}-shaped clip {r['n']}x3x{r['h']}x{r['w']}: "
                                       f"{'quantise + rate term (CEM) + ' if a.config == 'c5' else ''}decoder fwd + {args.loss} + bwd + "

@@ -28,4 +28,11 @@ for m in bf16x6 f16x3 bf16x3; do BNERV_SPLIT=$m python $R/tools/kbench.py 30 2>/
 BNERV_SPLIT=bf16x6 $R/tools/pmc_bf.sh conv conv_bf_kernel $O/e2_pmc_bf16x6.txt
 $R/tools/ubench/mfma_interleave > $O/e2_ub_interleave.txt 2>&1
 $R/tools/ubench/bf16_split > $O/e2_ub_bf16split.txt 2>&1
+# wide split kernels (default on): conv and weight gradient at the C3 / C4 shapes against the f32 kernels, and their PMC passes
+python $R/tools/kwide2.py 20 > $O/e2_kwide_on.txt 2>&1
+BNERV_SPLIT_WIDE=off python $R/tools/kwide2.py 20 > $O/e2_kwide_off.txt 2>&1
+python $R/tools/kwgrad2.py 20 > $O/e2_kwgrad_on.txt 2>&1
+BNERV_SPLIT_WIDE=off python $R/tools/kwgrad2.py 20 > $O/e2_kwgrad_off.txt 2>&1
+$R/tools/pmc_bf.sh conv38_k2s conv_bfw_kernel $O/e2_pmc_bfw.txt
+$R/tools/pmc_bf.sh wgrad38 wgrad_bfw_kernel $O/e2_pmc_wbfw.txt
 echo done

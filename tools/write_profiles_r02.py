@@ -69,5 +69,38 @@ open(P + "split_kernels.md", "w").write(
     + "\n```\n\n## PMC of conv_bf_kernel<3,IN_AFFINE,EP_BIAS,bf16x6> (12->12 @720x1280)\n\n```\n" + rd("pmc_bf16x6.txt")
     + "```\n\n## tools/ubench/mfma_interleave: VALU work beside the f32 MFMA (16x16x4) -- interleaved in the wave or phased, 1 / 2 / 4 waves per SIMD\n\n```\n" + rd("ub_interleave.txt")
     + "```\n\n## tools/ubench/bf16_split: VALU beside the bf16 MFMA (16x16x32), and accuracy of split products against fp64\n\n```\n" + rd("ub_bf16split.txt") + "```\n")
+# wide split kernels: micro-benchmarks against the f32 kernels + PMC of both
+def two_col(on, off):
+    rows = []
+    offs = {l[:58].strip(): l for l in off.splitlines() if "@" in l}
+    for l in on.splitlines():
+        if "@" not in l:
+            continue
+        key = l[:58].strip()
+        o = offs.get(key)
+        rows.append(f"{key:58s} {l[58:].rstrip():>20s}   | f32 kernel {o[58:].rstrip() if o else '':>20s}")
+    return "\n".join(rows)
+
+
+acc = "\n".join(l for l in rd("kwgrad_on.txt").splitlines() if "max |dw" in l)
+cb, wb = counters(rd("pmc_bfw.txt")), counters(rd("pmc_wbfw.txt"))
+busy = lambda k: 100 * k.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(k.get("GRBM_GUI_ACTIVE", 1) / 8 * 1024, 1)
+json.dump({"kernel": "conv_bfw_kernel<IN_AFFINE,EP_BIAS_GELU,bf16x6,3> (K2s: TAT conv0 forward) 38->38 3x3 @1080x1920", "shape": [38, 1080, 1920], "fetch_size_kb": cb.get("FETCH_SIZE", 0),
+           "fetch_correction": 2, "write_size_kb": cb.get("WRITE_SIZE", 0), "hbm_bytes_per_launch": (2 * cb.get("FETCH_SIZE", 0) + cb.get("WRITE_SIZE", 0)) * 1024,
+           "algorithmic_bytes_per_launch": 945613584, "source": "profiles/r02_wide_kernels.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction)"},
+          open(P + "traffic_wide.json", "w"), indent=1)
+open(P + "wide_kernels.md", "w").write(
+    "# Round 2 -- the wide split 16-bit kernels (default on): conv_bfw_kernel (csrc/convbf.hip) and wgrad_bfw_kernel (csrc/wgrad.hip), MI355X\n\n"
+    "bf16x6: every f32 operand as three bf16 pieces, six products per MFMA pair on v_mfma_f32_16x16x32_bf16, f32 accumulation.  Columns: us and "
+    "f32-equivalent TFLOP/s (2 x Cin x Cout x 9 x H x W / t) through the C-ABI (HIP events), default build | BNERV_SPLIT_WIDE=off (the f32 MFMA kernels).\n\n"
+    "## convolutions, forward and data gradient (tools/kwide2.py 20)\n\n```\n" + two_col(rd("kwide_on.txt"), rd("kwide_off.txt")) +
+    "\n```\n\n## weight gradients, plain / affine prologue / shuffled (up-conv) gradient (tools/kwgrad2.py 20)\n\n```\n" + two_col(rd("kwgrad_on.txt"), rd("kwgrad_off.txt")) +
+    "\n```\n\nAccuracy of the split weight gradient against an f64 torch reference on the full tensors (max |dw - ref| / sum |x||g|, same order as above):\n\n```\n" + acc +
+    f"\n```\n\n## PMC (tools/pmc_bf.sh conv38_k2s / wgrad38; 38->38 3x3 @1080x1920, chip-wide sums per dispatch)\n\n"
+    f"conv_bfw (K2s: affine -> conv -> bias -> gelu, gelu'): matrix pipe {busy(cb):.0f} % busy; per launch HBM {mb(2 * cb.get('FETCH_SIZE', 0) + cb.get('WRITE_SIZE', 0)):.0f} MB "
+    f"(FETCH_SIZE x2 + WRITE_SIZE) against 945.6 MB algorithmic; LDS bank-conflict cycles {100 * cb.get('SQ_LDS_BANK_CONFLICT', 0) / max(cb.get('SQ_LDS_IDX_ACTIVE', 1), 1):.0f} % of LDS-active.\n"
+    f"wgrad_bfw (plain): matrix pipe {busy(wb):.0f} % busy; HBM {mb(2 * wb.get('FETCH_SIZE', 0) + wb.get('WRITE_SIZE', 0)):.0f} MB against 630.4 MB algorithmic (x and g once); "
+    f"LDS bank-conflict cycles {100 * wb.get('SQ_LDS_BANK_CONFLICT', 0) / max(wb.get('SQ_LDS_IDX_ACTIVE', 1), 1):.0f} % of LDS-active; "
+    f"{(wb.get('SQ_INSTS_VALU', 0) - wb.get('SQ_INSTS_MFMA', 0)) / max(wb.get('SQ_INSTS_MFMA', 1), 1):.2f} other VALU per MFMA.\n\n```\n" + rd("pmc_bfw.txt") + "\n" + rd("pmc_wbfw.txt") + "```\n")
 for c in ("c1", "c3", "c4", "c5"):
     print(c, b[c]["value"], b[c]["ms_per_step"], b[c]["roofline"]["achieved"], (b[c].get("cpu_baseline") or {}).get("value"))
