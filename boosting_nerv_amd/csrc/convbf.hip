@@ -1068,7 +1068,11 @@ int launch_bfw(hipStream_t st, KArgs& ka) {
 template <int IN, int EP, int SP, bool PS2 = false>
 int launch_bfw_ntb(hipStream_t st, KArgs& ka) {
     const int nt = cdiv(ka.d.Cout, 16);
-    const int ntb = nt <= 3 ? nt : (nt == 4 ? 2 : 3);
+    int ntb = nt <= 3 ? nt : (nt == 4 ? 2 : 3);
+    // low-resolution stages: fewer cout tiles per block while the work items would leave half the chip idle (each group re-stages the
+    // input tile, but on CUs that had nothing to do: the launch is as long as ONE block's chain of stages)
+    const int tiles = ka.d.B * ka.tiles_x * ka.tiles_y;
+    while (ntb > 1 && cdiv(nt, ntb) * tiles < 128) --ntb;
     if (ntb == 1) return launch_bfw<IN, EP, SP, 1, PS2>(st, ka);
     if (ntb == 2) return launch_bfw<IN, EP, SP, 2, PS2>(st, ka);
     return launch_bfw<IN, EP, SP, 3, PS2>(st, ka);
