@@ -1072,7 +1072,9 @@ int launch_bfw_ntb(hipStream_t st, KArgs& ka) {
     // low-resolution stages: fewer cout tiles per block while the work items would leave half the chip idle (each group re-stages the
     // input tile, but on CUs that had nothing to do: the launch is as long as ONE block's chain of stages)
     const int tiles = ka.d.B * ka.tiles_x * ka.tiles_y;
-    while (ntb > 1 && cdiv(nt, ntb) * tiles < 128) --ntb;
+    int min_items = 128;
+    if (const char* e = getenv("BNERV_SPLIT_WIDE_MIN_ITEMS")) min_items = atoi(e);     // tests set 1 to keep the widest blocks on small shapes
+    while (ntb > 1 && cdiv(nt, ntb) * tiles < min_items) --ntb;
     if (ntb == 1) return launch_bfw<IN, EP, SP, 1, PS2>(st, ka);
     if (ntb == 2) return launch_bfw<IN, EP, SP, 2, PS2>(st, ka);
     return launch_bfw<IN, EP, SP, 3, PS2>(st, ka);

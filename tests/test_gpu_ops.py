@@ -560,12 +560,14 @@ def test_dense_gemm_shapes(ops):
             close(a, r, msg=f"gemm d{n} {B}x{I}x{O}")
 
 
-@pytest.mark.parametrize("shape", [(1, 38, 24, 64), (2, 55, 17, 36), (1, 95, 10, 44), (2, 22, 9, 40), (1, 30, 16, 32)])
-def test_wide_split_conv_kernel_tat_block(ops, shape, monkeypatch):
+@pytest.mark.parametrize("min_items", ["1", "128"])          # 1: up to 3 cout tiles per block; 128 (default): small shapes split to 1
+@pytest.mark.parametrize("shape", [(1, 38, 24, 64), (2, 55, 17, 36), (1, 95, 10, 44), (2, 22, 9, 40), (1, 30, 16, 32), (2, 38, 21, 100)])   # (the last: interior tiles)
+def test_wide_split_conv_kernel_tat_block(ops, shape, min_items, monkeypatch):
     """The wide split-16-bit conv kernel (csrc/convbf.hip conv_bfw_kernel: several cout tiles / K chunks per staged input tile,
     bf16x6 products with f32 accumulation) on the TAT block -- its four launches cover the affine -> gelu-pair, affine -> residual,
     dGELU-saved and dSIN modes -- against the oracle, with the tile-count threshold lowered so that small shapes reach it."""
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_ITEMS", min_items)
     x0, mods, w0, b0, w1, b1, g = _tat_inputs(*shape, seed=7)
     ref = _tat_ref(x0, mods, w0, b0, w1, b1)
     cot = torch.randn(ref.shape, generator=g)
@@ -578,11 +580,13 @@ def test_wide_split_conv_kernel_tat_block(ops, shape, monkeypatch):
         close(a, r, msg=f"wide tat d{n}")
 
 
-@pytest.mark.parametrize("case", [(1, 38, 38, 24, 64), (1, 70, 18, 8, 32), (2, 55, 55, 17, 36), (1, 20, 95, 9, 32), (1, 95, 12, 16, 32)])
-def test_wide_split_conv_kernel_plain(ops, case, monkeypatch):
+@pytest.mark.parametrize("min_items", ["1", "128"])
+@pytest.mark.parametrize("case", [(1, 38, 38, 24, 64), (1, 70, 18, 8, 32), (2, 55, 55, 17, 36), (1, 20, 95, 9, 32), (1, 95, 12, 16, 32), (2, 46, 64, 22, 132)])
+def test_wide_split_conv_kernel_plain(ops, case, min_items, monkeypatch):
     """Same kernel through conv2d_ps (plain -> bias forward, plain data gradient) and the sin block conv, incl. Cout <= 16 with several
     K chunks and Cin <= 16 with several cout tiles."""
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_ITEMS", min_items)
     B, Cin, Ct, H, W = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(B, Cin, H, W, generator=g).requires_grad_(True)
@@ -598,11 +602,13 @@ def test_wide_split_conv_kernel_plain(ops, case, monkeypatch):
         close(a, r, msg=f"wide conv d{n}")
 
 
-@pytest.mark.parametrize("case", [(1, 12, 48, 16, 32), (2, 38, 152, 9, 32), (1, 20, 36, 17, 40), (1, 46, 184, 8, 32)])
-def test_wide_split_conv_kernel_upconv_ps2(ops, case, monkeypatch):
+@pytest.mark.parametrize("min_items", ["1", "128"])
+@pytest.mark.parametrize("case", [(1, 12, 48, 16, 32), (2, 38, 152, 9, 32), (1, 20, 36, 17, 40), (1, 46, 184, 8, 32), (1, 22, 88, 14, 100)])
+def test_wide_split_conv_kernel_upconv_ps2(ops, case, min_items, monkeypatch):
     """Up-conv + PixelShuffle(2) through the wide split kernel: forward with the pair-up epilogue (plain and sin/cos), data gradient
     through the unshuffle(2) prologue; whole SNeRV block as well (its up-conv, TAT convs and every gradient)."""
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_ITEMS", min_items)
     B, Cin, Ct, H, W = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(B, Cin, H, W, generator=g).requires_grad_(True)
