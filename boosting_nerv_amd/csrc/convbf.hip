@@ -580,7 +580,7 @@ int launch_bf(hipStream_t st, KArgs& ka) {
 //     chunks do not fit LDS and splitting them again per (tile, chunk) would cost as much as the chunk's MFMAs;
 //   * channels beyond Cin inside the last chunk are never loaded: their A slots keep finite stale data and meet zero weights.
 // Modes: bf16x6 (default when enabled) and bf16x3; the scaled f16 mode is not built for this kernel.
-constexpr int AFF_MAX = 128;
+constexpr int AFF_MAX = 512;                                // affine table: 2 x (Cin rounded up to 16) floats of LDS, sized per layer
 
 template <int NS>
 __global__ __launch_bounds__(256) void bf_wprep_kernel(const float* __restrict__ w, u32x4* __restrict__ frag, int wCo, int wCi, int transposed,
@@ -632,7 +632,8 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
     char* s_a = reinterpret_cast<char*>(smem);
     char* s_b = s_a + NS * BG::PIECE;
     float* s_red = reinterpret_cast<float*>(s_b + SB_SLOTS * 16);  // [4 waves][2][NTB * 16]
-    float* s_aff = s_red + 4 * 2 * NTB * 16;                       // [2][AFF_MAX]
+    float* s_aff = s_red + 4 * 2 * NTB * 16;                       // [2][aff_n]
+    const int aff_n = (ka.d.Cin + 15) & ~15;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
             for (int e = 0; e < 8; ++e) {
                 const int ci = 16 * c + 8 * s_h + e;
                 const bool on = AFF && inside && e < ra_valid;
-                const float sc = on ? s_aff[ci & (AFF_MAX - 1)] : 0.f, sh = on ? s_aff[AFF_MAX + (ci & (AFF_MAX - 1))] : 0.f;
+                const float sc = on ? s_aff[ci] : 0.f, sh = on ? s_aff[aff_n + ci] : 0.f;      // (ci < aff_n: chunks cover Cin rounded up to 16)
                 ra[e].x = xform1<IN>(ra[e].x, sc, sh, 0.f);
                 ra[e].y = xform1<IN>(ra[e].y, sc, sh, 0.f);
                 ra[e].z = xform1<IN>(ra[e].z, sc, sh, 0.f);
@@ -762,11 +763,11 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
             if (i < SB_SLOTS) reinterpret_cast<u32x4*>(s_b)[i] = rb[k];
         }
     };
-    auto load_affine = [&](int b) __attribute__((always_inline)) {                 // s_aff[c] = 1 + scale[b][c], s_aff[AFF_MAX + c] = shift[b][c]
-        for (int i = tid; i < 2 * AFF_MAX; i += 256) {
-            const int c = i & (AFF_MAX - 1);
+    auto load_affine = [&](int b) __attribute__((always_inline)) {                 // s_aff[c] = 1 + scale[b][c], s_aff[aff_n + c] = shift[b][c]
+        for (int i = tid; i < 2 * aff_n; i += 256) {
+            const int c = i < aff_n ? i : i - aff_n;
             float v = 0.f;
-            if (c < Cin) v = i < AFF_MAX ? 1.0f + d.scale[b * Cin + c] : d.shift[b * Cin + c];
+            if (c < Cin) v = i < aff_n ? 1.0f + d.scale[b * Cin + c] : d.shift[b * Cin + c];
             s_aff[i] = v;
         }
     };
@@ -1048,13 +1049,19 @@ int launch_bfw(hipStream_t st, KArgs& ka) {
     ka.total_items = ngroups * d.B * ka.tiles_x * ka.tiles_y;
     ka.magic_tiles = div_magic(ka.tiles_x * ka.tiles_y);
     ka.magic_tiles_x = div_magic(ka.tiles_x);
-    const size_t lds = (size_t)NS * BG::PIECE + (size_t)NTB * BG::STEPS * NS * 1024 + (size_t)(4 * 2 * NTB * 16 + 2 * AFF_MAX) * sizeof(float);
+    const size_t lds = (size_t)NS * BG::PIECE + (size_t)NTB * BG::STEPS * NS * 1024 + (size_t)(4 * 2 * NTB * 16 + 2 * ((d.Cin + 15) & ~15)) * sizeof(float);
+    // LDS depends on the layer through the affine table (2 x Cin floats): occupancy is looked up per distinct size
+    static size_t attr_lds = 0, occ_lds = 0;
     static int blocks_per_cu = 0;
-    if (blocks_per_cu == 0) {
+    if (lds > attr_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bfw_kernel<IN, EP, SP, NTB, PS2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    if (lds != occ_lds) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_bfw_kernel<IN, EP, SP, NTB, PS2>), 256, lds) != hipSuccess || nb < 1) nb = 1;
         blocks_per_cu = nb > 2 ? 2 : nb;
+        occ_lds = lds;
     }
     int grid = 256 * blocks_per_cu;
     if (grid > ka.total_items) grid = ka.total_items;

@@ -561,7 +561,7 @@ def test_dense_gemm_shapes(ops):
 
 
 @pytest.mark.parametrize("min_items", ["1", "128"])          # 1: up to 3 cout tiles per block; 128 (default): small shapes split to 1
-@pytest.mark.parametrize("shape", [(1, 38, 24, 64), (2, 55, 17, 36), (1, 95, 10, 44), (2, 22, 9, 40), (1, 30, 16, 32), (2, 38, 21, 100)])   # (the last: interior tiles)
+@pytest.mark.parametrize("shape", [(1, 38, 24, 64), (2, 55, 17, 36), (1, 95, 10, 44), (2, 22, 9, 40), (1, 30, 16, 32), (2, 38, 21, 100), (1, 177, 10, 36)])   # (interior tiles; C4's 177-channel stage)
 def test_wide_split_conv_kernel_tat_block(ops, shape, min_items, monkeypatch):
     """The wide split-16-bit conv kernel (csrc/convbf.hip conv_bfw_kernel: several cout tiles / K chunks per staged input tile,
     bf16x6 products with f32 accumulation) on the TAT block -- its four launches cover the affine -> gelu-pair, affine -> residual,
