@@ -121,6 +121,7 @@ SYMBOLS = {
     "bnerv_dense_gemm_bwd": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _Z, _I, _I, _I, _I]),
     "bnerv_cnx_mlp_fwd": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I]),
     "bnerv_cnx_mlp_bwd": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I]),
+    "bnerv_cnx_param_grads": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I]),
     "bnerv_ans_encode_gaussian": (C.c_long, [_V, _Z, _I, _I, C.c_double, C.c_double, _V, _Z]),
     "bnerv_ans_decode_gaussian": (_I, [_V, _Z, _Z, _I, _I, C.c_double, C.c_double, _V]),
     "bnerv_ans_encode_categorical": (C.c_long, [_V, _Z, _V, _I, _V, _Z]),

@@ -570,16 +570,20 @@ int launch_bf(hipStream_t st, KArgs& ka) {
 
 // ---------------------------------------------------------------------------------------------------------------- wide split kernel
 // The same split core for the layers with MORE than 16 input or output channels (3x3, stride-1 output: the TAT convolutions,
-// stride-1 block convs and every data gradient of the 22..95-channel stages of C3 / C4 -- conv.hip's lean2 scope without the
-// unshuffle / tanh-grad prologues).  Here the staged input tile of one 16-channel K chunk feeds NTB cout tiles, so the staging work
-// that sets the pace of the one-tile kernel above is amortised over NTB times the matrix work -- this is where the 16-bit pipe pays.
-//   * work item = (cout group of NTB tiles, sample, 8x32 tile); pipeline stage = (item, K chunk): the loads of the next stage --
-//     the input chunk AND its B fragments -- fly in registers under the MFMA phase of the current one;
+// stride-1 block convs, PixelShuffle(2) up-convs and every data gradient of the 22..177-channel stages of C3 / C4, C1's up-convs and
+// 30-channel stage -- conv.hip's lean2 scope without the tanh-grad prologue and the x3 / x5 shuffles).  Here the staged input tile of
+// one 16-channel K chunk feeds NTB cout tiles, so the staging work that sets the pace of the one-tile kernel above is amortised over
+// NTB times the matrix work -- this is where the 16-bit pipe pays.  Default on (wide_mode()).
+//   * work item = (cout group of NTB tiles, sample, 8x32 tile); pipeline stage = (item, K chunk): the input chunk of the next stage
+//     is loaded into registers under the MFMA phase of the current one and transformed / split / written to LDS after barrier (B);
 //   * B fragments come PRE-SPLIT from a scratch buffer of the stream context (bf_wprep_kernel, one small launch per call in front
 //     of this kernel: the weight tensor -> [group][chunk][tile][step][piece][lane] 16-B fragments), because the fragments of all
-//     chunks do not fit LDS and splitting them again per (tile, chunk) would cost as much as the chunk's MFMAs;
+//     chunks do not fit LDS and splitting them again per (tile, chunk) would cost as much as the chunk's MFMAs; a stage copies its
+//     46 KB (NTB = 3) from there (L2-resident) to LDS after barrier (B);
+//   * the MFMA phase is a fragment pipeline (see the loop): A fragments one phase ahead, B pieces reloaded behind their last product;
+//   * NTB shrinks at the low-resolution stages so that the work items still cover the chip (launch_bfw_ntb);
 //   * channels beyond Cin inside the last chunk are never loaded: their A slots keep finite stale data and meet zero weights.
-// Modes: bf16x6 (default when enabled) and bf16x3; the scaled f16 mode is not built for this kernel.
+// Modes: bf16x6 (default) and bf16x3; the scaled f16 mode is not built for this kernel.
 constexpr int AFF_MAX = 512;                                // affine table: 2 x (Cin rounded up to 16) floats of LDS, sized per layer
 
 template <int NS>

@@ -341,6 +341,29 @@ int launch_mlp_c(hipStream_t st, const MlpArgs& a, bool bwd) {
     return bnerv_set_error(BNERV_E_ARG, "cnx_mlp: C must be 16, 32, 48 or 64 (got %d)", a.C);
 }
 
+// dw2 = gamma S, db2 = gamma t, dgamma = rowsum(w2 * S) + b2 * t for one ConvNeXt block ([C x 4C] bookkeeping after the two k = 1
+// weight-gradient launches): one block per output row c
+__global__ __launch_bounds__(256) void cnx_param_grads_kernel(const float* __restrict__ S, const float* __restrict__ t, const float* __restrict__ w2,
+                                                              const float* __restrict__ b2, const float* __restrict__ gamma, float* __restrict__ dw2,
+                                                              float* __restrict__ db2, float* __restrict__ dgamma, int C) {
+    __shared__ float s_part[4];
+    const int c = blockIdx.x, n = 4 * C;
+    const float g = gamma[c];
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const float sv = S[(size_t)c * n + j];
+        dw2[(size_t)c * n + j] = g * sv;
+        acc = fmaf(w2[(size_t)c * n + j], sv, acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dgamma[c] = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) + b2[c] * t[c];
+        db2[c] = g * t[c];
+    }
+}
+
 }  // namespace
 
 extern "C" int bnerv_dense_gemm_fwd(void* stream, const float* x, const float* w, const float* b, float* y, float* aux, int B, int I, int O, int act) {
@@ -420,4 +443,13 @@ extern "C" int bnerv_cnx_mlp_bwd(void* stream, const float* h1, const float* dou
     a.hin = h1; a.dout = dout; a.w1 = w1; a.w2 = w2; a.gamma = gamma; a.dx = dx; a.gbuf = gbuf; a.dhbuf = dhbuf;
     a.B = B; a.C = C; a.HW = HW;
     return launch_mlp_c(reinterpret_cast<hipStream_t>(stream), a, true);
+}
+
+// S [C, 4C], t [C]: what bnerv_conv_wgrad (k = 1) returns for (gelu(h1), dout); outputs dw2 [C, 4C], db2 [C], dgamma [C]
+extern "C" int bnerv_cnx_param_grads(void* stream, const float* S, const float* t, const float* w2, const float* b2, const float* gamma,
+                                     float* dw2, float* db2, float* dgamma, int C) {
+    BNERV_REQUIRE(S && t && w2 && b2 && gamma && dw2 && db2 && dgamma && C > 0, "cnx_param_grads: bad args");
+    hipLaunchKernelGGL(cnx_param_grads_kernel, dim3(C), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, t, w2, b2, gamma, dw2, db2, dgamma, C);
+    BNERV_LAUNCH_CHECK("cnx_param_grads");
+    return BNERV_OK;
 }

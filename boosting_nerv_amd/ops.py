@@ -661,9 +661,11 @@ class _CnxMlp(torch.autograd.Function):
         S = torch.empty(Cc, 4 * Cc, 1, 1, dtype=torch.float32, device=dev); t = torch.empty(Cc, dtype=torch.float32, device=dev)
         _wgrad(gbuf, dout, S, t, B=B, Cin=4 * Cc, Cout=Cc, H=H, W=W, k=1, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE)
         S = S.reshape(Cc, 4 * Cc)
-        if ctx.has_gamma:      # [C x 4C] bookkeeping: dw2 = gamma S, db2 = gamma t, dgamma = rowsum(w2 * S) + b2 t
-            dgamma = (w2 * S).sum(1) + b2 * t
-            dw2, db2 = gm[:, None] * S, gm * t
+        if ctx.has_gamma:      # [C x 4C] bookkeeping in one launch: dw2 = gamma S, db2 = gamma t, dgamma = rowsum(w2 * S) + b2 t
+            S = S.contiguous()
+            dw2, db2, dgamma = torch.empty_like(S), torch.empty_like(t), torch.empty_like(t)
+            L.check(L.load().bnerv_cnx_param_grads(L.stream(), L.ptr(S), L.ptr(t), L.ptr(w2), L.ptr(b2), L.ptr(gm), L.ptr(dw2), L.ptr(db2),
+                                                   L.ptr(dgamma), Cc), "bnerv_cnx_param_grads")
         else:
             dgamma, dw2, db2 = None, S, t
         return dx, dout, dw1.reshape(4 * Cc, Cc), db1, dw2, db2, dgamma

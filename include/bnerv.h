@@ -260,6 +260,9 @@ int bnerv_cnx_mlp_fwd(void* stream, const float* x, const float* inp, const floa
                       const float* gamma, float* out, float* hsave, int B, int C, int HW);
 int bnerv_cnx_mlp_bwd(void* stream, const float* h1, const float* dout, const float* w1, const float* w2, const float* gamma,
                       float* dx, float* gbuf, float* dhbuf, int B, int C, int HW);
+/* the [C x 4C] bookkeeping of that backward in one launch: dw2 = gamma S, db2 = gamma t, dgamma = rowsum(w2 * S) + b2 * t */
+int bnerv_cnx_param_grads(void* stream, const float* S, const float* t, const float* w2, const float* b2, const float* gamma,
+                          float* dw2, float* db2, float* dgamma, int C);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Range-ANS entropy coder of the compression report (HOST buffers; csrc/ans.cpp).  Replaces constriction's AnsCoder +

@@ -54,8 +54,11 @@ for c, name in (("c3", "HNeRV-boost 3M, 1080x1920"), ("c4", "E-NeRV-boost 3M, 10
     open(P + f"{c}_step_kerneltrace.md", "w").write(hdr(f"{c.upper()} train step ({name}); rocprofv3 --kernel-trace --stats (20+5 steps incl. graph capture warm-up), MI355X",
         f"rocprofv3 --kernel-trace --stats -d /tmp/ks_{c} -- python bench.py --config {c} --steps 20 --warmup 5 --no_cpu_baseline",
         f"Bench line of the same build (profiles/r02_bench_{c}.json): {b[c]['value']} frames/s, {b[c]['ms_per_step']} ms/step; final-stage family {b[c]['roofline']['achieved']} TF "
-        f"({100 * b[c]['roofline']['frac']:.1f} %); CPU oracle {b[c]['cpu_baseline']['value']} frames/s.  No MIOpen / rocBLAS kernel is left in the trace: the ConvNeXt encoder "
-        f"(depthwise, LayerNorm, fused pointwise MLP, patchify GEMMs) and the token MLPs run on the kernels of this library; `at::native::*` rows are reshapes / permute copies and the synthetic clip.\n") + rd(f"{c}_trace.md"))
+        f"({100 * b[c]['roofline']['frac']:.1f} %); CPU oracle {b[c]['cpu_baseline']['value']} frames/s.  "
+        + ("No MIOpen / rocBLAS kernel is left in the trace: the ConvNeXt encoder (depthwise, LayerNorm, fused pointwise MLP, patchify GEMMs) runs on the kernels of this library; "
+           "`at::native::*` rows are reshapes / permute copies and the synthetic clip.\n" if c == "c3" else
+           "The `Cijk_*` rows are the eight linears of E-NeRV's 144-token transformer block on hipBLASLt (plain library GEMMs, ~0.3 ms per step; DESIGN section 6), the `at::native::*` rows "
+           "its softmax / GELU / reshapes and the synthetic clip; everything else is this library.\n")) + rd(f"{c}_trace.md"))
 for c in ("c1", "c3"):
     open(P + f"timeline_{c}.md", "w").write(f"# Round 2 -- per-launch timeline of one eager {c.upper()} train step (tools/ktimeline.py over `rocprofv3 --kernel-trace --output-format csv -- python bench.py "
                                             f"--config {c} --steps 4 --warmup 5 --no_cpu_baseline --no_graph`), MI355X\n\nColumns: index, start, duration, gap to the previous launch (eager launch gaps: absent under graph replay), "
