@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(const GemmArgs g) {
     for (int k0 = kbeg; k0 < kend; k0 += 16) {
         // stage A: 32 x 16 and B: 16 x 32 (two elements of each per thread), zero outside the matrix
         for (int e = tid; e < 512; e += 256) {
-            const int m = e >> 4, k = e & 15;
+            // consecutive threads walk the unit-stride index of A: k for row-major activations, m for the transposed operand of
+            // the weight gradients (sam == 1: a 32-float row segment per k instead of 16 lines sak apart)
+            const int m = g.sam == 1 ? (e & 31) : (e >> 4), k = g.sam == 1 ? (e >> 5) : (e & 15);
             float v = 0.f;
             if (m0 + m < g.M && k0 + k < kend) {
                 const long idx = (long)(m0 + m) * g.sam + (long)(k0 + k) * g.sak;
@@ -90,17 +92,24 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(const GemmArgs g) {
     }
 }
 
-// out[m][n] = sum_z slab[z][m][n] in a fixed order; column N-1 goes to c2 (bias gradient)
+// out[m][n] = sum_z slab[z][m][n] in a fixed order; column N-1 goes to c2 (bias gradient).  Block = 32 outputs x 8 slab lanes
+// (lane l adds slabs l, l + 8, ...; the eight partial sums are added in lane order), so a few hundred slabs are read by
+// M N / 32 blocks instead of M N / 256 threads walking all of them
 __global__ __launch_bounds__(256) void gemm_splitk_finish_kernel(const float* slab, int nz, int M, int N, float* c, float* c2) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M * N) return;
-    float s0 = 0.f, s1 = 0.f;
-    int z = 0;
-    for (; z + 1 < nz; z += 2) { s0 += slab[(size_t)z * M * N + i]; s1 += slab[(size_t)(z + 1) * M * N + i]; }
-    if (z < nz) s0 += slab[(size_t)z * M * N + i];
-    const int m = i / N, n = i - m * N;
-    if (n == N - 1) { if (c2) c2[m] = s0 + s1; }
-    else c[(size_t)m * (N - 1) + n] = s0 + s1;
+    __shared__ float s_p[8][32];
+    const int o = threadIdx.x & 31, zl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
+    float s = 0.f;
+    if (i < M * N)
+        for (int z = zl; z < nz; z += 8) s += slab[(size_t)z * M * N + i];
+    s_p[zl][o] = s;
+    __syncthreads();
+    if (zl == 0 && i < M * N) {
+        const float t = ((s_p[0][o] + s_p[1][o]) + (s_p[2][o] + s_p[3][o])) + ((s_p[4][o] + s_p[5][o]) + (s_p[6][o] + s_p[7][o]));
+        const int m = i / N, n = i - m * N;
+        if (n == N - 1) { if (c2) c2[m] = t; }
+        else c[(size_t)m * (N - 1) + n] = t;
+    }
 }
 
 int launch_gemm(hipStream_t st, const GemmArgs& g, int nz = 1) {
@@ -109,8 +118,10 @@ int launch_gemm(hipStream_t st, const GemmArgs& g, int nz = 1) {
     return BNERV_OK;
 }
 
-constexpr int GEMM_SPLITK_MIN_ROWS = 4096;               // weight gradients over more rows than this are split along the rows
-int dw_splits(int B) { return B < GEMM_SPLITK_MIN_ROWS ? 1 : (cdiv(B, 1024) > 512 ? 512 : cdiv(B, 1024)); }
+constexpr int GEMM_SPLITK_MIN_ROWS = 512;                // weight gradients over more rows than this are split along the rows (an [O, I] output
+                                                         // is a handful of 32 x 32 tiles: without the split 2304 rows ran on 18 blocks for 243 us)
+// (256 rows per split: the K loop has no prefetch, so its global latency is hidden by blocks per CU -- 1024 rows per split left ~2)
+int dw_splits(int B) { return B < GEMM_SPLITK_MIN_ROWS ? 1 : (cdiv(B, 256) > 512 ? 512 : cdiv(B, 256)); }
 
 // ---------------------------------------------------------------------------------------------------------------- ConvNeXt MLP
 // x, inp, out, dout, dx: [B, C, HW];  w1 [4C, C], b1 [4C], w2 [C, 4C], b2 [C], gamma [C] (may be NULL: no layer scale).
@@ -410,7 +421,7 @@ extern "C" int bnerv_dense_gemm_bwd(void* stream, const float* x, const float* w
         g.kchunk = ((cdiv(B, nz) + 15) / 16) * 16;
         rc = launch_gemm(st, g, cdiv(B, g.kchunk));
         if (rc != BNERV_OK) return rc;
-        hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3(cdiv(O * (I + 1), 256)), dim3(256), 0, st, reinterpret_cast<const float*>(ws), cdiv(B, g.kchunk), O, I + 1, dw, db);
+        hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3(cdiv(O * (I + 1), 32)), dim3(256), 0, st, reinterpret_cast<const float*>(ws), cdiv(B, g.kchunk), O, I + 1, dw, db);
         BNERV_LAUNCH_CHECK("gemm_splitk_finish");
     } else {
         rc = launch_gemm(st, g);
