@@ -2,7 +2,9 @@
 what the restatement shows against ITSELF?  C1 (NeRV-boost 1.5M, 720x1280, Fusion10_freq, Adan, cosine schedule), E epochs over the
 synthetic Bunny-shaped clip, for several frame orders: the HIP path (twice: it is bitwise reproducible) and the oracle restatement
 on stock PyTorch-ROCm ops R times (MIOpen / hipFFT reductions use atomics: its runs differ from each other on identical inputs).
-usage: python tools/parity_stat.py [epochs=10] [n_orders=3] [repeats=3]     (checker tool: imports the oracle, not part of the product)"""
+usage: python tools/parity_stat.py [epochs=10] [n_orders=3] [repeats=3]     (checker tool: imports the oracle, not part of the product)
+PARITY_CFG=c1|c3|c4 picks the recipe (c3 / c4: the 3M models at 1080x1920, wide layers on the split bf16x6 kernels); PARITY_NT limits the
+clip to its first NT frames (the stock-ops restatement needs ~0.2 s per 1080p step)."""
 import os, sys, time, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -15,10 +17,15 @@ from boosting_nerv_amd.synth import SyntheticVideo
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 NO = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 RP = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-RC = bench.RECIPES["c1"]
-NT, FH, FW = RC["n"], RC["h"], RC["w"]
+CFG = os.environ.get("PARITY_CFG", "c1")
+RC = bench.RECIPES[CFG]
+NT, FH, FW = min(RC["n"], int(os.environ.get("PARITY_NT", RC["n"]))), RC["h"], RC["w"]
 dev = torch.device("cuda:0")
-args, model0 = bench.build("c1")
+args, model0 = bench.build(CFG)
+TAKES_IMAGE = "HNeRV" in args.model
+STOCK_FWD = {"NeRV_Boost": lambda sd, i: cpu_ref.nerv_boost_forward(sd, norm[i:i + 1]),
+             "HNeRV_Boost": lambda sd, i: cpu_ref.hnerv_boost_forward(sd, frames[i:i + 1], norm[i:i + 1]),
+             "ENeRV_Boost": lambda sd, i: cpu_ref.enerv_boost_forward(sd, norm[i:i + 1])}[args.model]
 sd0 = {k: v.clone() for k, v in model0.state_dict().items()}
 vid = SyntheticVideo(NT, FH, FW)
 frames = torch.stack([vid.frame(i, device=dev) for i in range(NT)])
@@ -33,18 +40,19 @@ def schedule(seed):
 
 
 def run_hip(order, lrs):
-    _, model = bench.build("c1")
+    _, model = bench.build(CFG)
     model.load_state_dict(sd0)
     model = model.to(dev)
     opt = Adan(model.parameters(), lr=lrs[0])
-    step = TrainStep(model, opt, args.loss, False, (1, 3, FH, FW), dev, use_graph=True, warmup_eager=3)
+    step = TrainStep(model, opt, args.loss, TAKES_IMAGE, (1, 3, FH, FW), dev, use_graph=True, warmup_eager=3)
     for s, fi in enumerate(order):
         for pg in opt.param_groups:
             pg["lr"] = lrs[s]
         step(frames[fi:fi + 1], norm[fi:fi + 1])
     model.eval()
     with torch.no_grad():
-        return torch.stack([hu.psnr_fn_device(model(norm[i:i + 1], norm_idx=norm[i:i + 1])[0], frames[i:i + 1]) for i in range(NT)]).mean().item()
+        return torch.stack([hu.psnr_fn_device(model(frames[i:i + 1] if TAKES_IMAGE else norm[i:i + 1], norm_idx=norm[i:i + 1])[0], frames[i:i + 1])
+                            for i in range(NT)]).mean().item()
 
 
 def run_stock(order, lrs):
@@ -54,10 +62,10 @@ def run_stock(order, lrs):
         adan.lr = lrs[s]
         cpu_ref.train_step(args.model, sd, adan, frames[fi:fi + 1], norm[fi:fi + 1], args.loss)
     with torch.no_grad():
-        return torch.stack([cpu_ref.psnr_fn_single(cpu_ref.nerv_boost_forward(sd, norm[i:i + 1]), frames[i:i + 1]) for i in range(NT)]).mean().item()
+        return torch.stack([cpu_ref.psnr_fn_single(STOCK_FWD(sd, i), frames[i:i + 1]) for i in range(NT)]).mean().item()
 
 
-print(f"C1, {E} epochs x {NT} frames = {E * NT} steps per run; {NO} frame orders; stock-ops restatement repeated {RP}x per order")
+print(f"{CFG.upper()} ({args.model}, {FH}x{FW}), {E} epochs x {NT} frames = {E * NT} steps per run; {NO} frame orders; stock-ops restatement repeated {RP}x per order")
 print("| order seed | HIP run 1 | HIP run 2 | stock-ops runs | stock spread (max - min) | HIP - mean(stock) |")
 print("|---|---|---|---|---|---|")
 gaps, spreads, pair_diffs = [], [], []
