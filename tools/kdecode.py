@@ -18,7 +18,9 @@ with torch.no_grad():
     torch.cuda.synchronize()
     print(f"eager decode : {100 / (time.time() - t0):8.1f} frames/s")
     g = torch.cuda.CUDAGraph(); s = torch.cuda.Stream()
+    from boosting_nerv_amd import _lib as L
     with torch.cuda.stream(s):
+        L.ctx()                                  # the capture stream's library context (and its scratch) must exist before the capture
         with torch.cuda.graph(g, stream=s):
             out = model(idx, norm_idx=idx)[0]
     g.replay(); torch.cuda.synchronize()
