@@ -114,8 +114,9 @@ SYMBOLS = {
     "bnerv_conv_partial_rows": (_I, [C.POINTER(ConvDesc)]),
     "bnerv_conv_wgrad_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bnerv_conv_wgrad": (_I, [_V, C.POINTER(WgradDesc)]),
-    "bnerv_cem_scale_fwd": (_I, [_V, C.POINTER(CemChunk), _V]),
-    "bnerv_cem_scale_bwd": (_I, [_V, C.POINTER(CemChunkBwd), _V, _V, _V]),
+    "bnerv_cem_ws_bytes": (_Z, [_I, _I]),
+    "bnerv_cem_scale_fwd": (_I, [_V, C.POINTER(CemChunk), _V, _V, _Z]),
+    "bnerv_cem_scale_bwd": (_I, [_V, C.POINTER(CemChunkBwd), _V, _V, _V, _V, _Z]),
     "bnerv_dense_gemm_fwd": (_I, [_V, _V, _V, _V, _V, _V, _I, _I, _I, _I]),
     "bnerv_dense_gemm_bwd_ws_bytes": (_Z, [_I, _I, _I]),
     "bnerv_dense_gemm_bwd": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _Z, _I, _I, _I, _I]),
@@ -144,7 +145,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class BnervError(RuntimeError):

@@ -503,7 +503,9 @@ class _CemScaleRate(torch.autograd.Function):
                 ck.it[j].w, ck.it[j].scale, ck.it[j].dequant, ck.it[j].n = wc[i].data_ptr(), sc[i].data_ptr(), deq[i].data_ptr(), wc[i].numel()
                 ck.it[j].noise = nz[i].data_ptr() if nz[i] is not None else None
             ck.n_items, ck.training, ck.first = m, int(training), i0
-            L.check(lib.bnerv_cem_scale_fwd(L.stream(), C.byref(ck), L.ptr(stats)), "bnerv_cem_scale_fwd")
+            nb = lib.bnerv_cem_ws_bytes(m, max(wc[i0 + j].numel() for j in range(m)))
+            ws_ = _ws(nb, dev)                                 # chunk partial sums (stream-ordered allocation: reused by the next group)
+            L.check(lib.bnerv_cem_scale_fwd(L.stream(), C.byref(ck), L.ptr(stats), L.ptr(ws_), nb), "bnerv_cem_scale_fwd")
         ctx.n, ctx.training = n, training
         ctx.save_for_backward(stats, *wc, *sc, *[z for z in nz if z is not None])
         ctx.has_noise = [z is not None for z in nz]
@@ -534,7 +536,9 @@ class _CemScaleRate(torch.autograd.Function):
                 ck.it[j].noise = nz[i].data_ptr() if nz[i] is not None else None
                 ck.it[j].d_dequant = dds[i].data_ptr() if dds[i] is not None else None
             ck.n_items, ck.training, ck.first = m, int(ctx.training), i0
-            L.check(lib.bnerv_cem_scale_bwd(L.stream(), C.byref(ck), L.ptr(stats), L.ptr(d_bits), L.ptr(dscale)), "bnerv_cem_scale_bwd")
+            nb = lib.bnerv_cem_ws_bytes(m, max(wc[i0 + j].numel() for j in range(m)))
+            ws_ = _ws(nb, dev)
+            L.check(lib.bnerv_cem_scale_bwd(L.stream(), C.byref(ck), L.ptr(stats), L.ptr(d_bits), L.ptr(dscale), L.ptr(ws_), nb), "bnerv_cem_scale_bwd")
         gs = [dscale[i:i + 1].reshape(sc[i].shape) for i in range(n)]
         return (None, None, *[dw.reshape(sh) for dw, sh in zip(dws, ctx.wshapes)], *gs, *([None] * n))
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BNERV_ABI_VERSION 2
+#define BNERV_ABI_VERSION 3
 
 #define BNERV_OK 0
 #define BNERV_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -234,8 +234,12 @@ typedef struct { const float* w; const float* scale; const float* noise; float* 
 typedef struct { bnerv_cem_item it[BNERV_CEM_MAX_TENSORS]; int n_items; int training; int first; int _pad; } bnerv_cem_chunk;
 typedef struct { const float* w; const float* scale; const float* noise; const float* d_dequant; float* dw; int n; int _pad; } bnerv_cem_item_bwd;
 typedef struct { bnerv_cem_item_bwd it[BNERV_CEM_MAX_TENSORS]; int n_items; int training; int first; int _pad; } bnerv_cem_chunk_bwd;
-int bnerv_cem_scale_fwd(void* stream, const bnerv_cem_chunk* chunk, float* stats);
-int bnerv_cem_scale_bwd(void* stream, const bnerv_cem_chunk_bwd* chunk, const float* stats, const float* d_bits, float* dscale);
+/* Every tensor is cut into chunks of 8192 elements (one block each); the chunk partial sums (f64, fixed order) live in a caller-provided
+ * workspace of bnerv_cem_ws_bytes(n_items, numel of the largest tensor of the chunk) bytes per call (ABI 3). */
+size_t bnerv_cem_ws_bytes(int n_items, int max_n);
+int bnerv_cem_scale_fwd(void* stream, const bnerv_cem_chunk* chunk, float* stats, void* ws, size_t ws_bytes);
+int bnerv_cem_scale_bwd(void* stream, const bnerv_cem_chunk_bwd* chunk, const float* stats, const float* d_bits, float* dscale,
+                        void* ws, size_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * GEMM-shaped dense work on v_mfma_f32_16x16x4_f32 (csrc/gemm.hip).
