@@ -2,6 +2,7 @@
 inputs, plus the golden fixtures produced by the real reference.  Tolerance per SURVEY 8(d): rtol 1e-3 (atol scaled to
 the tensor's magnitude) -- fp32 arithmetic, different summation order than MKLDNN."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -633,3 +634,12 @@ def test_wide_split_conv_kernel_upconv_ps2(ops, case, min_items, monkeypatch):
     close(out2, ref2, msg="ps2 snerv fwd")
     for n, a, r in zip(["x", "wu", "bu", "s0", "t0", "s1", "t1", "w0", "b0", "w1", "b1"], torch.autograd.grad(out2, gl, cot2.to(DEV)), rg2):
         close(a, r, msg=f"ps2 snerv d{n}")
+
+
+def test_wide_split_kernels_random_shapes():
+    """tools/fuzz_wide.py: random (B, Cin, Cout, H, W) for plain / PixelShuffle(2) convs and TAT blocks through the wide split kernels
+    (both cout-tile policies) against float64 torch references -- outputs and every gradient within 2e-5 of the tensor's max."""
+    import subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_wide.py")
+    r = subprocess.run([sys.executable, tool, "60", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
