@@ -1064,7 +1064,7 @@ int launch_bfw(hipStream_t st, KArgs& ka) {
     if (lds != occ_lds) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_bfw_kernel<IN, EP, SP, NTB, PS2>), 256, lds) != hipSuccess || nb < 1) nb = 1;
-        blocks_per_cu = nb > 2 ? 2 : nb;
+        blocks_per_cu = NTB == 1 ? (nb > 3 ? 3 : nb) : (nb > 2 ? 2 : nb);   // (one-tile variants fit three blocks: 49 KB LDS, <= 168 VGPRs where the compiler got there)
         occ_lds = lds;
     }
     int grid = 256 * blocks_per_cu;
