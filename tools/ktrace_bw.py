@@ -1,5 +1,9 @@
-"""Phase timeline of wgrad_bfw_kernel from a -DBNERV_TRACE_BW build (debug variant; BNERV_LIB points at it).  s_memtime ticks = 100 MHz
-constant clock on gfx950 -> printed in ns."""
+"""Phase timeline of wgrad_bfw_kernel from a -DBNERV_TRACE_BW build (debug variant; BNERV_LIB points at it).  The numbers printed are
+s_memtime ticks x 10: on this stack the ticks advance at the shader clock (~1.9 GHz under this load), so divide by 10 for cycles.
+Build the variant next to the product library (from boosting_nerv_amd/csrc, after build.sh):
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DBNERV_TRACE_BW -c wgrad.hip -o _obj/wgrad_tbw.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o ../_dbg/libbnerv_tbw.so _obj/wgrad_tbw.o $(ls _obj/*.o | grep -v "wgrad")
+  BNERV_LIB=$PWD/../_dbg/libbnerv_tbw.so python ../../tools/ktrace_bw.py"""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
