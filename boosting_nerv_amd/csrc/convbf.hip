@@ -616,13 +616,14 @@ __global__ __launch_bounds__(256) void bf_wprep_kernel(const float* __restrict__
 
 struct WItem { int g, b, ty, tx; };
 
-// PS2: the output goes through PixelShuffle(2) (conv channel 4c + 2i + j at (y, x) -> out[c][2y + i][2x + j]; the up-convs).
+// PS2 = 2: the output goes through PixelShuffle(2) (conv channel 4c + 2i + j at (y, x) -> out[c][2y + i][2x + j]; the up-convs) with
+// paired 16-B stores; PS2 = 3: PixelShuffle(s), s = out_s in {3, 5}, with four 4-B stores s columns apart per accumulator quad.
 // IN_UNSHUFFLE: the input is read through the inverse map from the shuffled tensor (data gradient of an up-conv; in_s == 2).
-template <int IN, int EP, int SP, int NTB, bool PS2>
+template <int IN, int EP, int SP, int NTB, int PS2>
 __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const u32x4* __restrict__ wfrag, const int ngroups, const SidePack side) {
     constexpr int KS = 3;
     constexpr bool UNSH = (IN == BNERV_IN_UNSHUFFLE);
-    static_assert(!PS2 || EP == BNERV_EP_BIAS || EP == BNERV_EP_BIAS_SIN, "pixel-shuffle epilogues");
+    static_assert(PS2 == 0 || EP == BNERV_EP_BIAS || EP == BNERV_EP_BIAS_SIN, "pixel-shuffle epilogues");
     using G = Geo<KS>;
     using BG = BfGeo<KS>;
     constexpr int NS = Split<SP>::NS;
@@ -903,7 +904,24 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
                     const unsigned vo = okm[m] ? ovoff : OOB;
                     f32x4 v = acc[m][n];
                     if constexpr (RED) { if (!okm[m]) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                    if constexpr (PS2) {
+                    if constexpr (PS2 == 3) {
+                        // PixelShuffle(s), s = 3 or 5: conv channel c s^2 + i s + j at (y, x) -> out[c][s y + i][s x + j]; the lane's four
+                        // pixels land s columns apart in one output row: four 4-B stores (the L2 merges the s^2 channels of a block)
+                        const int sps = d.out_s, ss = sps * sps;
+                        const int cps = sps == 3 ? co / 9 : co / 25, rps = co - cps * ss, ips = sps == 3 ? rps / 3 : rps / 5, jps = rps - ips * sps;
+                        const int Hs = H * sps, Ws = W * sps;
+                        const unsigned pvo = (okm[m] && co < Cout) ? (unsigned)((((cps * Hs + ips) * Ws) + jps + sps * 4 * kq) * 4) : OOB;
+                        const unsigned pso = (unsigned)(((((it.b * (Cout / ss)) * Hs) + sps * (ty0 + 2 * wave + (m >> 1))) * Ws + sps * (tx0 + (m & 1) * 16)) * 4);
+                        const float q4[4] = {v.x + bias_l, v.y + bias_l, v.z + bias_l, v.w + bias_l};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned vo_e = pvo == OOB ? OOB : pvo + (unsigned)(e * sps * 4);
+                            float s_ = q4[e], c_ = 0.f;
+                            if constexpr (EP == BNERV_EP_BIAS_SIN) sincos_f(q4[e], &s_, &c_);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s_), ro, (int)vo_e, (int)pso, 0);
+                            if constexpr (EP == BNERV_EP_BIAS_SIN) { if (d.out2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c_), ro2, (int)vo_e, (int)pso, 0); }
+                        }
+                    } else if constexpr (PS2 == 2) {
                         // lane pair (j = 0 / 1 = even / odd conv channel) owns 8 consecutive output columns of row 2y + i: the even
                         // lane keeps pixels 0, 1 of both and stores columns 0..3, the odd lane pixels 2, 3 and columns 4..7
                         const bool odd = li & 1;
@@ -1037,7 +1055,7 @@ static int wide_mode() {                                   // BNERV_SPLIT_WIDE =
     return v;
 }
 
-template <int IN, int EP, int SP, int NTB, bool PS2 = false>
+template <int IN, int EP, int SP, int NTB, int PS2 = 0>
 int launch_bfw(hipStream_t st, KArgs& ka) {
     using BG = BfGeo<3>;
     constexpr int NS = Split<SP>::NS;
@@ -1076,7 +1094,7 @@ int launch_bfw(hipStream_t st, KArgs& ka) {
     return BNERV_OK;
 }
 
-template <int IN, int EP, int SP, bool PS2 = false>
+template <int IN, int EP, int SP, int PS2 = 0>
 int launch_bfw_ntb(hipStream_t st, KArgs& ka) {
     const int nt = cdiv(ka.d.Cout, 16);
     int ntb = nt <= 3 ? nt : (nt == 4 ? 2 : 3);
@@ -1091,16 +1109,21 @@ int launch_bfw_ntb(hipStream_t st, KArgs& ka) {
     return launch_bfw<IN, EP, SP, 3, PS2>(st, ka);
 }
 
-template <int IN, int EP, bool PS2 = false>
+template <int IN, int EP, int PS2 = 0>
 int launch_bfw_sp(hipStream_t st, KArgs& ka) {
     return wide_mode() == SP_BF16X3 ? launch_bfw_ntb<IN, EP, SP_BF16X3, PS2>(st, ka) : launch_bfw_ntb<IN, EP, SP_BF16X6, PS2>(st, ka);
 }
 
 int launch_wide_mode(hipStream_t st, KArgs& ka) {
     const int in = ka.d.in_mode, ep = ka.d.ep_mode;
+    if (ka.d.out_s == 3 || ka.d.out_s == 5) {              // up-conv forward through PixelShuffle(3 / 5): scatter stores
+        if (in == BNERV_IN_PLAIN && ep == BNERV_EP_BIAS_SIN) return launch_bfw_sp<BNERV_IN_PLAIN, BNERV_EP_BIAS_SIN, 3>(st, ka);
+        if (in == BNERV_IN_PLAIN && ep == BNERV_EP_BIAS) return launch_bfw_sp<BNERV_IN_PLAIN, BNERV_EP_BIAS, 3>(st, ka);
+        return -1;
+    }
     if (ka.d.out_s == 2) {                                 // up-conv forward: conv -> bias -> PixelShuffle(2) [-> sin, cos]
-        if (in == BNERV_IN_PLAIN && ep == BNERV_EP_BIAS_SIN) return launch_bfw_sp<BNERV_IN_PLAIN, BNERV_EP_BIAS_SIN, true>(st, ka);
-        if (in == BNERV_IN_PLAIN && ep == BNERV_EP_BIAS) return launch_bfw_sp<BNERV_IN_PLAIN, BNERV_EP_BIAS, true>(st, ka);
+        if (in == BNERV_IN_PLAIN && ep == BNERV_EP_BIAS_SIN) return launch_bfw_sp<BNERV_IN_PLAIN, BNERV_EP_BIAS_SIN, 2>(st, ka);
+        if (in == BNERV_IN_PLAIN && ep == BNERV_EP_BIAS) return launch_bfw_sp<BNERV_IN_PLAIN, BNERV_EP_BIAS, 2>(st, ka);
         return -1;
     }
     if (in == BNERV_IN_UNSHUFFLE) return ep == BNERV_EP_PLAIN ? launch_bfw_sp<BNERV_IN_UNSHUFFLE, BNERV_EP_PLAIN>(st, ka) : -1;
@@ -1130,7 +1153,8 @@ extern "C" int bnerv_debug_trace_read_bf(void* host) { return (int)hipMemcpyFrom
 int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec) {
     if (!vec || d.in_mode == BNERV_IN_TANHGRAD) return -1;
     const bool shuffled = d.out_s != 1 || d.in_mode == BNERV_IN_UNSHUFFLE;                // up-conv forward / its data gradient
-    if (d.out_s != 1 && (d.out_s != 2 || d.Cout % 4 != 0)) return -1;
+    if (d.out_s != 1 && !((d.out_s == 2 || d.out_s == 3 || d.out_s == 5) && d.Cout % (d.out_s * d.out_s) == 0)) return -1;
+    if ((size_t)d.B * d.Cout * d.H * d.W * 4 >= LEAN_MAX_BYTES) return -1;      // (the shuffled output is addressed as one buffer)
     if (d.in_mode == BNERV_IN_UNSHUFFLE && (d.in_s != 2 || d.Cin % 4 != 0 || d.out_s != 1)) return -1;
     const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
     if ((size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 >= LEAN_MAX_BYTES) return -1;

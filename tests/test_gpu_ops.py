@@ -636,6 +636,39 @@ def test_wide_split_conv_kernel_upconv_ps2(ops, case, min_items, monkeypatch):
         close(a, r, msg=f"ps2 snerv d{n}")
 
 
+@pytest.mark.parametrize("min_items", ["1", "128"])
+@pytest.mark.parametrize("case", [(1, 20, 45, 9, 32, 3), (1, 17, 50, 8, 32, 5), (2, 40, 90, 14, 100, 3), (1, 33, 175, 11, 36, 5), (1, 79, 594, 10, 32, 3)])
+def test_wide_split_conv_kernel_upconv_ps35(ops, case, min_items, monkeypatch):
+    """Up-conv + PixelShuffle(3 / 5) forward through the wide split kernel's scatter-store epilogue (plain and sin / cos), gradients
+    through the kernels that own them."""
+    monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_ITEMS", min_items)
+    B, Cin, Ct, H, W, s = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(Ct, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).requires_grad_(True)
+    b = torch.randn(Ct, generator=g).requires_grad_(True)
+    ref = cpu_ref.upconv(x, w, b, s)
+    cot = torch.randn(ref.shape, generator=g)
+    rg = torch.autograd.grad(ref, [x, w, b], cot)
+    xg, wg, bg = gpu(x), gpu(w), gpu(b)
+    out = ops.conv2d_ps(xg, wg, bg, s)
+    close(out, ref, msg=f"ps{s} conv fwd")
+    for n, a, r in zip("xwb", torch.autograd.grad(out, [xg, wg, bg], cot.to(DEV)), rg):
+        close(a, r, msg=f"ps{s} conv d{n}")
+    Cc = Ct // (s * s)
+    x0, mods, w0, b0, w1, b1, g2 = _tat_inputs(B, Cc, s * H, s * W, seed=13)
+    ref2 = _tat_ref(torch.sin(cpu_ref.upconv(x, w, b, s)), mods, w0, b0, w1, b1)
+    cot2 = torch.randn(ref2.shape, generator=g2)
+    leaves = [x, w, b] + mods + [w0, b0, w1, b1]
+    rg2 = torch.autograd.grad(ref2, leaves, cot2)
+    gl = [gpu(t) for t in leaves]
+    out2 = ops.snerv_block(*gl, s)
+    close(out2, ref2, msg=f"ps{s} snerv fwd")
+    for n, a, r in zip(["x", "wu", "bu", "s0", "t0", "s1", "t1", "w0", "b0", "w1", "b1"], torch.autograd.grad(out2, gl, cot2.to(DEV)), rg2):
+        close(a, r, msg=f"ps{s} snerv d{n}")
+
+
 def test_wide_split_kernels_random_shapes():
     """tools/fuzz_wide.py: random (B, Cin, Cout, H, W) for plain / PixelShuffle(2) convs and TAT blocks through the wide split kernels
     (both cout-tile policies) against float64 torch references -- outputs and every gradient within 2e-5 of the tensor's max."""

@@ -1,5 +1,5 @@
 """Randomised shape sweep of the wide split kernels (conv_bfw / wgrad_bfw) against float64 torch references on the GPU: plain and
-PixelShuffle(2) convolutions with their data / weight / bias gradients, and the TAT block (affine prologues, gelu pair, residual,
+PixelShuffle(2 / 3 / 5) convolutions with their data / weight / bias gradients, and the TAT block (affine prologues, gelu pair, residual,
 dGELU / dSIN epilogues with their per-channel sums).  usage: python tools/fuzz_wide.py [cases=120] [seed=0]
 (checker tool: torch fp64 is the reference here, not part of the product)"""
 import math, os, random, sys, torch
@@ -37,7 +37,7 @@ def ref_tat(x0, mods, w0, b0, w1, b1):
 bad = 0
 for it in range(N):
     os.environ["BNERV_SPLIT_WIDE_MIN_ITEMS"] = rng.choice(["1", "128"])
-    kind = rng.choice(["conv", "ps2", "tat"])
+    kind = rng.choice(["conv", "ps2", "ps3", "ps5", "tat"])
     B = rng.choice([1, 1, 2, 3])
     H, W = rng.randint(3, 45), 4 * rng.randint(1, 40)
     g = torch.Generator(device="cpu").manual_seed(rng.randint(0, 1 << 30))
@@ -60,9 +60,11 @@ for it in range(N):
         for n_, a, r in zip(["dx0", "ds0", "dt0", "ds1", "dt1", "dw0", "db0", "dw1", "db1"], grads, rgrads):
             bad += check("tat " + n_, a, r, case)
     else:
-        s = 2 if kind == "ps2" else 1
+        s = {"conv": 1, "ps2": 2, "ps3": 3, "ps5": 5}[kind]
         Cin = rng.randint(9, 110)
-        Ct = 4 * rng.randint(5, 40) if s == 2 else rng.randint(17, 110)
+        Ct = s * s * rng.randint(5 if s == 2 else 2, 40 if s == 2 else (20 if s == 3 else 8)) if s > 1 else rng.randint(17, 110)
+        if s > 2:
+            H, W = min(H, 20), min(W, 64)
         if Cin <= 16 and Ct <= 16:
             Ct = 24
         case = (kind, B, Cin, Ct, H, W, os.environ["BNERV_SPLIT_WIDE_MIN_ITEMS"])
