@@ -1175,7 +1175,8 @@ constexpr int BW_TH = 4, BW_NTW = 8, BW_NPL = (BW_NTW * 16 + 7) / 9 + 1;      //
 constexpr int BW_ROW = 64, BW_PLANE = 6 * BW_ROW + 32, BW_COPY = BW_NPL * BW_PLANE + 192, BW_CONST = 4 * BW_ROW;
 constexpr int BW_PIECE = 3 * BW_COPY + 2 * BW_CONST;                          // + a plane of ones (piece 0 only) and a plane of zeros
 
-// GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient of an up-conv (conv channel 4c + 2i + j at (y, x) = du[c][2y + i][2x + j])
+// GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient of an up-conv (conv channel 4c + 2i + j at (y, x) = du[c][2y + i][2x + j]),
+// 3 = shuffled by s = g_s in {3, 5} (conv channel c s^2 + i s + j at (y, x) = du[c][s y + i][s x + j]; strided 4-B loads)
 template <int IN, int SP, int MTW, int GM2>
 __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const int slots, const int ngroups_n, const int ngroups_m, const SidePack side) {
     constexpr int NS = Split<SP>::NS;
@@ -1241,7 +1242,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
         const int cl = 16 * m + li;
         if constexpr (GM2 == 1)
             gs_off[m] = co_base + cl < Cout ? (unsigned)(((((cl >> 2) * 2 * H) + 2 * wave + ((cl >> 1) & 1)) * 2 * W + 8 * kq + 32 * (cl & 1)) * 4) : OOB;
-        else
+        else if constexpr (GM2 == 3) {                     // x3 / x5 shuffle: absolute shuffled channel, row s (y) + i, column s (4 kq) + j
+            const int sg_ = d.g_s, co = co_base + cl, cs = sg_ == 3 ? co / 9 : co / 25, rs = co - cs * sg_ * sg_, is = sg_ == 3 ? rs / 3 : rs / 5;
+            gs_off[m] = co < Cout ? (unsigned)((((cs * sg_ * H) + sg_ * wave + is) * sg_ * W + (rs - is * sg_) + sg_ * 4 * kq) * 4) : OOB;
+        } else
             gs_off[m] = co_base + cl < Cout ? (unsigned)(((cl * H + wave) * W + 4 * kq) * 4) : OOB;
     }
     f32x4 xv[NXS];
@@ -1256,12 +1260,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
         const int ty0 = a.ty * BW_TH, tx0 = a.tx * 32;
         if (tile_interior(a)) {
             const unsigned sx = (unsigned)((((a.b * Cin + ci_lo) * H + ty0 - 1) * W + tx0) * 4);
+            if constexpr (GM2 == 3) {                          // four 4-B loads s columns apart per pixel group
+                const int sg_ = d.g_s;
+                const unsigned sgb = (unsigned)(((((a.b * (Cout / (sg_ * sg_))) * sg_ * H) + sg_ * ty0) * sg_ * W + sg_ * tx0) * 4);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            ga[m][h][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)gs_off[m], (int)(sgb + (unsigned)(sg_ * (16 * h + t) * 4)), 0));
+            } else {
             const unsigned sg = GM2 == 1 ? (unsigned)(((((a.b * (Cout >> 2) + (co_base >> 2)) * 2 * H) + 2 * ty0) * 2 * W + 2 * tx0) * 4)
                                          : (unsigned)((((a.b * Cout + co_base) * H + ty0) * W + tx0) * 4);
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 ga[m][0] = bload(rg, gs_off[m], sg);
                 ga[m][1] = bload(rg, gs_off[m], sg + (GM2 == 1 ? 16u : 64u));
+            }
             }
 #pragma unroll
             for (int k = 0; k < NXS; ++k) {
@@ -1277,7 +1293,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
             for (int m = 0; m < MTW; ++m) {
                 const int co = co_base + 16 * m + li;
                 const bool ok = co < Cout && gy < H;
-                if constexpr (GM2 == 1) {
+                if constexpr (GM2 == 3) {
+                    const int sg_ = d.g_s, cs = sg_ == 3 ? co / 9 : co / 25, rs = co - cs * sg_ * sg_, is = sg_ == 3 ? rs / 3 : rs / 5;
+                    const unsigned base = (unsigned)(((((a.b * (Cout / (sg_ * sg_)) + cs) * sg_ * H) + sg_ * gy + is) * sg_ * W + sg_ * gx + (rs - is * sg_)) * 4);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            ga[m][h][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)((ok && gx + 16 * h < W) ? base + (unsigned)(sg_ * (16 * h + t) * 4) : OOB), 0, 0));
+                } else if constexpr (GM2 == 1) {
                     const int px0 = gx + 16 * (co & 1);
                     const unsigned base = (unsigned)(((((a.b * (Cout >> 2) + (co >> 2)) * 2 * H) + 2 * gy + ((co >> 1) & 1)) * 2 * W + 2 * px0) * 4);
                     ga[m][0] = bload(rg, (ok && px0 < W) ? base : OOB, 0u);
@@ -1494,9 +1518,9 @@ static int bw_mode() {                                     // BNERV_SPLIT_WIDE =
 }
 static bool bw_ok(const WArgs& wa) {
     const bnerv_wgrad_desc& d = wa.d;
-    if (bw_mode() < 0 || !wa.vec || d.k != 3 || d.g_s > 2 || d.g_mode == BNERV_IN_TANHGRAD) return false;
+    if (bw_mode() < 0 || !wa.vec || d.k != 3 || (d.g_s > 3 && d.g_s != 5) || d.g_mode == BNERV_IN_TANHGRAD) return false;
     if (d.in_mode != BNERV_IN_PLAIN && d.in_mode != BNERV_IN_AFFINE) return false;
-    if (d.g_s == 2 && d.in_mode != BNERV_IN_PLAIN) return false;
+    if (d.g_s >= 2 && d.in_mode != BNERV_IN_PLAIN) return false;
     if (d.Cout <= 16) return false;                        // (one cout tile: the f32 kernels are as fast or faster -- 64 -> 16 @540x960: 108 vs 115 us)
     int min_tiles = 16;
     if (const char* e = getenv("BNERV_SPLIT_WIDE_MIN_TILES")) min_tiles = atoi(e);
@@ -1544,6 +1568,8 @@ int launch_bw_m(hipStream_t st, const WArgs& wa, const BwPlan& p) {
 }
 static int launch_bw_modes(hipStream_t st, const WArgs& wa, const BwPlan& p) {
     const bool x3 = bw_mode() == SP_BF16X3;
+    if (wa.d.g_s == 3 || wa.d.g_s == 5)                    // (x3 / x5 up-convs: strided 4-B gradient loads)
+        return x3 ? launch_bw_m<BNERV_IN_PLAIN, SP_BF16X3, 3>(st, wa, p) : launch_bw_m<BNERV_IN_PLAIN, SP_BF16X6, 3>(st, wa, p);
     if (wa.d.g_s == 2)                                     // (the up-convs: plain input, shuffled gradient)
         return x3 ? launch_bw_m<BNERV_IN_PLAIN, SP_BF16X3, 1>(st, wa, p) : launch_bw_m<BNERV_IN_PLAIN, SP_BF16X6, 1>(st, wa, p);
     if (wa.d.in_mode == BNERV_IN_AFFINE) return x3 ? launch_bw_m<BNERV_IN_AFFINE, SP_BF16X3, 0>(st, wa, p) : launch_bw_m<BNERV_IN_AFFINE, SP_BF16X6, 0>(st, wa, p);
