@@ -673,9 +673,10 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
     // conv-space pair (4c + 2i, 4c + 2i + 1) at 4 pixels is 8 consecutive floats of row 2y + i of du[c]; thread offset in units of
     // the shuffled tensor, the (c, i) row added per pair.
     const int W2 = 2 * W, H2 = 2 * H;
-    const unsigned voff0 = !has_slot ? OOB : (UNSH ? (unsigned)(((2 * s_r) * W2 + 8 * s_sg) * 4) : (unsigned)((((8 * s_h) * H + s_r) * W + 4 * s_sg) * 4));
+    const int sin_ = UNSH ? d.in_s : 1, Wsi = sin_ * W, Hsi = sin_ * H;      // (UNSH with in_s = 3 / 5: four 4-B loads s columns apart per channel)
+    const unsigned voff0 = !has_slot ? OOB : (UNSH ? (unsigned)(((sin_ * s_r) * Wsi + 4 * sin_ * s_sg) * 4) : (unsigned)((((8 * s_h) * H + s_r) * W + 4 * s_sg) * 4));
     const unsigned hw4 = (unsigned)(H * W * 4);
-    const unsigned shift = UNSH ? (unsigned)((2 * G::PAD * W2 + 2 * G::XOFF) * 4) : (unsigned)((G::PAD * W + G::XOFF) * 4);
+    const unsigned shift = UNSH ? (unsigned)((sin_ * G::PAD * Wsi + sin_ * G::XOFF) * 4) : (unsigned)((G::PAD * W + G::XOFF) * 4);
     const unsigned in_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
     const unsigned out_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, in_bytes);
@@ -703,6 +704,23 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
         nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
         ra_valid = nv;
         if constexpr (UNSH) {
+            if (sin_ != 2) {                               // x3 / x5: conv channel c s^2 + i s + j at (y, x) = du[c][s y + i][s x + j]
+                const int ss = sin_ * sin_;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ci = 16 * c + 8 * s_h + e;
+                    const int cs = sin_ == 3 ? ci / 9 : ci / 25, rs = ci - cs * ss, is = sin_ == 3 ? rs / 3 : rs / 5;
+                    const unsigned sb = (unsigned)(((((a.b * (Cin / ss) + cs) * Hsi) + sin_ * ty0 + is) * Wsi + sin_ * tx0 + (rs - is * sin_)) * 4);
+                    f32x4 l = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (e < nv) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            l[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(vo == OOB ? OOB : vo + (unsigned)(t * sin_ * 4)), (int)sb, 0));
+                    }
+                    ra[e] = l;
+                }
+                return;
+            }
             const int cd0 = (16 * c + 8 * s_h) >> 2;       // first du channel of this half (two per half: (cd0, i), (cd0 + 1, i))
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
@@ -1155,7 +1173,7 @@ int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec) {
     const bool shuffled = d.out_s != 1 || d.in_mode == BNERV_IN_UNSHUFFLE;                // up-conv forward / its data gradient
     if (d.out_s != 1 && !((d.out_s == 2 || d.out_s == 3 || d.out_s == 5) && d.Cout % (d.out_s * d.out_s) == 0)) return -1;
     if ((size_t)d.B * d.Cout * d.H * d.W * 4 >= LEAN_MAX_BYTES) return -1;      // (the shuffled output is addressed as one buffer)
-    if (d.in_mode == BNERV_IN_UNSHUFFLE && (d.in_s != 2 || d.Cin % 4 != 0 || d.out_s != 1)) return -1;
+    if (d.in_mode == BNERV_IN_UNSHUFFLE && (!(d.in_s == 2 || d.in_s == 3 || d.in_s == 5) || d.Cin % (d.in_s * d.in_s) != 0 || d.out_s != 1)) return -1;
     const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
     if ((size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 >= LEAN_MAX_BYTES) return -1;
     KArgs ka;
