@@ -41,11 +41,15 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(const GemmArgs g) {
     const int kbeg = g.kchunk > 0 ? (int)blockIdx.z * g.kchunk : 0;
     const int kend = g.kchunk > 0 ? min(g.K, kbeg + g.kchunk) : g.K;
     float* cbase = g.c + (g.kchunk > 0 ? (size_t)blockIdx.z * g.M * g.ldc : 0);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        // stage A: 32 x 16 and B: 16 x 32 (two elements of each per thread), zero outside the matrix
-        for (int e = tid; e < 512; e += 256) {
-            // consecutive threads walk the unit-stride index of A: k for row-major activations, m for the transposed operand of
-            // the weight gradients (sam == 1: a 32-float row segment per k instead of 16 lines sak apart)
+    // K loop, 16 at a time: the loads of step k0 + 16 are issued into registers before the MFMAs of step k0 and written to LDS after
+    // them (one barrier pair per step, global latency under the previous step instead of in front of every one).
+    // Staging slot e = tid, tid + 256: A 32 x 16 and B 16 x 32 (two elements of each per thread), zero outside the matrix; consecutive
+    // threads walk the unit-stride index of A: k for row-major activations, m for the transposed operand of the weight gradients.
+    float ra[2], rb[2];
+    auto load_step = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + j * 256;
             const int m = g.sam == 1 ? (e & 31) : (e >> 4), k = g.sam == 1 ? (e >> 5) : (e & 15);
             float v = 0.f;
             if (m0 + m < g.M && k0 + k < kend) {
@@ -54,14 +58,28 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(const GemmArgs g) {
                 if (g.pro == PRO_RELU) v = g.a_aux[idx] > 0.f ? v : 0.f;
                 else if (g.pro == PRO_COS) v *= g.a_aux[idx];
             }
-            s_a[m][k] = v;
+            ra[j] = v;
             const int kb = e >> 5, n = e & 31;
             float u = 0.f;
             if (k0 + kb < kend && n0 + n < g.N)
                 u = (g.ones_col && n0 + n == g.N - 1) ? 1.0f : g.b[(long)(k0 + kb) * g.sbk + (long)(n0 + n) * g.sbn];
-            s_b[kb][n] = u;
+            rb[j] = u;
         }
+    };
+    auto store_step = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + j * 256;
+            const int m = g.sam == 1 ? (e & 31) : (e >> 4), k = g.sam == 1 ? (e >> 5) : (e & 15);
+            s_a[m][k] = ra[j];
+            s_b[e >> 5][e & 31] = rb[j];
+        }
+    };
+    if (kbeg < kend) load_step(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        store_step();
         __syncthreads();
+        if (k0 + 16 < kend) load_step(k0 + 16);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s_a[mt * 16 + li][4 * s + kq], s_b[4 * s + kq][nt * 16 + li], acc, 0, 0, 0);
