@@ -21,7 +21,7 @@
 #include "common.h"
 #include "sidejob.h"
 
-int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec);   // convbf.hip
+int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec, int ksplit, int chunks_per_split);   // convbf.hip
 
 namespace {
 
@@ -1769,11 +1769,9 @@ extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
         BNERV_LAUNCH_CHECK("head1x1_dgrad");
         return BNERV_OK;
     }
-    if (ka.ksplit == 1) {                                  // split-bf16 kernels (convbf.hip) take the 12..16-channel stride-1 layers
-        const int rb = bnerv_convbf_try(st, d, ka.vec);
-        if (rb != -1) return rb;
-    }
-    const int rc = d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);
+    // split-bf16 kernels (convbf.hip) first: the wide layers (with the same split-K plan: its slabs are reduced below), opt-in 12-channel ones
+    int rc = bnerv_convbf_try(st, d, ka.vec, ka.ksplit, ka.chunks_per_split);
+    if (rc == -1) rc = d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);
     if (rc != BNERV_OK || ka.ksplit == 1) return rc;
     return bnerv_reduce_slabs(stream, d.partial, ka.ksplit, d.B * d.Cout * d.H * d.W, d.out);
 }

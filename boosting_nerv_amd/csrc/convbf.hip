@@ -29,6 +29,7 @@ template <int KS> struct Geo {
 struct KArgs {
     bnerv_conv_desc d;
     int tiles_x, tiles_y, total_items;
+    int ksplit, cps;                       // wide kernel, EP_PLAIN: the K chunks are split over `ksplit` work items of `cps` chunks, each writing its slab of d.partial
     unsigned magic_tiles, magic_tiles_x;   // floor(2^32 / n) + 1: a / n == umulhi(a, magic) for a * n < 2^32
 };
 
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(256) void bf_wprep_kernel(const float* __restrict__
     }
 }
 
-struct WItem { int g, b, ty, tx; };
+struct WItem { int g, b, ty, tx, sp; };
 
 // PS2 = 2: the output goes through PixelShuffle(2) (conv channel 4c + 2i + j at (y, x) -> out[c][2y + i][2x + j]; the up-convs) with
 // paired 16-B stores; PS2 = 3: PixelShuffle(s), s = out_s in {3, 5}, with four 4-B stores s columns apart per accumulator quad.
@@ -660,8 +661,10 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
         const int rest = fast_div(i, ka.magic_tiles), t = i - rest * tiles;
         w.ty = fast_div(t, ka.magic_tiles_x);
         w.tx = t - w.ty * tiles_x;
-        w.g = rest / d.B;
-        w.b = rest - w.g * d.B;
+        const int q = rest / d.B;
+        w.b = rest - q * d.B;
+        w.sp = q / ngroups;                                // (split slowest: the splits of one tile run far apart, their slabs meet in reduce_slabs)
+        w.g = q - w.sp * ngroups;
         return w;
     };
 
@@ -680,7 +683,8 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
     const unsigned in_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
     const unsigned out_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, in_bytes);
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.out, 0, out_bytes);
+    const bool ksplit_on = EP == BNERV_EP_PLAIN && ka.ksplit > 1;
+    const __amdgpu_buffer_rsrc_t ro = ksplit_on ? make_rsrc(d.partial, 0, out_bytes * (unsigned)ka.ksplit) : make_rsrc(d.out, 0, out_bytes);
     const __amdgpu_buffer_rsrc_t ro2 = make_rsrc(((EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) && d.out2) ? d.out2 : d.out, 0, out_bytes);
     const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(d.aux0 ? d.aux0 : d.out, 0, out_bytes);
     const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(d.aux1 ? d.aux1 : d.out, 0, out_bytes);
@@ -823,9 +827,12 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
 #pragma unroll
     for (int n = 0; n < NTB; ++n) scl[n] = 0.f;
     if constexpr (AFF) { load_affine(it.b); aff_b = it.b; }
-    issue(it, 0);
+    // K chunks of an item: all of them, or -- split-K, EP_PLAIN -- the item's `cps` chunks from sp * cps on
+    auto c_first = [&](const WItem& a) __attribute__((always_inline)) { return a.sp * ka.cps; };
+    auto c_stop = [&](const WItem& a) __attribute__((always_inline)) { return min(nck, a.sp * ka.cps + ka.cps); };
+    issue(it, c_first(it));
     lds_barrier();                                         // zeroed s_a and the affine table visible
-    commit(it, 0);
+    commit(it, c_first(it));
     WItem prev = it;
     bool have_prev = false;
     while (itx < r1) {
@@ -837,12 +844,13 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
         const bool has_next_item = itx + nlb < r1;
         WItem nxt = it;
         if (has_next_item) nxt = decode(itx + nlb);
-        for (int c = 0; c < nck; ++c) {
-            const bool last_chunk = c == nck - 1;
+        const int c_lo = c_first(it), c_hi = c_stop(it), c_nxt = c_first(nxt);
+        for (int c = c_lo; c < c_hi; ++c) {
+            const bool last_chunk = c == c_hi - 1;
             const bool more = !last_chunk || has_next_item;
             lds_barrier();                                 // (A) this stage's s_a / s_b (and s_red of the previous item) visible
-            if (more) issue(last_chunk ? nxt : it, last_chunk ? 0 : c + 1);
-            if constexpr (RED) { if (c == 0 && have_prev) flush_partials(prev); }
+            if (more) issue(last_chunk ? nxt : it, last_chunk ? c_nxt : c + 1);
+            if constexpr (RED) { if (c == c_lo && have_prev) flush_partials(prev); }
             {
                 // Fragment pipeline.  Phase = (K step, pair of M tiles), ten per stage.  A fragments of the next phase are read (second
                 // register set) before this phase's products are issued.  B fragments are shared by the two phases of a step and stay
@@ -894,7 +902,7 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
                 if constexpr (AFF) {
                     if (last_chunk && nxt.b != aff_b) { load_affine(nxt.b); lds_barrier(); aff_b = nxt.b; }
                 }
-                commit(last_chunk ? nxt : it, last_chunk ? 0 : c + 1);
+                commit(last_chunk ? nxt : it, last_chunk ? c_nxt : c + 1);
             }
         }
         // ---- epilogue straight from the accumulators, one cout tile after the other
@@ -906,7 +914,7 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
             bool okm[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                so[m] = (unsigned)((((it.b * Cout) * H + ty0 + 2 * wave + (m >> 1)) * W + tx0 + (m & 1) * 16) * 4);
+                so[m] = (unsigned)((((it.b * Cout) * H + ty0 + 2 * wave + (m >> 1)) * W + tx0 + (m & 1) * 16) * 4) + (ksplit_on ? (unsigned)it.sp * out_bytes : 0u);
                 okm[m] = full || (ty0 + 2 * wave + (m >> 1) < H && tx0 + (m & 1) * 16 + 4 * kq < W);
             }
             float ps[NTB], pt[NTB];
@@ -1086,10 +1094,10 @@ int launch_bfw(hipStream_t st, KArgs& ka) {
     hipLaunchKernelGGL(bf_wprep_kernel<NS>, dim3(cdiv(nfrag, 256)), dim3(256), 0, st, d.w, reinterpret_cast<u32x4*>(scratch),
                        d.wCo, d.wCi, d.transposed, d.Cin, d.Cout, nck, NTB, nfrag);
     BNERV_LAUNCH_CHECK("bf_wprep");
-    ka.total_items = ngroups * d.B * ka.tiles_x * ka.tiles_y;
+    ka.total_items = ka.ksplit * ngroups * d.B * ka.tiles_x * ka.tiles_y;
     ka.magic_tiles = div_magic(ka.tiles_x * ka.tiles_y);
     ka.magic_tiles_x = div_magic(ka.tiles_x);
-    const size_t lds = (size_t)NS * BG::PIECE + (size_t)NTB * BG::STEPS * NS * 1024 + (size_t)(4 * 2 * NTB * 16 + 2 * ((d.Cin + 15) & ~15)) * sizeof(float);
+    const size_t lds = (size_t)NS * BG::PIECE + (size_t)NTB * BG::STEPS * NS * 1024 + (size_t)(4 * 2 * NTB * 16 + ((IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE) ? 2 * ((d.Cin + 15) & ~15) : 0)) * sizeof(float);   // (affine table only where there is an affine prologue)
     // LDS depends on the layer through the affine table (2 x Cin floats): occupancy is looked up per distinct size
     static size_t attr_lds = 0, occ_lds = 0;
     static int blocks_per_cu = 0;
@@ -1121,7 +1129,7 @@ int launch_bfw_ntb(hipStream_t st, KArgs& ka) {
     const int tiles = ka.d.B * ka.tiles_x * ka.tiles_y;
     int min_items = 128;
     if (const char* e = getenv("BNERV_SPLIT_WIDE_MIN_ITEMS")) min_items = atoi(e);     // tests set 1 to keep the widest blocks on small shapes
-    while (ntb > 1 && cdiv(nt, ntb) * tiles < min_items) --ntb;
+    while (ntb > 1 && ka.ksplit * cdiv(nt, ntb) * tiles < min_items) --ntb;
     if (ntb == 1) return launch_bfw<IN, EP, SP, 1, PS2>(st, ka);
     if (ntb == 2) return launch_bfw<IN, EP, SP, 2, PS2>(st, ka);
     return launch_bfw<IN, EP, SP, 3, PS2>(st, ka);
@@ -1168,8 +1176,9 @@ extern "C" int bnerv_debug_trace_read_bf(void* host) { return (int)hipMemcpyFrom
 
 // Called by bnerv_conv_igemm (conv.hip) after argument validation.  Returns -1 when the shape / mode is not this kernel's
 // (the caller then takes its f32-MFMA kernels), otherwise the launch status.
-int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec) {
+int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec, int ksplit, int chunks_per_split) {
     if (!vec || d.in_mode == BNERV_IN_TANHGRAD) return -1;
+    if (ksplit > 1 && (d.ep_mode != BNERV_EP_PLAIN || !d.partial || d.out_s != 1)) return -1;
     const bool shuffled = d.out_s != 1 || d.in_mode == BNERV_IN_UNSHUFFLE;                // up-conv forward / its data gradient
     if (d.out_s != 1 && !((d.out_s == 2 || d.out_s == 3 || d.out_s == 5) && d.Cout % (d.out_s * d.out_s) == 0)) return -1;
     if ((size_t)d.B * d.Cout * d.H * d.W * 4 >= LEAN_MAX_BYTES) return -1;      // (the shuffled output is addressed as one buffer)
@@ -1180,9 +1189,12 @@ int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec) {
     ka.d = d;
     ka.tiles_x = cdiv(d.W, TW);
     ka.tiles_y = cdiv(d.H, TH);
+    ka.ksplit = ksplit > 1 ? ksplit : 1;
+    ka.cps = ksplit > 1 ? chunks_per_split : cdiv(d.Cin, 16);
+    if ((size_t)ka.ksplit * d.B * d.Cout * d.H * d.W * 4 >= LEAN_MAX_BYTES) return -1;
     const bool narrow = d.Cout <= 16 && d.Cin <= 16 && !shuffled;
     if (narrow) {                                          // one cout tile, one K chunk: opt-in (see split_mode)
-        if (split_mode() < 0 || d.Cin <= 8 || d.wCo > 16 || d.wCi > 16) return -1;
+        if (split_mode() < 0 || ksplit > 1 || d.Cin <= 8 || d.wCo > 16 || d.wCi > 16) return -1;
         return d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);
     }
     // several cout tiles and / or K chunks: the wide kernel, where the image is big enough to fill the chip with its work items

@@ -582,7 +582,7 @@ def test_wide_split_conv_kernel_tat_block(ops, shape, min_items, monkeypatch):
 
 
 @pytest.mark.parametrize("min_items", ["1", "128"])
-@pytest.mark.parametrize("case", [(1, 38, 38, 24, 64), (1, 70, 18, 8, 32), (2, 55, 55, 17, 36), (1, 20, 95, 9, 32), (1, 95, 12, 16, 32), (2, 46, 64, 22, 132)])
+@pytest.mark.parametrize("case", [(1, 38, 38, 24, 64), (1, 70, 18, 8, 32), (2, 55, 55, 17, 36), (1, 20, 95, 9, 32), (1, 95, 12, 16, 32), (2, 46, 64, 22, 132), (1, 30, 160, 8, 32)])   # (last: split-K data gradient)
 def test_wide_split_conv_kernel_plain(ops, case, min_items, monkeypatch):
     """Same kernel through conv2d_ps (plain -> bias forward, plain data gradient) and the sin block conv, incl. Cout <= 16 with several
     K chunks and Cin <= 16 with several cout tiles."""
@@ -604,7 +604,7 @@ def test_wide_split_conv_kernel_plain(ops, case, min_items, monkeypatch):
 
 
 @pytest.mark.parametrize("min_items", ["1", "128"])
-@pytest.mark.parametrize("case", [(1, 12, 48, 16, 32), (2, 38, 152, 9, 32), (1, 20, 36, 17, 40), (1, 46, 184, 8, 32), (1, 22, 88, 14, 100)])
+@pytest.mark.parametrize("case", [(1, 12, 48, 16, 32), (2, 38, 152, 9, 32), (1, 20, 36, 17, 40), (1, 46, 184, 8, 32), (1, 22, 88, 14, 100), (1, 24, 256, 8, 32)])   # (last: split-K data gradient)
 def test_wide_split_conv_kernel_upconv_ps2(ops, case, min_items, monkeypatch):
     """Up-conv + PixelShuffle(2) through the wide split kernel: forward with the pair-up epilogue (plain and sin/cos), data gradient
     through the unshuffle(2) prologue; whole SNeRV block as well (its up-conv, TAT convs and every gradient)."""
@@ -637,7 +637,8 @@ def test_wide_split_conv_kernel_upconv_ps2(ops, case, min_items, monkeypatch):
 
 
 @pytest.mark.parametrize("min_items", ["1", "128"])
-@pytest.mark.parametrize("case", [(1, 20, 45, 9, 32, 3), (1, 17, 50, 8, 32, 5), (2, 40, 90, 14, 100, 3), (1, 33, 175, 11, 36, 5), (1, 79, 594, 10, 32, 3)])
+@pytest.mark.parametrize("case", [(1, 20, 45, 9, 32, 3), (1, 17, 50, 8, 32, 5), (2, 40, 90, 14, 100, 3), (1, 33, 175, 11, 36, 5), (1, 79, 594, 10, 32, 3),
+                                  (1, 40, 288, 9, 32, 3)])   # (the last two: data gradients with >= 8 K chunks on few tiles -> the split-K plan)
 def test_wide_split_conv_kernel_upconv_ps35(ops, case, min_items, monkeypatch):
     """Up-conv + PixelShuffle(3 / 5) forward through the wide split kernel's scatter-store epilogue (plain and sin / cos), gradients
     through the kernels that own them."""
