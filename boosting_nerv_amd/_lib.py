@@ -105,6 +105,11 @@ SYMBOLS = {
     "bnerv_ctx_destroy": (None, [_V]),
     "bnerv_ctx_scratch_bytes": (_Z, [_V]),
     "bnerv_ctx_reserve": (_I, [_V, _Z]),
+    "bnerv_ctx_wplan_record": (_I, [_V]),
+    "bnerv_ctx_wplan_freeze": (_I, [_V]),
+    "bnerv_ctx_wplan_run": (_I, [_V, _V]),
+    "bnerv_ctx_wplan_end": (_I, [_V]),
+    "bnerv_ctx_wplan_entries": (_I, [_V]),
     "bnerv_reduce_slabs_deferred": (_I, [_V, _V, _V, _I, _I, _V]),
     "bnerv_flush_deferred": (_I, [_V, _V]),
     "bnerv_deferred_pending": (_I, [_V]),
@@ -145,7 +150,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class BnervError(RuntimeError):
@@ -219,17 +224,54 @@ class StreamContext:
 
 
 _contexts = {}
+_ctx_override = []      # innermost last.  A module-level stack on purpose (not thread-local): autograd runs backward on its own thread
+
+
+def _device_scratch_bytes(dev):
+    return max([load().bnerv_ctx_scratch_bytes(o.handle) for (d, _), o in _contexts.items() if d == dev] or [0])
+
+
+def new_ctx():
+    """A private context for whoever captures a graph (engine.TrainStep / DecodeGraph): its scratch is reserved to what the
+    device's stream contexts have grown to (a capture cannot allocate), and its weight-fragment plan -- whose arena the captured
+    kernels read -- lives and dies with its owner, whatever torch's stream pool hands out to other users later."""
+    c = StreamContext()
+    reserve_ctx(c)
+    return c
+
+
+def reserve_ctx(c):
+    want = _device_scratch_bytes(torch.cuda.current_device())
+    if want:
+        check(load().bnerv_ctx_reserve(c.handle, want), "bnerv_ctx_reserve")
+
+
+class use_ctx:
+    """with use_ctx(c): every library call made meanwhile (forward, backward) names context c instead of the current stream's.
+    The caller keeps all of that work on ONE stream."""
+
+    def __init__(self, c):
+        self.c = c
+
+    def __enter__(self):
+        _ctx_override.append(self.c)
+        return self.c
+
+    def __exit__(self, *exc):
+        _ctx_override.pop()
 
 
 def ctx():
-    """Context of torch's current stream (created on first use; one per (device, stream)).  A new context reserves the scratch
-    the other contexts of its device have grown to: a stream that is about to be captured into a graph cannot allocate, so whoever
-    captures touches ctx() on that stream first (engine.TrainStep._capture does)."""
+    """Context of torch's current stream (created on first use; one per (device, stream)) unless a use_ctx block is open.  A new
+    context reserves the scratch the other contexts of its device have grown to: a stream that is about to be captured into a
+    graph cannot allocate."""
+    if _ctx_override:
+        return _ctx_override[-1]
     st = torch.cuda.current_stream()
     key = (st.device_index, st.cuda_stream)
     c = _contexts.get(key)
     if c is None:
-        want = max([load().bnerv_ctx_scratch_bytes(o.handle) for (dev, _), o in _contexts.items() if dev == st.device_index] or [0])
+        want = _device_scratch_bytes(st.device_index)
         c = _contexts[key] = StreamContext()
         if want:
             check(load().bnerv_ctx_reserve(c.handle, want), "bnerv_ctx_reserve")

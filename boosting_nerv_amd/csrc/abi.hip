@@ -88,6 +88,7 @@ extern "C" int bnerv_ctx_create(bnerv_ctx** out) {
 }
 extern "C" void bnerv_ctx_destroy(bnerv_ctx* ctx) {
     if (ctx && ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx) bnerv_wplan_free(ctx);
     delete ctx;
 }
 

@@ -587,32 +587,85 @@ int launch_bf(hipStream_t st, KArgs& ka) {
 // Modes: bf16x6 (default) and bf16x3; the scaled f16 mode is not built for this kernel.
 constexpr int AFF_MAX = 512;                                // affine table: 2 x (Cin rounded up to 16) floats of LDS, sized per layer
 
+// one 16-B fragment slot-lane (group, chunk, tile, step, lane (q, n)): gathers its 8 k-elements from the OIHW array, splits them and
+// writes the NS pieces -- every slot is written (zeros where the layer has no channel / tap), so the buffer needs no clearing pass
+template <int NS>
+__device__ __forceinline__ void wprep_slot(const float* __restrict__ w, u32x4* __restrict__ frag, int wCi, int transposed, int Cin, int Cout,
+                                           int nck, int ntb, int f) {
+    const int lane = f & 63, rest = f >> 6;
+    const int st = rest % 5, r2 = rest / 5;
+    const int nl = r2 % ntb, gc = r2 / ntb;
+    const int c = gc % nck, g = gc / nck;
+    const int n = lane & 15, q = lane >> 4;
+    const int co = (g * ntb + nl) * 16 + n, tg = 2 * st + (q >> 1), ci0 = 16 * c + 8 * (q & 1);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = ci0 + e;
+        float v = 0.f;
+        if (co < Cout && ci < Cin && tg < 9) v = transposed ? w[((size_t)ci * wCi + co) * 9 + (8 - tg)] : w[((size_t)co * wCi + ci) * 9 + tg];
+        x[e] = v;
+    }
+    u32x4 pc[NS];
+    split8<NS == 3 ? SP_BF16X6 : SP_BF16X3, 8>(x, pc);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) frag[((size_t)rest * NS + p) * 64 + lane] = pc[p];
+}
+
 template <int NS>
 __global__ __launch_bounds__(256) void bf_wprep_kernel(const float* __restrict__ w, u32x4* __restrict__ frag, int wCo, int wCi, int transposed,
                                                        int Cin, int Cout, int nck, int ntb, int nfrag) {
-    // one thread per 16-B fragment slot-lane (group, chunk, tile, step, lane (q, n)): gathers its 8 k-elements from the OIHW array,
-    // splits them and writes the NS pieces -- every slot is written (zeros where the layer has no channel / tap), so the scratch
-    // needs no clearing pass
-    for (int f = blockIdx.x * 256 + threadIdx.x; f < nfrag; f += gridDim.x * 256) {
-        const int lane = f & 63, rest = f >> 6;
-        const int st = rest % 5, r2 = rest / 5;
-        const int nl = r2 % ntb, gc = r2 / ntb;
-        const int c = gc % nck, g = gc / nck;
-        const int n = lane & 15, q = lane >> 4;
-        const int co = (g * ntb + nl) * 16 + n, tg = 2 * st + (q >> 1), ci0 = 16 * c + 8 * (q & 1);
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ci = ci0 + e;
-            float v = 0.f;
-            if (co < Cout && ci < Cin && tg < 9) v = transposed ? w[((size_t)ci * wCi + co) * 9 + (8 - tg)] : w[((size_t)co * wCi + ci) * 9 + tg];
-            x[e] = v;
-        }
-        u32x4 pc[NS];
-        split8<NS == 3 ? SP_BF16X6 : SP_BF16X3, 8>(x, pc);
-#pragma unroll
-        for (int p = 0; p < NS; ++p) frag[((size_t)rest * NS + p) * 64 + lane] = pc[p];
-    }
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < nfrag; f += gridDim.x * 256) wprep_slot<NS>(w, frag, wCi, transposed, Cin, Cout, nck, ntb, f);
+}
+
+// ---- weight-fragment plan of a repeated step (include/bnerv.h, bnerv_ctx_wplan_*): the fragments of every wide conv call of the
+// step in ONE launch at its start (the weights do not change between the first forward conv and the last data gradient), instead of
+// one small launch in front of each call (C1: 12, C3 / C4: ~50 launches of 3-6 us per step, each a pipeline drain of its own)
+struct WPlanEntry {
+    const float* w;
+    unsigned long long slot0;                              // first 16-B slot of the entry in the arena
+    int wCo, wCi, transposed, Cin, Cout, nck, ntb, nfrag, ns, block0;
+};
+}  // namespace
+struct BfWPlan {
+    int state = 0;                                         // 0: none, 1: recording, 2: frozen
+    bool live = false;                                     // between wplan_run and wplan_end: the arena holds the current weights' fragments
+    std::vector<WPlanEntry> e;
+    u32x4* arena = nullptr;
+    WPlanEntry* table = nullptr;
+    int* blockmap = nullptr;
+    int blocks = 0;
+};
+namespace {
+
+__global__ __launch_bounds__(256) void bf_wprep_plan_kernel(const WPlanEntry* __restrict__ table, const int* __restrict__ blockmap, u32x4* __restrict__ arena) {
+    const WPlanEntry e = table[blockmap[blockIdx.x]];
+    const int f = ((int)blockIdx.x - e.block0) * 256 + threadIdx.x;
+    if (f >= e.nfrag) return;
+    if (e.ns == 3) wprep_slot<3>(e.w, arena + e.slot0, e.wCi, e.transposed, e.Cin, e.Cout, e.nck, e.ntb, f);
+    else wprep_slot<2>(e.w, arena + e.slot0, e.wCi, e.transposed, e.Cin, e.Cout, e.nck, e.ntb, f);
+}
+
+static bool wplan_same(const WPlanEntry& a, const bnerv_conv_desc& d, int nck, int ntb, int ns) {
+    return a.w == d.w && a.wCo == d.wCo && a.wCi == d.wCi && a.transposed == d.transposed && a.Cin == d.Cin && a.Cout == d.Cout && a.nck == nck &&
+           a.ntb == ntb && a.ns == ns;
+}
+// the arena fragments of this call, or nullptr (no live plan / no matching entry)
+static const u32x4* wplan_lookup(const bnerv_ctx* ctx, const bnerv_conv_desc& d, int nck, int ntb, int ns) {
+    const BfWPlan* p = ctx ? ctx->wplan : nullptr;
+    if (!p || p->state != 2 || !p->live) return nullptr;
+    for (const WPlanEntry& a : p->e)
+        if (wplan_same(a, d, nck, ntb, ns)) return p->arena + a.slot0;
+    return nullptr;
+}
+static void wplan_note(bnerv_ctx* ctx, const bnerv_conv_desc& d, int nck, int ntb, int ns, int nfrag) {
+    BfWPlan* p = ctx ? ctx->wplan : nullptr;
+    if (!p || p->state != 1) return;
+    for (const WPlanEntry& a : p->e)
+        if (wplan_same(a, d, nck, ntb, ns)) return;
+    WPlanEntry a{};
+    a.w = d.w; a.wCo = d.wCo; a.wCi = d.wCi; a.transposed = d.transposed; a.Cin = d.Cin; a.Cout = d.Cout; a.nck = nck; a.ntb = ntb; a.nfrag = nfrag; a.ns = ns;
+    p->e.push_back(a);
 }
 
 struct WItem { int g, b, ty, tx, sp; };
@@ -1088,12 +1141,17 @@ int launch_bfw(hipStream_t st, KArgs& ka) {
     const bnerv_conv_desc& d = ka.d;
     const int nck = cdiv(d.Cin, 16), ngroups = cdiv(cdiv(d.Cout, 16), NTB);
     const size_t slots = (size_t)ngroups * nck * NTB * BG::STEPS * NS * 64;
-    void* scratch = bnerv_ctx_scratch(d.ctx, slots * 16, st);
-    if (!scratch) return -1;                               // no context, or it would have to grow inside a graph capture: f32 kernels
     const int nfrag = ngroups * nck * NTB * BG::STEPS * 64;
-    hipLaunchKernelGGL(bf_wprep_kernel<NS>, dim3(cdiv(nfrag, 256)), dim3(256), 0, st, d.w, reinterpret_cast<u32x4*>(scratch),
-                       d.wCo, d.wCi, d.transposed, d.Cin, d.Cout, nck, NTB, nfrag);
-    BNERV_LAUNCH_CHECK("bf_wprep");
+    const void* scratch = wplan_lookup(d.ctx, d, nck, NTB, NS);      // a live plan prepared this call's fragments at the start of the step
+    if (!scratch) {
+        void* own = bnerv_ctx_scratch(d.ctx, slots * 16, st);
+        if (!own) return -1;                               // no context, or it would have to grow inside a graph capture: f32 kernels
+        hipLaunchKernelGGL(bf_wprep_kernel<NS>, dim3(cdiv(nfrag, 256)), dim3(256), 0, st, d.w, reinterpret_cast<u32x4*>(own),
+                           d.wCo, d.wCi, d.transposed, d.Cin, d.Cout, nck, NTB, nfrag);
+        BNERV_LAUNCH_CHECK("bf_wprep");
+        wplan_note(d.ctx, d, nck, NTB, NS, nfrag);
+        scratch = own;
+    }
     ka.total_items = ka.ksplit * ngroups * d.B * ka.tiles_x * ka.tiles_y;
     ka.magic_tiles = div_magic(ka.tiles_x * ka.tiles_y);
     ka.magic_tiles_x = div_magic(ka.tiles_x);
@@ -1169,6 +1227,76 @@ int launch_wide_mode(hipStream_t st, KArgs& ka) {
 }
 
 }  // namespace
+
+// ---- plan API (include/bnerv.h)
+static void wplan_release_device(BfWPlan* p) {
+    if (p->arena) (void)hipFree(p->arena);
+    if (p->table) (void)hipFree(p->table);
+    if (p->blockmap) (void)hipFree(p->blockmap);
+    p->arena = nullptr; p->table = nullptr; p->blockmap = nullptr; p->blocks = 0;
+}
+void bnerv_wplan_free(bnerv_ctx* ctx) {
+    if (!ctx || !ctx->wplan) return;
+    wplan_release_device(ctx->wplan);
+    delete ctx->wplan;
+    ctx->wplan = nullptr;
+}
+extern "C" int bnerv_ctx_wplan_record(bnerv_ctx* ctx) {
+    BNERV_REQUIRE(ctx != nullptr, "ctx_wplan_record: null context");
+    if (!ctx->wplan) ctx->wplan = new (std::nothrow) BfWPlan();
+    BNERV_REQUIRE(ctx->wplan != nullptr, "ctx_wplan_record: out of memory");
+    BfWPlan* p = ctx->wplan;
+    if (p->arena) {                                        // a previous plan's arena may still be read by work in flight
+        if (hipDeviceSynchronize() != hipSuccess) return bnerv_set_error(BNERV_E_LAUNCH, "ctx_wplan_record: device synchronize failed");
+        wplan_release_device(p);
+    }
+    p->e.clear();
+    p->live = false;
+    p->state = 1;
+    return BNERV_OK;
+}
+extern "C" int bnerv_ctx_wplan_freeze(bnerv_ctx* ctx) {
+    BNERV_REQUIRE(ctx != nullptr && ctx->wplan != nullptr && ctx->wplan->state == 1, "ctx_wplan_freeze: no recording in progress");
+    BfWPlan* p = ctx->wplan;
+    p->state = 0;
+    p->live = false;
+    if (p->e.empty()) return 0;
+    unsigned long long slots = 0;
+    int blocks = 0;
+    for (WPlanEntry& a : p->e) {
+        a.slot0 = slots; a.block0 = blocks;
+        slots += (unsigned long long)(a.nfrag >> 6) * a.ns * 64;
+        blocks += cdiv(a.nfrag, 256);
+    }
+    std::vector<int> map((size_t)blocks);
+    for (size_t i = 0; i < p->e.size(); ++i)
+        for (int b = 0; b < cdiv(p->e[i].nfrag, 256); ++b) map[(size_t)p->e[i].block0 + b] = (int)i;
+    const size_t tbytes = p->e.size() * sizeof(WPlanEntry), mbytes = map.size() * sizeof(int);
+    if (hipMalloc(reinterpret_cast<void**>(&p->arena), (size_t)slots * 16) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&p->table), tbytes) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&p->blockmap), mbytes) != hipSuccess || hipMemcpy(p->table, p->e.data(), tbytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->blockmap, map.data(), mbytes, hipMemcpyHostToDevice) != hipSuccess) {
+        wplan_release_device(p);
+        p->e.clear();
+        return bnerv_set_error(BNERV_E_WS, "ctx_wplan_freeze: cannot allocate the fragment arena (%llu bytes)", slots * 16ull);
+    }
+    p->blocks = blocks;
+    p->state = 2;
+    return (int)p->e.size();
+}
+extern "C" int bnerv_ctx_wplan_run(bnerv_ctx* ctx, void* stream) {
+    BNERV_REQUIRE(ctx != nullptr, "ctx_wplan_run: null context");
+    BfWPlan* p = ctx->wplan;
+    if (!p || p->state != 2 || p->blocks == 0) return BNERV_OK;       // nothing planned: every call prepares its own fragments
+    hipLaunchKernelGGL(bf_wprep_plan_kernel, dim3(p->blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p->table, p->blockmap, p->arena);
+    BNERV_LAUNCH_CHECK("bf_wprep_plan");
+    p->live = true;
+    return BNERV_OK;
+}
+extern "C" int bnerv_ctx_wplan_end(bnerv_ctx* ctx) {
+    if (ctx && ctx->wplan) ctx->wplan->live = false;
+    return BNERV_OK;
+}
+extern "C" int bnerv_ctx_wplan_entries(const bnerv_ctx* ctx) { return (ctx && ctx->wplan && ctx->wplan->state == 2) ? (int)ctx->wplan->e.size() : 0; }
 
 #ifdef BNERV_TRACE
 extern "C" int bnerv_debug_trace_read_bf(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_bf), sizeof(g_trace_bf)); }

@@ -35,7 +35,9 @@ struct bnerv_ctx {
     std::vector<SideJob> queue;          // deferred slab reductions of ONE stream, in issue order
     void* scratch = nullptr;             // pre-split weight fragments of the wide split conv kernels (reused call after call:
     size_t scratch_bytes = 0;            //  stream order keeps a call's fragments alive until its kernel has read them)
+    struct BfWPlan* wplan = nullptr;     // weight-fragment plan of a captured step (convbf.hip; bnerv_ctx_wplan_* in include/bnerv.h)
 };
+void bnerv_wplan_free(bnerv_ctx* ctx);   // convbf.hip: releases the plan and its device buffers (called by bnerv_ctx_destroy)
 // >= `bytes` of device scratch owned by the context, or nullptr when there is no context / the buffer would have to grow while
 // `st` is being captured into a graph (allocation is illegal there: the first, eager calls size it)
 void* bnerv_ctx_scratch(bnerv_ctx* ctx, size_t bytes, hipStream_t st);

@@ -37,6 +37,7 @@ class TrainStep:
         # group, so the path the scaling runs take can be tested on a single-GPU box
         self.bucket = GradBucket(model.parameters(), process_group, force=force_bucket) if (world_size > 1 or force_bucket) else None
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self._wplan_entries = 0                              # entries of the capture stream context's weight-fragment plan
 
     # ---- pieces -------------------------------------------------------------------------------------------------------
     def _fwd_bwd(self):
@@ -49,6 +50,42 @@ class TrainStep:
         img_out.backward(grad)
         self.loss_out = loss
         self.psnr_out = stats[:, 4]
+
+    def _planned_fwd_bwd(self):
+        """_fwd_bwd inside a capture: the weight fragments of every wide split conv call of the step come from ONE launch at the
+        start (the context's frozen plan, include/bnerv.h bnerv_ctx_wplan_*) -- the weights only change in the Adan launch after
+        backward.  Without a plan this is _fwd_bwd."""
+        from . import _lib as L
+        if not self._wplan_entries:
+            return self._fwd_bwd()
+        lib, c = L.load(), L.ctx()
+        L.check(lib.bnerv_ctx_wplan_run(c.handle, L.stream()), "bnerv_ctx_wplan_run")
+        try:
+            self._fwd_bwd()
+        finally:
+            lib.bnerv_ctx_wplan_end(c.handle)
+
+    def _record_wplan(self):
+        """One forward + backward on the capture stream, eager, with the stream context recording which weight tensors the wide split
+        convs split (gradients are discarded: the next _fwd_bwd starts with zero_grad; no parameter or optimizer state changes).
+        Only the plain step: a step whose forward draws random numbers (CompressionStep) would advance its generator here."""
+        import os
+        from . import _lib as L
+        self._wplan_entries = 0
+        if type(self) is not TrainStep or os.environ.get("BNERV_WPLAN", "1") == "0":
+            return
+        lib = L.load()
+        with torch.cuda.stream(self._cap_stream), L.use_ctx(self._cap_ctx) as c:
+            L.check(lib.bnerv_ctx_wplan_record(c.handle), "bnerv_ctx_wplan_record")
+            try:
+                self._fwd_bwd()
+            finally:
+                n = lib.bnerv_ctx_wplan_freeze(c.handle)
+            if n < 0:
+                L.check(n, "bnerv_ctx_wplan_freeze")
+            self._wplan_entries = n
+        self.opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
 
     def _eager(self):
         self._fwd_bwd()
@@ -78,21 +115,29 @@ class TrainStep:
         self._opt_epoch = getattr(self.opt, "state_epoch", 0)
         pool = torch.cuda.graph_pool_handle()
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), None
-        # capture on a stream of our own whose library context exists -- and has its scratch reserved -- BEFORE the capture starts
+        # capture on a stream of our own with a library context of our own, whose scratch is reserved BEFORE the capture starts
         # (nothing may allocate inside it; the eager warm-up steps on the current stream sized the scratch)
         if getattr(self, "_cap_stream", None) is None:
             self._cap_stream = torch.cuda.Stream(device=self.dev)
-        with torch.cuda.stream(self._cap_stream):
-            L.ctx()
+            self._cap_ctx = L.new_ctx()
+        else:
+            L.reserve_ctx(self._cap_ctx)
+        with L.use_ctx(self._cap_ctx):
+            self._capture_in_ctx(pool)
+
+    def _capture_in_ctx(self, pool):
+        import os
+        import torch.distributed as dist
+        self._record_wplan()
         cap = dict(pool=pool, stream=self._cap_stream)
         if self.bucket is None:
             with torch.cuda.graph(self.graph_a, **cap):
-                self._fwd_bwd()
+                self._planned_fwd_bwd()
                 self.opt.launch_step()
             return
 
         def head():
-            self._fwd_bwd()
+            self._planned_fwd_bwd()
             for p in self.params:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
@@ -214,16 +259,39 @@ class DecodeGraph:
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
+        import os
+        from . import _lib as L
+        lib = L.load()
+        self._ctx = L.new_ctx()
+        plan = os.environ.get("BNERV_WPLAN", "1") != "0"
         try:
-            with torch.no_grad(), torch.cuda.stream(side):
-                for _ in range(2):                          # warm-up: workspaces and lazily built tables exist before capture
-                    model(self.inp, self.embed, norm_idx=self.norm)
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph, stream=side):
-                    self.out = model(self.inp, self.embed, norm_idx=self.norm)[0]
+            with torch.no_grad(), torch.cuda.stream(side), L.use_ctx(self._ctx) as c:
+                # warm-up: workspaces and lazily built tables exist before capture; the first one records which weight tensors the
+                # wide split convs split.  A decoder's weights are fixed, so their 16-bit fragments are prepared ONCE, here
+                # (bnerv_ctx_wplan_*), and the captured forward launches no preparation at all; refresh() after a weight change.
+                if plan:
+                    L.check(lib.bnerv_ctx_wplan_record(c.handle), "bnerv_ctx_wplan_record")
+                model(self.inp, self.embed, norm_idx=self.norm)
+                self.wplan_entries = lib.bnerv_ctx_wplan_freeze(c.handle) if plan else 0
+                if self.wplan_entries < 0:
+                    L.check(self.wplan_entries, "bnerv_ctx_wplan_freeze")
+                model(self.inp, self.embed, norm_idx=self.norm)
+                L.check(lib.bnerv_ctx_wplan_run(c.handle, L.stream()), "bnerv_ctx_wplan_run")
+                try:
+                    self.graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph, stream=side):
+                        self.out = model(self.inp, self.embed, norm_idx=self.norm)[0]
+                finally:
+                    lib.bnerv_ctx_wplan_end(c.handle)
         finally:
             model.time_decode = td
             cur.wait_stream(side)
+
+    def refresh(self):
+        """Re-prepare the weight fragments the captured forward reads (one launch) after the model's weights were written."""
+        from . import _lib as L
+        L.check(L.load().bnerv_ctx_wplan_run(self._ctx.handle, L.stream()), "bnerv_ctx_wplan_run")
+        L.load().bnerv_ctx_wplan_end(self._ctx.handle)
 
     def matches(self, cur_input, embed, norm_idx):
         return (cur_input.shape == self.inp.shape and norm_idx.shape == self.norm.shape and

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BNERV_ABI_VERSION 3
+#define BNERV_ABI_VERSION 4
 
 #define BNERV_OK 0
 #define BNERV_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -126,6 +126,24 @@ void bnerv_ctx_destroy(bnerv_ctx* ctx);
  * bnerv_ctx_scratch_bytes(old_ctx)). */
 size_t bnerv_ctx_scratch_bytes(const bnerv_ctx* ctx);
 int bnerv_ctx_reserve(bnerv_ctx* ctx, size_t bytes);
+/* Weight-fragment plan of a repeated step (ABI 4).  Every wide split conv call (forward conv, up-conv, data gradient) is preceded
+ * by a small launch that splits its weight tensor into 16-bit matrix fragments; inside one train step the weights do not change
+ * between the first forward conv and the last data gradient (the optimizer runs after backward), so a step that is replayed as a
+ * graph can prepare ALL of them in one launch at its start:
+ *     bnerv_ctx_wplan_record(ctx);  <one forward + backward with this context, eager>;  n = bnerv_ctx_wplan_freeze(ctx);
+ *     per step (normally inside the capture):  bnerv_ctx_wplan_run(ctx, stream);  <forward, backward>;  bnerv_ctx_wplan_end(ctx);
+ * record: forget any previous plan and note, for every wide split conv call of this context, (weight pointer, layout, fragment
+ * geometry).  freeze: allocate one arena for the distinct entries (device synchronize; not inside a capture); returns their number
+ * (>= 0) or a negative error.  run: ONE launch that writes every entry's fragments from the CURRENT weights; from then until
+ * wplan_end, a conv call of this context whose weight pointer / geometry matches an entry reads the arena and launches no
+ * preparation of its own; calls that match nothing, and all calls outside run..end, behave as before (own preparation, scratch
+ * buffer).  The caller guarantees that the planned weight tensors are not written between run and end and that their addresses
+ * stay what they were at record time; the fragments are the same bits either way, so results do not depend on the plan. */
+int bnerv_ctx_wplan_record(bnerv_ctx* ctx);
+int bnerv_ctx_wplan_freeze(bnerv_ctx* ctx);
+int bnerv_ctx_wplan_run(bnerv_ctx* ctx, void* stream);
+int bnerv_ctx_wplan_end(bnerv_ctx* ctx);
+int bnerv_ctx_wplan_entries(const bnerv_ctx* ctx);     /* entries of the frozen plan (0: none) */
 int bnerv_reduce_slabs_deferred(bnerv_ctx* ctx, void* stream, const float* slabs, int n_slabs, int count, float* out);
 int bnerv_flush_deferred(bnerv_ctx* ctx, void* stream);
 int bnerv_deferred_pending(const bnerv_ctx* ctx);

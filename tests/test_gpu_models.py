@@ -244,6 +244,39 @@ def test_train_trajectory_matches_oracle(use_graph):
         assert d.mean().item() <= 2e-5, (k, d.mean().item())
 
 
+def test_weight_fragment_plan_changes_no_bit(monkeypatch):
+    """The captured step prepares the 16-bit weight fragments of all its wide split conv calls in ONE launch (context plan,
+    include/bnerv.h bnerv_ctx_wplan_*) instead of one small launch per call: same fragments, so losses and parameters after 6
+    steps (1 eager + capture + replays, moving data) are bit-equal to the step captured without a plan (BNERV_WPLAN=0)."""
+    from boosting_nerv_amd.engine import TrainStep
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    from boosting_nerv_amd.optimizer import Adan
+    from boosting_nerv_amd.synth import SyntheticVideo
+    monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    vid = SyntheticVideo(4, 180, 320)
+    fd = torch.stack([vid.frame(i) for i in range(4)]).to(DEV)
+    nd = torch.tensor([(i + 1) / 4 for i in range(4)], dtype=torch.float64).to(DEV)
+
+    def run(plan):
+        monkeypatch.setenv("BNERV_WPLAN", "1" if plan else "0")
+        torch.manual_seed(1)
+        model = NeRV_Boost(1, args=configs.tiny_nerv()).to(DEV)
+        opt = Adan(model.parameters(), lr=0.003)
+        step = TrainStep(model, opt, "Fusion10_freq", False, (1, 3, 180, 320), torch.device(DEV), use_graph=True, warmup_eager=1)
+        losses = []
+        for s in range(6):
+            loss, _ = step(fd[s % 4:s % 4 + 1], nd[s % 4:s % 4 + 1])
+            losses.append(loss.item())
+        assert step.graph_a is not None
+        return step._wplan_entries, losses, {k: v.detach().clone() for k, v in model.state_dict().items()}
+    n1, l1, sd1 = run(True)
+    n0, l0, sd0 = run(False)
+    assert n1 > 0 and n0 == 0, (n1, n0)
+    assert l1 == l0, (l1, l0)
+    for k in sd1:
+        assert torch.equal(sd1[k], sd0[k]), k
+
+
 def test_short_schedule_end_psnr_matches_oracle():
     """SURVEY 8(d) parity gate: train the tiny NeRV_Boost for 3 epochs over 6 synthetic frames with the cosine schedule, same
     init and frame order on both sides, then evaluate every frame: the end PSNR (mean over frames, fp32 model) of the HIP

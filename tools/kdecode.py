@@ -29,3 +29,15 @@ with torch.no_grad():
         g.replay()
     torch.cuda.synchronize()
     print(f"graph decode : {300 / (time.time() - t0):8.1f} frames/s   ({(time.time() - t0) / 300 * 1e3:.3f} ms/frame)")
+    # engine.DecodeGraph: the same captured forward with the decoder's weight fragments prepared once (context plan, ABI 4)
+    from boosting_nerv_amd.engine import DecodeGraph
+    embed = model(idx, norm_idx=idx)[1][0]
+    dg = DecodeGraph(model, idx, embed, idx)
+    ref = model(idx, embed, norm_idx=idx)[0]
+    assert torch.equal(dg(idx, embed, idx)[0], ref)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(300):
+        dg.graph.replay()
+    torch.cuda.synchronize()
+    print(f"DecodeGraph  : {300 / (time.time() - t0):8.1f} frames/s   ({(time.time() - t0) / 300 * 1e3:.3f} ms/frame), {dg.wplan_entries} planned weight tensors")
