@@ -13,11 +13,17 @@
 
 namespace {
 
-struct AdanArgs { bnerv_adan_chunk c; bnerv_adan_hyper h; };
+// bstart[t] = first block of tensor t in the flat grid (tensor t owns min(ceil(n_t / 1024), 1024) blocks): a (blocks of the largest
+// tensor) x (tensors) grid launched 48 x 1024 blocks for the chunk that holds the 1.1 M-element stem matrix, ~1500 of them with work
+struct AdanArgs { bnerv_adan_chunk c; bnerv_adan_hyper h; int bstart[BNERV_ADAN_MAX_TENSORS + 1]; };
 
 __global__ __launch_bounds__(256) void adan_kernel(const AdanArgs a) {
-    const int t = blockIdx.y;
-    if (t >= a.c.n_tensors) return;
+    int t = 0;
+    for (int hi = a.c.n_tensors; hi - t > 1;) {            // (uniform: scalar loads from the kernel arguments)
+        const int mid = (t + hi) >> 1;
+        if ((int)blockIdx.x >= a.bstart[mid]) t = mid; else hi = mid;
+    }
+    const int bx = (int)blockIdx.x - a.bstart[t], gx = a.bstart[t + 1] - a.bstart[t];
     const int n = a.c.n[t];
     float* __restrict__ p = a.c.p[t];
     const float* __restrict__ g = a.c.g[t];
@@ -29,7 +35,7 @@ __global__ __launch_bounds__(256) void adan_kernel(const AdanArgs a) {
     const bool first = a.h.sched_dev[4] != 0.f;
     const float b1 = a.h.beta1, b2 = a.h.beta2, b3 = a.h.beta3, eps = a.h.eps, wd = a.h.weight_decay, clip = a.h.clip_global_grad_norm;
     const float step_size = lr / bc1, step_size_diff = lr * b2 / bc2;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < n; i += gx * 256) {
         const float gi = g[i] * clip;
         float t0 = (first ? -gi : ng[i]) + gi;                       // g - g_prev   (0 on the first step)
         const float mi = m[i] * b1 + (1.0f - b1) * gi;
@@ -51,15 +57,19 @@ __global__ __launch_bounds__(256) void adan_kernel(const AdanArgs a) {
     }
 }
 
-struct BucketArgs { bnerv_bucket_chunk c; float* bucket; float scale; int to_bucket; };
+struct BucketArgs { bnerv_bucket_chunk c; float* bucket; float scale; int to_bucket; int bstart[BNERV_ADAN_MAX_TENSORS * 2 + 1]; };
 
 __global__ __launch_bounds__(256) void bucket_kernel(const BucketArgs a) {
-    const int t = blockIdx.y;
-    if (t >= a.c.n_tensors) return;
+    int t = 0;                                             // flat grid, as adan_kernel
+    for (int hi = a.c.n_tensors; hi - t > 1;) {
+        const int mid = (t + hi) >> 1;
+        if ((int)blockIdx.x >= a.bstart[mid]) t = mid; else hi = mid;
+    }
+    const int bx = (int)blockIdx.x - a.bstart[t], gx = a.bstart[t + 1] - a.bstart[t];
     const int n = a.c.n[t];
     float* __restrict__ x = a.c.t[t];
     float* __restrict__ bk = a.bucket + a.c.off[t];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < n; i += gx * 256) {
         if (a.to_bucket) bk[i] = x[i] * a.scale;
         else x[i] = bk[i] * a.scale;
     }
@@ -73,15 +83,17 @@ extern "C" int bnerv_adan_multi_tensor(void* stream, const bnerv_adan_chunk* chu
     AdanArgs a;
     a.c = *chunk;
     a.h = *h;
-    int maxn = 0;
+    int blocks = 0;
     for (int i = 0; i < chunk->n_tensors; ++i) {
         BNERV_REQUIRE(chunk->p[i] && chunk->g[i] && chunk->exp_avg[i] && chunk->exp_avg_sq[i] && chunk->exp_avg_diff[i] && chunk->neg_pre_grad[i] && chunk->n[i] > 0,
                       "adan_multi_tensor: bad tensor %d", i);
-        if (chunk->n[i] > maxn) maxn = chunk->n[i];
+        int gx = cdiv(chunk->n[i], 256 * 4);
+        if (gx > 1024) gx = 1024;
+        a.bstart[i] = blocks;
+        blocks += gx;
     }
-    int gx = cdiv(maxn, 256 * 4);
-    if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(adan_kernel, dim3(gx, chunk->n_tensors), dim3(256), 0, (hipStream_t)stream, a);
+    for (int i = chunk->n_tensors; i <= BNERV_ADAN_MAX_TENSORS; ++i) a.bstart[i] = blocks;
+    hipLaunchKernelGGL(adan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     BNERV_LAUNCH_CHECK("adan");
     return BNERV_OK;
 }
@@ -90,14 +102,16 @@ static int bucket_launch(void* stream, const bnerv_bucket_chunk* c, float* bucke
     BNERV_REQUIRE(c && bucket && c->n_tensors > 0 && c->n_tensors <= BNERV_ADAN_MAX_TENSORS * 2, "bucket: bad args");
     BucketArgs a;
     a.c = *c; a.bucket = bucket; a.scale = scale; a.to_bucket = to_bucket;
-    int maxn = 0;
+    int blocks = 0;
     for (int i = 0; i < c->n_tensors; ++i) {
         BNERV_REQUIRE(c->t[i] && c->n[i] > 0 && c->off[i] >= 0, "bucket: bad tensor %d", i);
-        if (c->n[i] > maxn) maxn = c->n[i];
+        int gx = cdiv(c->n[i], 256 * 4);
+        if (gx > 1024) gx = 1024;
+        a.bstart[i] = blocks;
+        blocks += gx;
     }
-    int gx = cdiv(maxn, 256 * 4);
-    if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(bucket_kernel, dim3(gx, c->n_tensors), dim3(256), 0, (hipStream_t)stream, a);
+    for (int i = c->n_tensors; i <= BNERV_ADAN_MAX_TENSORS * 2; ++i) a.bstart[i] = blocks;
+    hipLaunchKernelGGL(bucket_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     BNERV_LAUNCH_CHECK("bucket");
     return BNERV_OK;
 }
