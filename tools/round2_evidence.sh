@@ -26,6 +26,7 @@ $R/tools/pmc_bf.sh wgrad wgrad_lean_kernel $O/e2_pmc_wgrad.txt
 python $R/tools/kbench.py 30 > $O/e2_kbench.txt 2>&1
 for m in bf16x6 f16x3 bf16x3; do BNERV_SPLIT=$m python $R/tools/kbench.py 30 2>/dev/null | head -19 > $O/e2_kbench_$m.txt; done
 BNERV_SPLIT=bf16x6 $R/tools/pmc_bf.sh conv conv_bf_kernel $O/e2_pmc_bf16x6.txt
+for u in mfma_interleave bf16_split; do [ -x $R/tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/ubench/$u $R/tools/ubench/$u.cpp; done   # (binaries are not tracked)
 $R/tools/ubench/mfma_interleave > $O/e2_ub_interleave.txt 2>&1
 $R/tools/ubench/bf16_split > $O/e2_ub_bf16split.txt 2>&1
 # wide split kernels (default on): conv and weight gradient at the C3 / C4 shapes against the f32 kernels, and their PMC passes
