@@ -124,6 +124,29 @@ def test_decode_graph_equals_eager_decode(name, cfg):
     assert torch.equal(first[0], model(ins[0], embeds[0], norm_idx=norms[0])[0]) or takes_image
 
 
+def test_decode_graph_refresh_after_weight_change(monkeypatch):
+    """DecodeGraph prepares the weight fragments of the wide split convs once (context plan); after the weights are written,
+    refresh() re-prepares them and the replayed forward equals the eager one again, bit for bit."""
+    from boosting_nerv_amd.engine import DecodeGraph
+    monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    torch.manual_seed(3)
+    model = _build("tiny_nerv", configs.tiny_nerv()).to(DEV).eval()
+    norm = torch.tensor([3 / 7], dtype=torch.float64, device=DEV)
+    with torch.no_grad():
+        embed = model(norm, norm_idx=norm)[1][0]
+        dg = DecodeGraph(model, norm, embed, norm)
+        assert dg.wplan_entries > 0
+        assert torch.equal(dg(norm, embed, norm)[0], model(norm, embed, norm_idx=norm)[0])
+        for p in model.parameters():
+            p.mul_(1.03)
+        ref = model(norm, embed, norm_idx=norm)[0]
+        stale = dg(norm, embed, norm)[0].clone()
+        dg.refresh()
+        out = dg(norm, embed, norm)[0]
+        assert torch.equal(out, ref), float((out - ref).abs().max())
+        assert not torch.equal(stale, ref)                  # (the planned layers really read the prepared fragments)
+
+
 @pytest.mark.parametrize("name,cfg", [("c3", configs.c3), ("c4", configs.c4)])
 def test_big_models_full_size_against_reference_golden(name, cfg):
     """BASELINE configs C3 (HNeRV-boost 3M incl. its ConvNeXt encoder, model_hnerv.py:224-251) and C4 (E-NeRV-boost 3M,
