@@ -1,0 +1,456 @@
+// conv4.hip -- the 3x3 stride-1 convolutions with at most 12 input and 12 output channels (every TAT conv, stride-1 block conv and
+// their data gradients of the 12-channel stages; reference call sites: model_blocks.py:74-89, :196-220 through
+// lib/quant_ops.py:39-41) on v_mfma_f32_4x4x1_16b_f32.
+//
+// Why another MFMA shape.  On gfx950 the f32 MFMA issues at the f32 vector rate whatever its shape, so the 16x16x4 kernels of
+// conv.hip pay for N = 16 output channels on a 12-channel layer (25 % of the matrix cycles are padding) and move an A AND a B
+// fragment through LDS for every 4 k-steps.  The 4x4x1 shape is 16 independent 4x4 outer products per instruction:
+//     D_b[i][j] += A_b[i] * B_b[j]            b = 0..15;  A_b[i] in lane 4b + i,  B_b[j] in lane 4b + j,  D_b[i][j]: lane 4b + j, reg i
+// With A = the input value of the lane's OWN pixel (a wave = 64 pixels = 2 tile rows x 32 px, block b = 4 consecutive pixels)
+// and B = a quad of weights (4 output channels of one (ci, tap)), one instruction is 64 px x 4 cout x 1 k:
+//   * N granularity 4: 12 output channels are exactly 3 instructions per (ci, tap) -- 324 MFMAs x 8 cycles per 64 pixels against
+//     108 x 32 for the 16x16x4 form;
+//   * the weights never move: BLGP = 4 + g broadcasts the 16-lane group g of B to all four groups, so one register holds four
+//     quads (each replicated over its group's four blocks) and the 27 quads of an input channel are 7 registers; all 12 channels
+//     (84 registers) stay resident for the whole persistent block;
+//   * the K loop is  { 1 ds_read_b32 ; 3 v_mfma }  x 108 with compile-time LDS offsets: no VALU, no SALU, no address arithmetic;
+//   * D: lane 4b + j holds 4 consecutive pixels of output channel 4n + j = one 16-byte store per accumulator, and every lane
+//     carries a real channel (the 16x16x4 epilogue spends a quarter of its lanes on the padding channels).
+// Tile geometry, staging (raw buffer loads prefetched under the matrix phase, prologue applied on the way into LDS), item
+// partition, epilogues and the hosted slab reductions are those of conv_lean_kernel (conv.hip).
+#include "common.h"
+#include "sidejob.h"
+#include "conv_common.h"
+
+namespace {
+using namespace bnerv_conv;
+
+#ifndef BNERV_ABL4
+#define BNERV_ABL4 0   // debug ablations (never shipped): 1 no MFMA, 2 no global loads / stores, 3 no epilogue math
+#endif
+constexpr int Q4_NCH = 12;                 // staged input channels
+constexpr int Q4_NG = 3;                   // output-channel quads
+constexpr int Q4_NQD = 9 * Q4_NG;          // weight quads per input channel (tap-major: q = tap * NG + n)
+constexpr int Q4_NWR = (Q4_NQD + 3) / 4;   // weight registers per input channel (4 quads each)
+constexpr int Q4_QPAD = Q4_NWR * 4;        // quads per channel in the LDS image (padding quads are zero)
+
+#ifdef BNERV_TRACE
+__device__ unsigned long long g_trace4[1024 * 4 * 6 * 8];
+#define TRACE(slot) do { if (lane == 0 && blockIdx.x < 1024 && trace_iter < 6) g_trace4[((blockIdx.x * 4 + wave) * 6 + trace_iter) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TRACE(slot) do {} while (0)
+#endif
+
+template <int G>
+__device__ __forceinline__ f32x4 mfma_q(float a, float w, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, w, c, 0, 0, 4 + G);
+}
+__device__ __forceinline__ f32x4 mfma_qsel(int g, float a, float w, f32x4 c) {          // g is a constant after unrolling
+    switch (g) {
+        case 0: return mfma_q<0>(a, w, c);
+        case 1: return mfma_q<1>(a, w, c);
+        case 2: return mfma_q<2>(a, w, c);
+        default: return mfma_q<3>(a, w, c);
+    }
+}
+
+template <int IN, int EP>
+__global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const SidePack side) {
+    using G = Geo<3>;
+    constexpr int NSLOT = Q4_NCH * G::ROWS * G::SEGS;
+    constexpr int NPRE = (NSLOT + 255) / 256;
+    constexpr int S_IN = Q4_NCH * G::PLANE + (NPRE * 256 - NSLOT) * 4;         // floats; the tail is a dump area for idle slots
+    constexpr int S_W = Q4_NCH * Q4_QPAD * 4;
+    constexpr bool AFF = (IN == BNERV_IN_AFFINE);
+    constexpr bool RED = (EP == BNERV_EP_DSIN || EP == BNERV_EP_DGELU_SAVED);
+    static_assert(IN == BNERV_IN_PLAIN || IN == BNERV_IN_AFFINE, "prologues of the 12-channel layers");
+    static_assert(G::PLANE == G::PLANE_RAW, "slot offset = 16 * slot index");
+    const bnerv_conv_desc& d = ka.d;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;
+    float* s_w = smem + S_IN;                              // [ci][quad][4] compact weight quads
+    float* s_red = s_w + S_W;                              // [4 waves][2][16] per-channel partial sums (DGELU_SAVED / DSIN)
+    float* s_aff = s_red + 128;                            // [2][16] affine prologue parameters of the current sample
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 3, lb = lane >> 2;               // output channel within a quad, pixel quad (row lb >> 3, columns 4 (lb & 7) ..)
+    const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
+    const int tiles_x = ka.tiles_x, tiles_y = ka.tiles_y;
+    { const int trace_iter = 5; (void)trace_iter; TRACE(0); }
+
+    // this block's item range: XCD x owns a contiguous slice of the item list; its blocks take it round-robin
+    const int xcd = blockIdx.x & 7, lbk = blockIdx.x >> 3;
+    const int nlb = (gridDim.x - xcd + 7) >> 3;
+    const int per = ka.total_items >> 3, extra = ka.total_items & 7;
+    const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
+    int itx = r0 + lbk;
+    if (itx >= r1) { side_run_hosted(side, smem); return; }
+    const int step_q = fast_div(nlb, ka.magic_tiles_x), step_r = nlb - step_q * tiles_x;
+    LItem it;
+    {
+        const int tiles = tiles_x * tiles_y;
+        it.b = fast_div(itx, ka.magic_tiles);
+        const int t = itx - it.b * tiles;
+        it.ty = fast_div(t, ka.magic_tiles_x);
+        it.tx = t - it.ty * tiles_x;
+    }
+    auto advance = [&](LItem a) {
+        a.tx += step_r;
+        a.ty += step_q;
+        if (a.tx >= tiles_x) { a.tx -= tiles_x; ++a.ty; }
+        while (a.ty >= tiles_y) { a.ty -= tiles_y; ++a.b; }
+        return a;
+    };
+
+    // ---- per-slot constants (slot = (channel, halo row, 4-px segment); thread t owns slots t, t+256, ...)
+    auto slot_geom = [&](int k, int& c, int& r, int& sg) {
+        const int sidx = tid + k * 256;
+        c = sidx / (G::ROWS * G::SEGS);
+        const int rem = sidx - c * (G::ROWS * G::SEGS);
+        r = rem / G::SEGS;
+        sg = rem - r * G::SEGS;
+    };
+    auto slot_inside = [&](int k, int ty0, int tx0) {
+        int c, r, sg;
+        slot_geom(k, c, r, sg);
+        const int gy = ty0 + r - G::PAD, gx = tx0 + 4 * sg - G::XOFF;
+        return (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    };
+    unsigned voff[NPRE];
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        int c, r, sg;
+        slot_geom(k, c, r, sg);
+        voff[k] = (tid + k * 256 < NSLOT && c < Cin) ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB;
+    }
+    const unsigned shift = (unsigned)((G::PAD * W + G::XOFF) * 4);          // the x view starts PAD rows + XOFF columns early: offsets >= 0
+    const unsigned in_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
+    const unsigned out_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, in_bytes);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ro2 = make_rsrc(((EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) && d.out2) ? d.out2 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(d.aux0 ? d.aux0 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(d.aux1 ? d.aux1 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ra2 = make_rsrc(d.aux2 ? d.aux2 : d.out, 0, out_bytes);
+
+    // epilogue lane constants: lane (lb, lj) owns output channels 4 n + lj, pixels (row lb >> 3, columns 4 (lb & 7) .. + 3) of the wave's two rows
+    const unsigned ovoff = (unsigned)(((lj * H + (lb >> 3)) * W + 4 * (lb & 7)) * 4);
+    const unsigned nstep = (unsigned)(4 * H * W * 4);      // + 4 output channels
+    float bias_l[Q4_NG];
+#pragma unroll
+    for (int n = 0; n < Q4_NG; ++n) bias_l[n] = (EP != BNERV_EP_PLAIN && !RED && d.bias && 4 * n + lj < Cout) ? d.bias[4 * n + lj] : 0.f;
+
+    // Affine prologue parameters live in LDS (s_aff[c] = 1 + scale[b][c], s_aff[16 + c] = shift[b][c], zero for c >= Cin, which also
+    // covers the idle slots: their channel index is 12); each commit reads the pair of its slots' channels (packed 4 bits each).
+    unsigned cpack = 0;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        int c, r, sg;
+        slot_geom(k, c, r, sg);
+        cpack |= (unsigned)(c & 15) << (4 * k);
+    }
+    auto fetch_affine = [&](int b) {                       // tid < 32 only: the value this lane contributes
+        const int c = tid & 15;
+        float v = 0.f;
+        if (tid < 32 && c < Cin) v = tid < 16 ? 1.0f + d.scale[b * Cin + c] : d.shift[b * Cin + c];
+        return v;
+    };
+    auto load_affine = [&](int b) {                        // mid-loop reload when the sample changes (B > 1; rare)
+        const float v = fetch_affine(b);
+        lds_barrier();
+        if (tid < 32) s_aff[tid] = v;
+        lds_barrier();
+    };
+    float scl[Q4_NG];                                      // 1 + scale[b][co] of the DGELU_SAVED / DSIN epilogues
+#pragma unroll
+    for (int n = 0; n < Q4_NG; ++n) scl[n] = 0.f;
+
+    f32x4 ra[NPRE];
+    auto issue = [&](const LItem& a) {
+        const int ty0 = a.ty * TH, tx0 = a.tx * TW;
+        const unsigned sb = (unsigned)((((a.b * Cin) * H + ty0) * W + tx0) * 4);
+        const bool interior = ty0 >= G::PAD && ty0 + TH + G::PAD <= H && tx0 >= G::XOFF && tx0 + TW + G::XOFF <= W;
+        if (interior) {
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) ra[k] = bload(rx, (BNERV_ABL4 == 2 && d.B > 0) ? OOB : voff[k], sb);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) ra[k] = bload(rx, slot_inside(k, ty0, tx0) ? voff[k] : OOB, sb);
+        }
+    };
+    auto commit = [&](const LItem& a) {
+        const int ty0 = a.ty * TH, tx0 = a.tx * TW;
+        const bool interior = ty0 >= G::PAD && ty0 + TH + G::PAD <= H && tx0 >= G::XOFF && tx0 + TW + G::XOFF <= W;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            f32x4 v = ra[k];
+            if constexpr (AFF) {
+                const int c = (cpack >> (4 * k)) & 15;
+                float s = s_aff[c], h = s_aff[16 + c];
+                if (!interior) {                           // zero padding is applied AFTER the prologue: outside stays 0
+                    const bool ok = slot_inside(k, ty0, tx0);
+                    s = ok ? s : 0.f;
+                    h = ok ? h : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = xform1<IN>(v[e], s, h, 0.f);
+            }
+            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(s_in) + (tid + k * 256) * 16) = v;
+        }
+    };
+    auto flush_partials = [&](const LItem& a) {            // wave 0: sum the 4 waves' channel sums of tile `a`, fixed order
+        if (wave == 0 && lane < 32) {
+            const int q = lane >> 4, c = lane & 15;
+            const float s = ((s_red[(0 * 2 + q) * 16 + c] + s_red[(1 * 2 + q) * 16 + c]) + s_red[(2 * 2 + q) * 16 + c]) + s_red[(3 * 2 + q) * 16 + c];
+            const size_t row = (size_t)(a.ty * tiles_x + a.tx) * d.B + a.b;            // [tiles][B][2][Cout]
+            if (c < Cout) d.partial[(row * 2 + q) * Cout + c] = s;
+        }
+    };
+
+    // prologue: the first tile's loads, then the weight loads back to back (one exposed memory latency for the lot)
+    int aff_b = -1, ep_b = -1;
+    float aff_v = 0.f;
+    { const int trace_iter = 5; (void)trace_iter; TRACE(2); }
+    if constexpr (AFF) { aff_v = fetch_affine(it.b); aff_b = it.b; }
+    issue(it);
+    { const int trace_iter = 5; (void)trace_iter; TRACE(3); }
+    {
+        // s_w[(ci * QPAD + q) * 4 + j] = W(co = 4 n + j, ci, tap), q = tap * NG + n; W(co, ci, t) = w[co][ci][t] or, transposed, w[ci][co][8 - t]
+        constexpr int NWV = (S_W + 255) / 256;
+        float wv[NWV];
+#pragma unroll
+        for (int u = 0; u < NWV; ++u) {
+            const int e = tid + u * 256;
+            const int j = e & 3, cq = e >> 2;
+            const int ci = cq / Q4_QPAD, q = cq - ci * Q4_QPAD;
+            const int tap = q / Q4_NG, n = q - tap * Q4_NG;
+            const int co = 4 * n + j;
+            float v = 0.f;
+            if (e < S_W && q < Q4_NQD && co < Cout && ci < Cin)
+                v = d.transposed ? d.w[(ci * d.wCi + co) * 9 + (8 - tap)] : d.w[(co * d.wCi + ci) * 9 + tap];
+            wv[u] = v;
+        }
+        { const int trace_iter = 5; (void)trace_iter; TRACE(4); }
+        if constexpr (AFF) { if (tid < 32) s_aff[tid] = aff_v; }
+#pragma unroll
+        for (int u = 0; u < NWV; ++u)
+            if (tid + u * 256 < S_W) s_w[tid + u * 256] = wv[u];
+    }
+    lds_barrier();
+    { const int trace_iter = 5; (void)trace_iter; TRACE(5); }
+    // resident B registers: wr[ci][v], lane l = quad 4 v + (l >> 4), element l & 3 (replicated over the group's four blocks)
+    float wr[Q4_NCH][Q4_NWR];
+#pragma unroll
+    for (int ci = 0; ci < Q4_NCH; ++ci)
+#pragma unroll
+        for (int v = 0; v < Q4_NWR; ++v) wr[ci][v] = s_w[(ci * Q4_QPAD + 4 * v + (lane >> 4)) * 4 + lj];
+    { const int trace_iter = 5; (void)trace_iter; TRACE(6); }
+    commit(it);
+    { const int trace_iter = 5; (void)trace_iter; TRACE(1); }
+    // A operand: the lane's own pixel, row 2 wave + (lane >> 5), column lane & 31
+    const float* a_base = s_in + (2 * wave + (lane >> 5)) * G::RS + (lane & 31) + G::COL0;
+    LItem prev = it;
+    bool have_prev = false;
+    int trace_iter = 0; (void)trace_iter;
+    for (; itx < r1; itx += nlb, ++trace_iter) {
+        TRACE(0);
+        f32x4 acc[Q4_NG];
+#pragma unroll
+        for (int n = 0; n < Q4_NG; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool has_next = itx + nlb < r1;
+        LItem nxt = it;
+        if (has_next) nxt = advance(it);
+        lds_barrier();                                     // (A) s_in(t) and s_red(t-1) visible
+        TRACE(1);
+        if (has_next) issue(nxt);                          // flies under the matrix phase
+        TRACE(2);
+        if constexpr (RED) { if (have_prev) flush_partials(prev); }
+        // K loop: the 3 A values of the next tap row are read while the 9 MFMAs of the current one issue
+        float a_cur[3], a_nxt[3];
+        if (BNERV_ABL4 != 1 || d.B < 0) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) a_cur[kx] = a_base[kx];
+#pragma unroll
+        for (int ci = 0; ci < Q4_NCH; ++ci) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int nci = ky == 2 ? ci + 1 : ci, nky = ky == 2 ? 0 : ky + 1;
+                if (nci < Q4_NCH) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) a_nxt[kx] = a_base[nci * G::PLANE + nky * G::RS + kx];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int n = 0; n < Q4_NG; ++n) {
+                        const int q = (ky * 3 + kx) * Q4_NG + n;
+                        acc[n] = mfma_qsel(q & 3, a_cur[kx], wr[ci][q >> 2], acc[n]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) a_cur[kx] = a_nxt[kx];
+            }
+        }
+        }
+        TRACE(3);
+        lds_barrier();                                     // (B) every wave is done reading s_in(t)
+        TRACE(4);
+        if (has_next) {
+            if constexpr (AFF) { if (nxt.b != aff_b) { load_affine(nxt.b); aff_b = nxt.b; } }
+            commit(nxt);
+        }
+        TRACE(5);
+        // ---- epilogue straight from the accumulators: acc[n] = 4 consecutive pixels of output channel 4 n + lj
+        {
+            const int ty0 = it.ty * TH, tx0 = it.tx * TW;
+            const unsigned ob = (unsigned)((((it.b * Cout) * H + ty0 + 2 * wave) * W + tx0) * 4);
+            const bool full = ty0 + TH <= H && tx0 + TW <= W;
+            if constexpr (RED) {
+                if (it.b != ep_b) {
+#pragma unroll
+                    for (int n = 0; n < Q4_NG; ++n) scl[n] = 4 * n + lj < Cout ? 1.0f + d.scale[it.b * Cout + 4 * n + lj] : 0.f;
+                    ep_b = it.b;
+                }
+            }
+            bool px_ok = true;
+            if (!full) px_ok = (ty0 + 2 * wave + (lb >> 3) < H) && (tx0 + 4 * (lb & 7) < W);
+            unsigned so[Q4_NG], vo[Q4_NG];
+#pragma unroll
+            for (int n = 0; n < Q4_NG; ++n) {
+                so[n] = ob + (unsigned)n * nstep;
+                const bool ok = px_ok && (4 * n + lj < Cout);
+                vo[n] = (ok && !(BNERV_ABL4 == 2 && d.B > 0)) ? ovoff : OOB;
+                if constexpr (RED) { if (!ok) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
+            if constexpr (EP == BNERV_EP_BIAS || EP == BNERV_EP_PLAIN) {
+#pragma unroll
+                for (int n = 0; n < Q4_NG; ++n) bstore(ro, vo[n], so[n], acc[n] + bias_l[n]);
+            } else if constexpr (EP == BNERV_EP_BIAS_SIN) {
+#pragma unroll
+                for (int n = 0; n < Q4_NG; ++n) {
+                    f32x4 sv, cv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(acc[n][e] + bias_l[n], &s_, &c_); sv[e] = s_; cv[e] = c_; }
+                    bstore(ro, vo[n], so[n], sv);
+                    if (d.out2) bstore(ro2, vo[n], so[n], cv);
+                }
+            } else if constexpr (EP == BNERV_EP_BIAS_GELU) {
+#pragma unroll
+                for (int n = 0; n < Q4_NG; ++n) {
+                    f32x4 hv, gv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float h_, g_; gelu_pair_f(acc[n][e] + bias_l[n], &h_, &g_); hv[e] = h_; gv[e] = g_; }
+                    bstore(ro, vo[n], so[n], hv);
+                    if (d.out2) bstore(ro2, vo[n], so[n], gv);
+                }
+            } else if constexpr (EP == BNERV_EP_BIAS_RES) {
+                f32x4 a0[Q4_NG];
+#pragma unroll
+                for (int n = 0; n < Q4_NG; ++n) a0[n] = bload(ra0, vo[n], so[n]);
+#pragma unroll
+                for (int n = 0; n < Q4_NG; ++n) bstore(ro, vo[n], so[n], acc[n] + bias_l[n] + a0[n]);
+            } else {                                       // DGELU_SAVED / DSIN, one channel quad at a time (12 aux registers)
+                float ps[Q4_NG], pt[Q4_NG];
+#pragma unroll
+                for (int n = 0; n < Q4_NG; ++n) {
+                    const f32x4 a0 = bload(ra0, vo[n], so[n]);
+                    const f32x4 a1 = bload(ra1, vo[n], so[n]);
+                    f32x4 a2 = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (EP == BNERV_EP_DSIN) { if (d.aux2) a2 = bload(ra2, vo[n], so[n]); }
+                    f32x4 r;
+                    const f32x4 v = acc[n];
+                    ps[n] = 0.f; pt[n] = 0.f;
+                    if constexpr (EP == BNERV_EP_DGELU_SAVED) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { r[e] = v[e] * scl[n] * a0[e]; ps[n] = fmaf(v[e], a1[e], ps[n]); pt[n] += v[e]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { r[e] = (a1[e] + v[e] * scl[n]) * a2[e]; ps[n] = fmaf(v[e], a0[e], ps[n]); pt[n] += v[e]; }
+                    }
+                    bstore(ro, vo[n], so[n], r);
+                }
+                // per-channel sums: lanes with equal lj (stride 4) hold the same channel
+#pragma unroll
+                for (int n = 0; n < Q4_NG; ++n) {
+#pragma unroll
+                    for (int off = 4; off < 64; off <<= 1) {
+                        ps[n] += __shfl_xor(ps[n], off, 64);
+                        pt[n] += __shfl_xor(pt[n], off, 64);
+                    }
+                }
+                if (lane < 4) {
+#pragma unroll
+                    for (int n = 0; n < Q4_NG; ++n) { s_red[(wave * 2 + 0) * 16 + 4 * n + lane] = ps[n]; s_red[(wave * 2 + 1) * 16 + 4 * n + lane] = pt[n]; }
+                }
+            }
+        }
+        TRACE(6);
+        TRACE(7);
+        prev = it;
+        have_prev = true;
+        it = nxt;
+    }
+    if constexpr (RED) {
+        lds_barrier();
+        flush_partials(prev);
+    }
+    side_run_hosted(side, smem);                           // queued slab reductions, least-loaded blocks first (sidejob.h)
+}
+
+template <int IN, int EP>
+int launch_q4(hipStream_t st, KArgs& ka) {
+    using G = Geo<3>;
+    const bnerv_conv_desc& d = ka.d;
+    constexpr int NSLOT = Q4_NCH * G::ROWS * G::SEGS;
+    constexpr int NPRE = (NSLOT + 255) / 256;
+    ka.ngroups = 1;
+    ka.total_items = d.B * ka.tiles_x * ka.tiles_y;
+    ka.nq_total = 3;
+    ka.w_resident = 1;
+    ka.magic_tiles = div_magic(ka.tiles_x * ka.tiles_y);
+    ka.magic_tiles_x = div_magic(ka.tiles_x);
+    const size_t lds = ((size_t)Q4_NCH * G::PLANE + (size_t)(NPRE * 256 - NSLOT) * 4 + (size_t)Q4_NCH * Q4_QPAD * 4 + 128 + 32) * sizeof(float);
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_q4_kernel<IN, EP>), 256, lds) != hipSuccess || nb < 1) nb = 1;
+        blocks_per_cu = nb;
+    }
+    int grid = 256 * blocks_per_cu;                        // everything resident: the static item partition is then balanced
+    if (grid > ka.total_items) grid = ka.total_items;
+    SidePack side;
+    bnerv_side_take(ka.d.ctx, &side, 2 * grid);
+    hipLaunchKernelGGL((conv_q4_kernel<IN, EP>), dim3(grid), dim3(256), lds, st, ka, side);
+    BNERV_LAUNCH_CHECK("conv_q4");
+    return BNERV_OK;
+}
+
+}  // namespace
+
+#ifdef BNERV_TRACE
+extern "C" int bnerv_debug_trace4_read(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace4), sizeof(g_trace4)); }
+#endif
+// 1: not this family's layer (the caller goes on to the 16x16x4 kernels); BNERV_OK / negative BNERV_E_*: handled.
+int bnerv_conv4_try(hipStream_t st, bnerv_conv::KArgs& ka) {
+    const bnerv_conv_desc& d = ka.d;
+    static const bool off = [] { const char* e = getenv("BNERV_Q4"); return e && e[0] == '0'; }();      // A/B switch (tools/kbench.py)
+    if (off) return 1;
+    const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
+    if (!(ka.vec && d.k == 3 && d.out_s == 1 && d.Cin > 8 && d.Cin <= Q4_NCH && d.Cout <= 4 * Q4_NG && ka.ksplit == 1 &&
+          (size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 < LEAN_MAX_BYTES))
+        return 1;
+    const int in = d.in_mode, ep = d.ep_mode;
+#define BNERV_CASE(I, E) if (in == I && ep == E) return launch_q4<I, E>(st, ka);
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS_SIN)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_PLAIN)
+    BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS)
+    BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_GELU)
+    BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_RES)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DGELU_SAVED)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DSIN)
+#undef BNERV_CASE
+    return 1;
+}
