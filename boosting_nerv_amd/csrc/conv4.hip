@@ -54,23 +54,36 @@ __device__ __forceinline__ f32x4 mfma_qsel(int g, float a, float w, f32x4 c) {  
     }
 }
 
+// LDS-DMA of one 16-byte slot per lane: LDS address = m0 + 16 * lane.  Issued through inline asm on purpose: the compiler would
+// order every later ds_read behind a builtin LDS-DMA with s_waitcnt vmcnt(0) (it cannot tell the two input buffers apart),
+// which would serialise the next tile's loads with this tile's matrix phase.  The waits are placed by hand (q4_wait_dma).
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void q4_wait_dma() {            // all but the N youngest vector-memory operations of this wave are complete
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int IN, int EP>
 __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const SidePack side) {
     using G = Geo<3>;
     constexpr int NSLOT = Q4_NCH * G::ROWS * G::SEGS;
     constexpr int NPRE = (NSLOT + 255) / 256;
-    constexpr int S_IN = Q4_NCH * G::PLANE + (NPRE * 256 - NSLOT) * 4;         // floats; the tail is a dump area for idle slots
+    constexpr int S_IN = NPRE * 256 * 4;                   // floats per input buffer: every slot (idle ones included) owns 16 bytes
     constexpr int S_W = Q4_NCH * Q4_QPAD * 4;
     constexpr bool AFF = (IN == BNERV_IN_AFFINE);
     constexpr bool RED = (EP == BNERV_EP_DSIN || EP == BNERV_EP_DGELU_SAVED);
+    constexpr bool TWO_OUT = (EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU);
     static_assert(IN == BNERV_IN_PLAIN || IN == BNERV_IN_AFFINE, "prologues of the 12-channel layers");
-    static_assert(G::PLANE == G::PLANE_RAW, "slot offset = 16 * slot index");
+    static_assert(G::PLANE == G::PLANE_RAW && S_IN >= Q4_NCH * G::PLANE, "slot offset = 16 * slot index");
     const bnerv_conv_desc& d = ka.d;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_in = smem;
-    float* s_w = smem + S_IN;                              // [ci][quad][4] compact weight quads
+    float* s_in = smem;                                    // [2][S_IN] input tiles, filled by LDS-DMA
+    float* s_w = smem + 2 * S_IN;                          // [ci][quad][4] compact weight quads
     float* s_red = s_w + S_W;                              // [4 waves][2][16] per-channel partial sums (DGELU_SAVED / DSIN)
     float* s_aff = s_red + 128;                            // [2][16] affine prologue parameters of the current sample
+    float* s_beta = s_aff + 32;                            // [9 taps][16] sum_ci shift[ci] * W(co, ci, tap)  (affine prologue, folded)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,7 +116,7 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
         return a;
     };
 
-    // ---- per-slot constants (slot = (channel, halo row, 4-px segment); thread t owns slots t, t+256, ...)
+    // ---- per-slot constants (slot = (channel, halo row, 4-px segment); thread t owns slots t, t+256, ...; its LDS home is byte 16 * slot)
     auto slot_geom = [&](int k, int& c, int& r, int& sg) {
         const int sidx = tid + k * 256;
         c = sidx / (G::ROWS * G::SEGS);
@@ -122,81 +135,48 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
     for (int k = 0; k < NPRE; ++k) {
         int c, r, sg;
         slot_geom(k, c, r, sg);
-        voff[k] = (tid + k * 256 < NSLOT && c < Cin) ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB;
+        voff[k] = (tid + k * 256 < NSLOT && c < Cin) ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB;       // out of range: the DMA writes zeros
     }
     const unsigned shift = (unsigned)((G::PAD * W + G::XOFF) * 4);          // the x view starts PAD rows + XOFF columns early: offsets >= 0
     const unsigned in_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
     const unsigned out_bytes = (unsigned)((size_t)d.B * Cout * H * W * 4);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, in_bytes);
+    i32x4 rx;                                              // the raw buffer descriptor of make_rsrc(d.x - shift, in_bytes), as the four dwords the DMA asm takes
+    {
+        const uintptr_t base = reinterpret_cast<uintptr_t>(d.x) - shift;
+        rx[0] = (int)(unsigned)(base & 0xffffffffu);
+        rx[1] = (int)(unsigned)((base >> 32) & 0xffffu);
+        rx[2] = (int)in_bytes;
+        rx[3] = 0x00020000;
+    }
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.out, 0, out_bytes);
-    const __amdgpu_buffer_rsrc_t ro2 = make_rsrc(((EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) && d.out2) ? d.out2 : d.out, 0, out_bytes);
+    const __amdgpu_buffer_rsrc_t ro2 = make_rsrc((TWO_OUT && d.out2) ? d.out2 : d.out, 0, out_bytes);
     const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(d.aux0 ? d.aux0 : d.out, 0, out_bytes);
     const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(d.aux1 ? d.aux1 : d.out, 0, out_bytes);
     const __amdgpu_buffer_rsrc_t ra2 = make_rsrc(d.aux2 ? d.aux2 : d.out, 0, out_bytes);
+    const unsigned lds_in = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)s_in + (unsigned)wave * 1024u;      // this wave's 64 slots of DMA pass 0
 
     // epilogue lane constants: lane (lb, lj) owns output channels 4 n + lj, pixels (row lb >> 3, columns 4 (lb & 7) .. + 3) of the wave's two rows
     const unsigned ovoff = (unsigned)(((lj * H + (lb >> 3)) * W + 4 * (lb & 7)) * 4);
     const unsigned nstep = (unsigned)(4 * H * W * 4);      // + 4 output channels
-    float bias_l[Q4_NG];
+    float bias_l[Q4_NG];                                   // bias (+ the folded shift term of an interior pixel)
 #pragma unroll
     for (int n = 0; n < Q4_NG; ++n) bias_l[n] = (EP != BNERV_EP_PLAIN && !RED && d.bias && 4 * n + lj < Cout) ? d.bias[4 * n + lj] : 0.f;
-
-    // Affine prologue parameters live in LDS (s_aff[c] = 1 + scale[b][c], s_aff[16 + c] = shift[b][c], zero for c >= Cin, which also
-    // covers the idle slots: their channel index is 12); each commit reads the pair of its slots' channels (packed 4 bits each).
-    unsigned cpack = 0;
-#pragma unroll
-    for (int k = 0; k < NPRE; ++k) {
-        int c, r, sg;
-        slot_geom(k, c, r, sg);
-        cpack |= (unsigned)(c & 15) << (4 * k);
-    }
-    auto fetch_affine = [&](int b) {                       // tid < 32 only: the value this lane contributes
-        const int c = tid & 15;
-        float v = 0.f;
-        if (tid < 32 && c < Cin) v = tid < 16 ? 1.0f + d.scale[b * Cin + c] : d.shift[b * Cin + c];
-        return v;
-    };
-    auto load_affine = [&](int b) {                        // mid-loop reload when the sample changes (B > 1; rare)
-        const float v = fetch_affine(b);
-        lds_barrier();
-        if (tid < 32) s_aff[tid] = v;
-        lds_barrier();
-    };
     float scl[Q4_NG];                                      // 1 + scale[b][co] of the DGELU_SAVED / DSIN epilogues
 #pragma unroll
     for (int n = 0; n < Q4_NG; ++n) scl[n] = 0.f;
 
-    f32x4 ra[NPRE];
-    auto issue = [&](const LItem& a) {
+    // tile (a) -> input buffer `buf`: NPRE DMA passes per wave, zeros outside the image / beyond Cin
+    auto issue = [&](const LItem& a, int buf) {
         const int ty0 = a.ty * TH, tx0 = a.tx * TW;
         const unsigned sb = (unsigned)((((a.b * Cin) * H + ty0) * W + tx0) * 4);
+        const unsigned lbase = lds_in + (unsigned)buf * (unsigned)(S_IN * 4);
         const bool interior = ty0 >= G::PAD && ty0 + TH + G::PAD <= H && tx0 >= G::XOFF && tx0 + TW + G::XOFF <= W;
         if (interior) {
 #pragma unroll
-            for (int k = 0; k < NPRE; ++k) ra[k] = bload(rx, (BNERV_ABL4 == 2 && d.B > 0) ? OOB : voff[k], sb);
+            for (int k = 0; k < NPRE; ++k) dma16(rx, (BNERV_ABL4 == 2 && d.B > 0) ? OOB : voff[k], sb, lbase + (unsigned)k * 4096u);
         } else {
 #pragma unroll
-            for (int k = 0; k < NPRE; ++k) ra[k] = bload(rx, slot_inside(k, ty0, tx0) ? voff[k] : OOB, sb);
-        }
-    };
-    auto commit = [&](const LItem& a) {
-        const int ty0 = a.ty * TH, tx0 = a.tx * TW;
-        const bool interior = ty0 >= G::PAD && ty0 + TH + G::PAD <= H && tx0 >= G::XOFF && tx0 + TW + G::XOFF <= W;
-#pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            f32x4 v = ra[k];
-            if constexpr (AFF) {
-                const int c = (cpack >> (4 * k)) & 15;
-                float s = s_aff[c], h = s_aff[16 + c];
-                if (!interior) {                           // zero padding is applied AFTER the prologue: outside stays 0
-                    const bool ok = slot_inside(k, ty0, tx0);
-                    s = ok ? s : 0.f;
-                    h = ok ? h : 0.f;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = xform1<IN>(v[e], s, h, 0.f);
-            }
-            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(s_in) + (tid + k * 256) * 16) = v;
+            for (int k = 0; k < NPRE; ++k) dma16(rx, slot_inside(k, ty0, tx0) ? voff[k] : OOB, sb, lbase + (unsigned)k * 4096u);
         }
     };
     auto flush_partials = [&](const LItem& a) {            // wave 0: sum the 4 waves' channel sums of tile `a`, fixed order
@@ -208,12 +188,60 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
         }
     };
 
-    // prologue: the first tile's loads, then the weight loads back to back (one exposed memory latency for the lot)
+    // resident B registers: wr[ci][v], lane l = quad 4 v + (l >> 4), element l & 3 (replicated over the group's four blocks).
+    // The TAT affine a = x (1 + s_ci) + t_ci in front of the convolution is folded: conv_w(a) = conv_{w (1 + s_ci)}(x) + sum of
+    // t_ci w over the taps that fall INSIDE the image (zero padding applies after the affine), so the staged tile is the raw
+    // tensor, the weights are scaled once per sample and the shift term joins the bias (interior pixels: all 9 taps; pixels on
+    // the image border: the taps that exist -- s_beta keeps the per-tap sums).
+    float wr[Q4_NCH][Q4_NWR];
+    float beta_l[Q4_NG];
+#pragma unroll
+    for (int n = 0; n < Q4_NG; ++n) beta_l[n] = 0.f;
+    auto fetch_affine = [&](int b) {                       // tid < 32 only: the value this lane contributes
+        const int c = tid & 15;
+        float v = 0.f;
+        if (tid < 32 && c < Cin) v = tid < 16 ? 1.0f + d.scale[b * Cin + c] : d.shift[b * Cin + c];
+        return v;
+    };
+    auto load_weights = [&]() {                            // after s_w (and s_aff) are visible
+#pragma unroll
+        for (int ci = 0; ci < Q4_NCH; ++ci) {
+            const float f = AFF ? s_aff[ci] : 1.0f;
+#pragma unroll
+            for (int v = 0; v < Q4_NWR; ++v) {
+                const float w = s_w[(ci * Q4_QPAD + 4 * v + (lane >> 4)) * 4 + lj];
+                wr[ci][v] = AFF ? w * f : w;
+            }
+        }
+    };
+    auto fold_shift = [&]() {                              // s_beta from s_w / s_aff (both visible), then the interior sums; ends with a barrier
+        if constexpr (AFF) {
+            if (tid < 9 * 16) {
+                const int tap = tid >> 4, co = tid & 15;
+                float acc_ = 0.f;
+                if (co < 4 * Q4_NG) {
+#pragma unroll
+                    for (int ci = 0; ci < Q4_NCH; ++ci) acc_ = fmaf(s_aff[16 + ci], s_w[(ci * Q4_QPAD + tap * Q4_NG + (co >> 2)) * 4 + (co & 3)], acc_);
+                }
+                s_beta[tid] = acc_;
+            }
+            lds_barrier();
+#pragma unroll
+            for (int n = 0; n < Q4_NG; ++n) {
+                float t = 0.f;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) t += s_beta[tap * 16 + 4 * n + lj];
+                beta_l[n] = t;
+            }
+        }
+    };
+
+    // prologue: the first tile's DMA, then the weight loads back to back (one exposed memory latency for the lot)
     int aff_b = -1, ep_b = -1;
     float aff_v = 0.f;
     { const int trace_iter = 5; (void)trace_iter; TRACE(2); }
     if constexpr (AFF) { aff_v = fetch_affine(it.b); aff_b = it.b; }
-    issue(it);
+    issue(it, 0);
     { const int trace_iter = 5; (void)trace_iter; TRACE(3); }
     {
         // s_w[(ci * QPAD + q) * 4 + j] = W(co = 4 n + j, ci, tap), q = tap * NG + n; W(co, ci, t) = w[co][ci][t] or, transposed, w[ci][co][8 - t]
@@ -237,19 +265,16 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
         for (int u = 0; u < NWV; ++u)
             if (tid + u * 256 < S_W) s_w[tid + u * 256] = wv[u];
     }
+    q4_wait_dma<0>();                                      // this wave's share of tile 0 has landed (the weight loads are complete: their values were stored)
     lds_barrier();
     { const int trace_iter = 5; (void)trace_iter; TRACE(5); }
-    // resident B registers: wr[ci][v], lane l = quad 4 v + (l >> 4), element l & 3 (replicated over the group's four blocks)
-    float wr[Q4_NCH][Q4_NWR];
-#pragma unroll
-    for (int ci = 0; ci < Q4_NCH; ++ci)
-#pragma unroll
-        for (int v = 0; v < Q4_NWR; ++v) wr[ci][v] = s_w[(ci * Q4_QPAD + 4 * v + (lane >> 4)) * 4 + lj];
+    load_weights();
+    fold_shift();
     { const int trace_iter = 5; (void)trace_iter; TRACE(6); }
-    commit(it);
     { const int trace_iter = 5; (void)trace_iter; TRACE(1); }
     // A operand: the lane's own pixel, row 2 wave + (lane >> 5), column lane & 31
     const float* a_base = s_in + (2 * wave + (lane >> 5)) * G::RS + (lane & 31) + G::COL0;
+    int buf = 0;
     LItem prev = it;
     bool have_prev = false;
     int trace_iter = 0; (void)trace_iter;
@@ -261,9 +286,8 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
         const bool has_next = itx + nlb < r1;
         LItem nxt = it;
         if (has_next) nxt = advance(it);
-        lds_barrier();                                     // (A) s_in(t) and s_red(t-1) visible
         TRACE(1);
-        if (has_next) issue(nxt);                          // flies under the matrix phase
+        if (has_next) issue(nxt, buf ^ 1);                 // lands under the matrix phase; the other buffer was last read before the barrier below
         TRACE(2);
         if constexpr (RED) { if (have_prev) flush_partials(prev); }
         // K loop: the 3 A values of the next tap row are read while the 9 MFMAs of the current one issue
@@ -295,12 +319,7 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
         }
         }
         TRACE(3);
-        lds_barrier();                                     // (B) every wave is done reading s_in(t)
         TRACE(4);
-        if (has_next) {
-            if constexpr (AFF) { if (nxt.b != aff_b) { load_affine(nxt.b); aff_b = nxt.b; } }
-            commit(nxt);
-        }
         TRACE(5);
         // ---- epilogue straight from the accumulators: acc[n] = 4 consecutive pixels of output channel 4 n + lj
         {
@@ -324,6 +343,34 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
                 vo[n] = (ok && !(BNERV_ABL4 == 2 && d.B > 0)) ? ovoff : OOB;
                 if constexpr (RED) { if (!ok) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
+            if constexpr (AFF) {
+                // the folded shift term: every tap of an interior pixel, the existing taps of a pixel on the image border
+                const bool border = ty0 == 0 || ty0 + TH >= H || tx0 == 0 || tx0 + TW >= W;
+                if (!border) {
+#pragma unroll
+                    for (int n = 0; n < Q4_NG; ++n) acc[n] += beta_l[n];
+                } else {
+                    const int gy = ty0 + 2 * wave + (lb >> 3), gx0 = tx0 + 4 * (lb & 7);
+#pragma unroll
+                    for (int n = 0; n < Q4_NG; ++n) {
+                        float col[3];
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            float t = 0.f;
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky) t += ((unsigned)(gy + ky - 1) < (unsigned)H) ? s_beta[(ky * 3 + kx) * 16 + 4 * n + lj] : 0.f;
+                            col[kx] = t;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = 0.f;
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) t += ((unsigned)(gx0 + e + kx - 1) < (unsigned)W) ? col[kx] : 0.f;
+                            acc[n][e] += t;
+                        }
+                    }
+                }
+            }
             if constexpr (EP == BNERV_EP_BIAS || EP == BNERV_EP_PLAIN) {
 #pragma unroll
                 for (int n = 0; n < Q4_NG; ++n) bstore(ro, vo[n], so[n], acc[n] + bias_l[n]);
@@ -334,7 +381,7 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(acc[n][e] + bias_l[n], &s_, &c_); sv[e] = s_; cv[e] = c_; }
                     bstore(ro, vo[n], so[n], sv);
-                    if (d.out2) bstore(ro2, vo[n], so[n], cv);
+                    bstore(ro2, d.out2 ? vo[n] : OOB, so[n], cv);            // always issued (dropped when there is no second output): the DMA wait counts it
                 }
             } else if constexpr (EP == BNERV_EP_BIAS_GELU) {
 #pragma unroll
@@ -343,7 +390,7 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { float h_, g_; gelu_pair_f(acc[n][e] + bias_l[n], &h_, &g_); hv[e] = h_; gv[e] = g_; }
                     bstore(ro, vo[n], so[n], hv);
-                    if (d.out2) bstore(ro2, vo[n], so[n], gv);
+                    bstore(ro2, d.out2 ? vo[n] : OOB, so[n], gv);
                 }
             } else if constexpr (EP == BNERV_EP_BIAS_RES) {
                 f32x4 a0[Q4_NG];
@@ -387,6 +434,23 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
             }
         }
         TRACE(6);
+        if (has_next) {
+            // the stores of this epilogue (Q4_NG, twice that with a second output) are younger than the DMA of the next tile
+            q4_wait_dma<(TWO_OUT ? 2 : 1) * Q4_NG>();
+            lds_barrier();                                 // next tile landed in every wave; every wave is done with this tile's buffer and s_red is visible
+            if constexpr (AFF) {
+                if (nxt.b != aff_b) {                      // B > 1: the next sample's scale / shift (rare)
+                    const float v = fetch_affine(nxt.b);
+                    if (tid < 32) s_aff[tid] = v;
+                    lds_barrier();
+                    load_weights();
+                    fold_shift();
+                    aff_b = nxt.b;
+                }
+            }
+            buf ^= 1;
+            a_base = s_in + buf * S_IN + (2 * wave + (lane >> 5)) * G::RS + (lane & 31) + G::COL0;
+        }
         TRACE(7);
         prev = it;
         have_prev = true;
@@ -411,7 +475,7 @@ int launch_q4(hipStream_t st, KArgs& ka) {
     ka.w_resident = 1;
     ka.magic_tiles = div_magic(ka.tiles_x * ka.tiles_y);
     ka.magic_tiles_x = div_magic(ka.tiles_x);
-    const size_t lds = ((size_t)Q4_NCH * G::PLANE + (size_t)(NPRE * 256 - NSLOT) * 4 + (size_t)Q4_NCH * Q4_QPAD * 4 + 128 + 32) * sizeof(float);
+    const size_t lds = ((size_t)2 * NPRE * 256 * 4 + (size_t)Q4_NCH * Q4_QPAD * 4 + 128 + 32 + 9 * 16) * sizeof(float);
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         int nb = 0;
@@ -446,9 +510,6 @@ int bnerv_conv4_try(hipStream_t st, bnerv_conv::KArgs& ka) {
     BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS)
     BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS_SIN)
     BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_PLAIN)
-    BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS)
-    BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_GELU)
-    BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_RES)
     BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DGELU_SAVED)
     BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DSIN)
 #undef BNERV_CASE
