@@ -64,6 +64,11 @@ class AdanHyper(C.Structure):
                 ("sched_dev", _fp)]
 
 
+class AdanEntry(C.Structure):
+    _fields_ = [("p", _fp), ("g", _fp), ("exp_avg", _fp), ("exp_avg_sq", _fp), ("exp_avg_diff", _fp), ("neg_pre_grad", _fp),
+                ("n", C.c_int), ("bstart", C.c_int)]
+
+
 class BucketChunk(C.Structure):
     _fields_ = [("t", _fp * (ADAN_MAX_TENSORS * 2)), ("n", C.c_int * (ADAN_MAX_TENSORS * 2)),
                 ("off", C.c_int * (ADAN_MAX_TENSORS * 2)), ("n_tensors", C.c_int)]
@@ -145,12 +150,15 @@ SYMBOLS = {
     "bnerv_psnr_ws_bytes": (_Z, [_I, _I, _I, _I]),
     "bnerv_psnr": (_I, [_V, _V, _V, _V, _V, _Z, _I, _I, _I, _I]),
     "bnerv_adan_multi_tensor": (_I, [_V, C.POINTER(AdanChunk), C.POINTER(AdanHyper)]),
+    "bnerv_adan_table_blocks": (_I, [_I]),
+    "bnerv_adan_table": (_I, [_V, _V, _I, _I, C.POINTER(AdanHyper)]),
+    "bnerv_fetch_frame": (_I, [_V, _V, _V, _V, _I, _Z, _V, _V]),
     "bnerv_bucket_gather": (_I, [_V, C.POINTER(BucketChunk), _V, _F]),
     "bnerv_bucket_scatter": (_I, [_V, C.POINTER(BucketChunk), _V, _F]),
 }
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class BnervError(RuntimeError):

@@ -290,6 +290,37 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
         if (has_next) issue(nxt, buf ^ 1);                 // lands under the matrix phase; the other buffer was last read before the barrier below
         TRACE(2);
         if constexpr (RED) { if (have_prev) flush_partials(prev); }
+        // the epilogue's auxiliary tensors (residual / saved activations) are fetched NOW, into registers: they land under the matrix
+        // phase instead of costing one exposed memory latency per tensor in the epilogue
+        constexpr int NAUX = (EP == BNERV_EP_BIAS_RES) ? 1 : (EP == BNERV_EP_DGELU_SAVED) ? 2 : (EP == BNERV_EP_DSIN) ? 3 : 0;
+        f32x4 ax0[NAUX ? Q4_NG : 1], ax1[NAUX >= 2 ? Q4_NG : 1], ax2[NAUX >= 3 ? Q4_NG : 1];
+        unsigned so[Q4_NG], vo[Q4_NG];
+        bool ch_ok[Q4_NG];
+        {
+            const int ty0 = it.ty * TH, tx0 = it.tx * TW;
+            const unsigned ob = (unsigned)((((it.b * Cout) * H + ty0 + 2 * wave) * W + tx0) * 4);
+            const bool full = ty0 + TH <= H && tx0 + TW <= W;
+            bool px_ok = true;
+            if (!full) px_ok = (ty0 + 2 * wave + (lb >> 3) < H) && (tx0 + 4 * (lb & 7) < W);
+#pragma unroll
+            for (int n = 0; n < Q4_NG; ++n) {
+                so[n] = ob + (unsigned)n * nstep;
+                ch_ok[n] = px_ok && (4 * n + lj < Cout);
+                vo[n] = (ch_ok[n] && !(BNERV_ABL4 == 2 && d.B > 0)) ? ovoff : OOB;
+            }
+            if constexpr (NAUX >= 1) {
+#pragma unroll
+                for (int n = 0; n < Q4_NG; ++n) ax0[n] = bload(ra0, vo[n], so[n]);
+            }
+            if constexpr (NAUX >= 2) {
+#pragma unroll
+                for (int n = 0; n < Q4_NG; ++n) ax1[n] = bload(ra1, vo[n], so[n]);
+            }
+            if constexpr (NAUX >= 3) {
+#pragma unroll
+                for (int n = 0; n < Q4_NG; ++n) ax2[n] = d.aux2 ? bload(ra2, vo[n], so[n]) : f32x4{1.f, 1.f, 1.f, 1.f};
+            }
+        }
         // K loop: the 3 A values of the next tap row are read while the 9 MFMAs of the current one issue
         float a_cur[3], a_nxt[3];
         if (BNERV_ABL4 != 1 || d.B < 0) {
@@ -324,8 +355,6 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
         // ---- epilogue straight from the accumulators: acc[n] = 4 consecutive pixels of output channel 4 n + lj
         {
             const int ty0 = it.ty * TH, tx0 = it.tx * TW;
-            const unsigned ob = (unsigned)((((it.b * Cout) * H + ty0 + 2 * wave) * W + tx0) * 4);
-            const bool full = ty0 + TH <= H && tx0 + TW <= W;
             if constexpr (RED) {
                 if (it.b != ep_b) {
 #pragma unroll
@@ -333,15 +362,9 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
                     ep_b = it.b;
                 }
             }
-            bool px_ok = true;
-            if (!full) px_ok = (ty0 + 2 * wave + (lb >> 3) < H) && (tx0 + 4 * (lb & 7) < W);
-            unsigned so[Q4_NG], vo[Q4_NG];
+            if constexpr (RED) {
 #pragma unroll
-            for (int n = 0; n < Q4_NG; ++n) {
-                so[n] = ob + (unsigned)n * nstep;
-                const bool ok = px_ok && (4 * n + lj < Cout);
-                vo[n] = (ok && !(BNERV_ABL4 == 2 && d.B > 0)) ? ovoff : OOB;
-                if constexpr (RED) { if (!ok) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int n = 0; n < Q4_NG; ++n) { if (!ch_ok[n]) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
             if constexpr (AFF) {
                 // the folded shift term: every tap of an interior pixel, the existing taps of a pixel on the image border
@@ -393,28 +416,21 @@ __global__ __launch_bounds__(256, 3) void conv_q4_kernel(const KArgs ka, const S
                     bstore(ro2, d.out2 ? vo[n] : OOB, so[n], gv);
                 }
             } else if constexpr (EP == BNERV_EP_BIAS_RES) {
-                f32x4 a0[Q4_NG];
 #pragma unroll
-                for (int n = 0; n < Q4_NG; ++n) a0[n] = bload(ra0, vo[n], so[n]);
-#pragma unroll
-                for (int n = 0; n < Q4_NG; ++n) bstore(ro, vo[n], so[n], acc[n] + bias_l[n] + a0[n]);
-            } else {                                       // DGELU_SAVED / DSIN, one channel quad at a time (12 aux registers)
+                for (int n = 0; n < Q4_NG; ++n) bstore(ro, vo[n], so[n], acc[n] + bias_l[n] + ax0[n]);
+            } else {                                       // DGELU_SAVED / DSIN
                 float ps[Q4_NG], pt[Q4_NG];
 #pragma unroll
                 for (int n = 0; n < Q4_NG; ++n) {
-                    const f32x4 a0 = bload(ra0, vo[n], so[n]);
-                    const f32x4 a1 = bload(ra1, vo[n], so[n]);
-                    f32x4 a2 = {1.f, 1.f, 1.f, 1.f};
-                    if constexpr (EP == BNERV_EP_DSIN) { if (d.aux2) a2 = bload(ra2, vo[n], so[n]); }
                     f32x4 r;
                     const f32x4 v = acc[n];
                     ps[n] = 0.f; pt[n] = 0.f;
                     if constexpr (EP == BNERV_EP_DGELU_SAVED) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { r[e] = v[e] * scl[n] * a0[e]; ps[n] = fmaf(v[e], a1[e], ps[n]); pt[n] += v[e]; }
+                        for (int e = 0; e < 4; ++e) { r[e] = v[e] * scl[n] * ax0[n][e]; ps[n] = fmaf(v[e], ax1[n][e], ps[n]); pt[n] += v[e]; }
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { r[e] = (a1[e] + v[e] * scl[n]) * a2[e]; ps[n] = fmaf(v[e], a0[e], ps[n]); pt[n] += v[e]; }
+                        for (int e = 0; e < 4; ++e) { r[e] = (ax1[n][e] + v[e] * scl[n]) * ax2[n][e]; ps[n] = fmaf(v[e], ax0[n][e], ps[n]); pt[n] += v[e]; }
                     }
                     bstore(ro, vo[n], so[n], r);
                 }

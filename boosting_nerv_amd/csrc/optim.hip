@@ -12,6 +12,7 @@
 #include "sidejob.h"
 
 namespace {
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 // bstart[t] = first block of tensor t in the flat grid (tensor t owns min(ceil(n_t / 1024), 1024) blocks): a (blocks of the largest
 // tensor) x (tensors) grid launched 48 x 1024 blocks for the chunk that holds the 1.1 M-element stem matrix, ~1500 of them with work
@@ -57,6 +58,60 @@ __global__ __launch_bounds__(256) void adan_kernel(const AdanArgs a) {
     }
 }
 
+__device__ __forceinline__ void adan_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                            float* __restrict__ d, float* __restrict__ ng, int n, int bx, int gx, const bnerv_adan_hyper& h) {
+    const float lr = h.sched_dev[0], bc1 = h.sched_dev[1], bc2 = h.sched_dev[2], bc3s = h.sched_dev[3];
+    const bool first = h.sched_dev[4] != 0.f;
+    const float b1 = h.beta1, b2 = h.beta2, b3 = h.beta3, eps = h.eps, wd = h.weight_decay, clip = h.clip_global_grad_norm;
+    const float step_size = lr / bc1, step_size_diff = lr * b2 / bc2;
+    for (int i = bx * 256 + threadIdx.x; i < n; i += gx * 256) {
+        const float gi = g[i] * clip;
+        float t0 = (first ? -gi : ng[i]) + gi;                       // g - g_prev   (0 on the first step)
+        const float mi = m[i] * b1 + (1.0f - b1) * gi;
+        const float di = d[i] * b2 + (1.0f - b2) * t0;
+        t0 = t0 * b2 + gi;
+        const float vi = v[i] * b3 + (1.0f - b3) * (t0 * t0);
+        const float denom = sqrtf(vi) / bc3s + eps;
+        float pi = p[i];
+        if (h.no_prox) {
+            pi *= (1.0f - lr * wd);
+            pi += -step_size * (mi / denom);
+            pi += -step_size_diff * (di / denom);
+        } else {
+            pi += -step_size * (mi / denom);
+            pi += -step_size_diff * (di / denom);
+            pi /= (1.0f + lr * wd);
+        }
+        p[i] = pi; m[i] = mi; v[i] = vi; d[i] = di; ng[i] = -gi;
+    }
+}
+
+// table form: the tensor of a block is found by bisection over bstart in device memory (uniform addresses: scalar loads)
+__global__ __launch_bounds__(256) void adan_table_kernel(const bnerv_adan_entry* __restrict__ tab, const int n_tensors, const bnerv_adan_hyper h) {
+    int t = 0;
+    for (int hi = n_tensors; hi - t > 1;) {
+        const int mid = (t + hi) >> 1;
+        if ((int)blockIdx.x >= tab[mid].bstart) t = mid; else hi = mid;
+    }
+    const bnerv_adan_entry e = tab[t];
+    const int gx = min(cdiv_dev(e.n, 256 * 4), 1024);
+    adan_update(e.p, e.g, e.exp_avg, e.exp_avg_sq, e.exp_avg_diff, e.neg_pre_grad, e.n, (int)blockIdx.x - e.bstart, gx, h);
+}
+
+__global__ __launch_bounds__(256) void fetch_frame_kernel(const float* __restrict__ clip, const double* __restrict__ norms, const float* __restrict__ sel,
+                                                          const int n_frames, const size_t frame_elems, float* __restrict__ dst, double* __restrict__ dst_norm) {
+    int k = (int)sel[0];
+    k = k < 0 ? 0 : (k >= n_frames ? n_frames - 1 : k);
+    const f32x4* src = reinterpret_cast<const f32x4*>(clip + (size_t)k * frame_elems);
+    f32x4* out = reinterpret_cast<f32x4*>(dst);
+    const size_t n4 = frame_elems / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (size_t i = n4 * 4; i < frame_elems; ++i) dst[i] = clip[(size_t)k * frame_elems + i];
+        if (norms && dst_norm) dst_norm[0] = norms[k];
+    }
+}
+
 struct BucketArgs { bnerv_bucket_chunk c; float* bucket; float scale; int to_bucket; int bstart[BNERV_ADAN_MAX_TENSORS * 2 + 1]; };
 
 __global__ __launch_bounds__(256) void bucket_kernel(const BucketArgs a) {
@@ -95,6 +150,34 @@ extern "C" int bnerv_adan_multi_tensor(void* stream, const bnerv_adan_chunk* chu
     for (int i = chunk->n_tensors; i <= BNERV_ADAN_MAX_TENSORS; ++i) a.bstart[i] = blocks;
     hipLaunchKernelGGL(adan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     BNERV_LAUNCH_CHECK("adan");
+    return BNERV_OK;
+}
+
+extern "C" int bnerv_adan_table_blocks(int n) {
+    if (n <= 0) return 0;
+    const int gx = cdiv(n, 256 * 4);
+    return gx > 1024 ? 1024 : gx;
+}
+
+extern "C" int bnerv_adan_table(void* stream, const bnerv_adan_entry* table_dev, int n_tensors, int total_blocks, const bnerv_adan_hyper* h) {
+    BNERV_REQUIRE(table_dev && h && h->sched_dev, "adan_table: null args");
+    BNERV_REQUIRE(n_tensors > 0 && total_blocks > 0, "adan_table: n_tensors=%d total_blocks=%d", n_tensors, total_blocks);
+    hipLaunchKernelGGL(adan_table_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n_tensors, *h);
+    BNERV_LAUNCH_CHECK("adan_table");
+    return BNERV_OK;
+}
+
+extern "C" int bnerv_fetch_frame(void* stream, const float* clip, const double* norms, const float* sel_dev, int n_frames, size_t frame_elems,
+                                 float* dst_img, double* dst_norm) {
+    BNERV_REQUIRE(clip && sel_dev && dst_img && n_frames > 0 && frame_elems > 0, "fetch_frame: bad args");
+    BNERV_REQUIRE((reinterpret_cast<uintptr_t>(clip) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst_img) & 15) == 0 && (frame_elems % 4 == 0 || n_frames == 1),
+                  "fetch_frame: 16-byte aligned frames required");
+    const size_t n4 = frame_elems / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fetch_frame_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, clip, norms, sel_dev, n_frames, frame_elems, dst_img, dst_norm);
+    BNERV_LAUNCH_CHECK("fetch_frame");
     return BNERV_OK;
 }
 

@@ -37,10 +37,32 @@ class TrainStep:
         # group, so the path the scaling runs take can be tested on a single-GPU box
         self.bucket = GradBucket(model.parameters(), process_group, force=force_bucket) if (world_size > 1 or force_bucket) else None
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self._fetching = False                               # inside step_frame(): the step starts with the frame fetch
         self._wplan_entries = 0                              # entries of the capture stream context's weight-fragment plan
+        self._clip = self._clip_norms = None                 # bind_clip(): the resident clip step_frame() picks its frame from
 
     # ---- pieces -------------------------------------------------------------------------------------------------------
+    def bind_clip(self, frames, norms):
+        """The clip this step trains on, resident on the device: frames [N, C, H, W] fp32, norms [N] fp64 ((idx + 1) / N,
+        hnerv_utils.py:47).  step_frame(i) then trains frame i with ONE host -> device copy per step (the 32-byte schedule record that
+        also carries i) instead of two device copies and that record: the frame is fetched by the first launch of the (captured) step.
+        Needs the Adan optimizer of this package (its schedule record carries the index)."""
+        if not hasattr(self.opt, "finish_capture"):
+            raise TypeError("bind_clip needs the fused Adan optimizer (its device schedule record carries the frame index)")
+        assert frames.shape[1:] == self.static_img.shape[1:] and self.static_img.shape[0] == 1, "bind_clip: one frame per step"
+        self._clip = frames.contiguous()
+        self._clip_norms = norms.to(torch.float64).contiguous()
+        self.graph_a = self.graph_b = None
+
+    def _fetch(self):
+        from . import _lib as L
+        sel = self.opt._sched[0][1]
+        L.check(L.load().bnerv_fetch_frame(L.stream(), L.ptr(self._clip), L.ptr(self._clip_norms), sel.data_ptr() + 5 * 4, self._clip.shape[0],
+                                           self._clip[0].numel(), L.ptr(self.static_img), L.ptr(self.static_idx)), "bnerv_fetch_frame")
+
     def _fwd_bwd(self):
+        if self._fetching:
+            self._fetch()
         self.opt.zero_grad(set_to_none=True)
         inp = self.static_img if self.takes_image else self.static_idx
         img_out, _, _ = self.model(inp, norm_idx=self.static_idx)
@@ -87,13 +109,14 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
 
-    def _eager(self):
+    def _eager(self, prepared=False):
         self._fwd_bwd()
         if self.bucket is not None:
             self.bucket.allreduce_mean()
         if self.clip_max_norm > 0:
             torch.nn.utils.clip_grad_norm_(self.params, self.clip_max_norm)
-        self.opt.prepare_step()
+        if not prepared:
+            self.opt.prepare_step()
         self.opt.launch_step()
 
     def _bucket_calls(self, which):
@@ -124,6 +147,8 @@ class TrainStep:
             L.reserve_ctx(self._cap_ctx)
         with L.use_ctx(self._cap_ctx):
             self._capture_in_ctx(pool)
+        if hasattr(self.opt, "finish_capture"):
+            self.opt.finish_capture()           # descriptor tables the captured optimizer launch points at (uploaded once, outside the graph)
 
     def _capture_in_ctx(self, pool):
         import os
@@ -171,18 +196,33 @@ class TrainStep:
     def __call__(self, img, norm_idx):
         """img [B,3,H,W] fp32 and norm_idx [B] fp64, already on the device.  Returns (loss, psnr[B]) device tensors that are
         overwritten by the next call."""
+        if self._fetching:
+            self._fetching = False
+            self.graph_a = self.graph_b = None      # the captured step started with a frame fetch: capture the plain form
         self.static_img.copy_(img, non_blocking=True)
         self.static_idx.copy_(norm_idx, non_blocking=True)
+        return self._run(None)
+
+    def step_frame(self, i):
+        """Train frame i of the clip given to bind_clip().  Same step as __call__(frames[i:i+1], norms[i:i+1])."""
+        assert self._clip is not None, "step_frame: call bind_clip(frames, norms) first"
+        if not self._fetching:
+            self._fetching = True
+            self.graph_a = self.graph_b = None
+        return self._run(int(i))
+
+    def _run(self, frame):
         if self.graph_a is not None and getattr(self.opt, "state_epoch", 0) != self._opt_epoch:
             self.graph_a = self.graph_b = None      # optimizer state tensors were replaced (restart_opt / load_state_dict): re-capture
+        if frame is not None:
+            self.opt.prepare_step(aux=frame)    # the schedule record (with the frame index) precedes the step's first launch
         if not self.use_graph or self.n_calls < self.warmup_eager:
-            self._eager()
+            self._eager(prepared=frame is not None)
         else:
+            if frame is None:
+                self.opt.prepare_step()         # host side of THIS step (a capture below records its kernels, runs nothing)
             if self.graph_a is None:
-                self.opt.prepare_step()         # host side of THIS step (the capture below records its kernels, runs nothing)
                 self._capture()
-            else:
-                self.opt.prepare_step()
             self.graph_a.replay()
             if self.graph_b is not None:
                 import torch.distributed as dist

@@ -4,7 +4,7 @@ done by ONE fused multi-tensor HIP kernel per <=48 tensors (bnerv_adan_multi_ten
 launches (optimizer.py:296-362).  This is the slot the reference reserves for the external `fused_adan` CUDA extension
 (optimizer.py:365-395), which it never ships.
 
-`step()` = `prepare_step()` (host: step count, bias corrections, lr -> a 5-float device buffer, via a pinned async copy)
+`step()` = `prepare_step()` (host: step count, bias corrections, lr -> an 8-float device buffer, via a pinned async copy)
 + `launch_step()` (kernel launches only -> capturable in a hipGraph; every scalar that changes per step is read from the
 device buffer, so a captured step replays with a moving LR schedule)."""
 import ctypes as C
@@ -34,7 +34,8 @@ class Adan(Optimizer):
                         foreach=foreach, fused=fused)
         super().__init__(params, defaults)
         self._sched = {}          # group index -> (pinned host [5], device [5])
-        self._chunk_cache = {}    # group index -> (key, [AdanChunk], tensors the chunks point into)
+        self._cap_tab = {}        # group index -> (pinned host, device) descriptor table of a captured launch, reserved outside the capture
+        self._chunk_cache = {}    # group index -> (key, device descriptor table, n, blocks, tensors the table points into, pending host table)
         self.state_epoch = 0      # bumped whenever state tensors are replaced: a captured step (engine.TrainStep) re-captures
 
     def _invalidate(self):
@@ -48,6 +49,7 @@ class Adan(Optimizer):
         for group in self.param_groups:
             group.setdefault("no_prox", False)
         self.__dict__.setdefault("_sched", {})
+        self.__dict__.setdefault("_cap_tab", {})
         self._invalidate()
 
     def load_state_dict(self, state_dict):
@@ -81,8 +83,10 @@ class Adan(Optimizer):
         return torch.clamp(self.defaults["max_grad_norm"] / (total + self.param_groups[-1]["eps"]), max=1.0).item()
 
     @torch.no_grad()
-    def prepare_step(self):
-        """Host side of a step: advance the step count and publish {lr, bc1, bc2, sqrt(bc3), first_step} to the device."""
+    def prepare_step(self, aux=None):
+        """Host side of a step: advance the step count and publish {lr, bc1, bc2, sqrt(bc3), first_step, aux} to the device.
+        `aux` (a float, optional) rides in slot 5 of the same 32-byte record: engine.TrainStep puts the index of the step's frame
+        there when the clip is resident on the device, so a step costs ONE host -> device copy."""
         for gi, group in enumerate(self.param_groups):
             beta1, beta2, beta3 = group["betas"]
             group["step"] = group.get("step", 0) + 1
@@ -96,8 +100,12 @@ class Adan(Optimizer):
                 # carries an event recorded after its copy was enqueued; a slot is rewritten only once that copy has executed, which
                 # bounds the host's run-ahead to _RING steps by construction (in practice the HIP launch queue already blocks the host
                 # long before 512 graph launches are outstanding; the guard makes that an invariant instead of an observation)
-                self._sched[gi] = (torch.zeros(self._RING, 5, dtype=torch.float32).pin_memory(), torch.zeros(5, dtype=torch.float32, device=dev),
+                self._sched[gi] = (torch.zeros(self._RING, 8, dtype=torch.float32).pin_memory(), torch.zeros(8, dtype=torch.float32, device=dev),
                                    [None] * self._RING)
+            if gi not in self._cap_tab:
+                # room for the descriptor table of a CAPTURED optimizer launch (launch_step inside a hipGraph capture may not allocate)
+                nb = len(group["params"]) * C.sizeof(L.AdanEntry)
+                self._cap_tab[gi] = (torch.empty(nb, dtype=torch.uint8).pin_memory(), torch.empty(nb, dtype=torch.uint8, device=dev))
             ring, devbuf, events = self._sched[gi]
             slot = group["step"] % self._RING
             if events[slot] is not None:
@@ -105,6 +113,8 @@ class Adan(Optimizer):
             host = ring[slot]
             host[0], host[1], host[2], host[3] = group["lr"], bc1, bc2, math.sqrt(bc3)
             host[4] = 1.0 if group["step"] == 1 else 0.0
+            if aux is not None:
+                host[5] = float(aux)
             devbuf.copy_(host, non_blocking=True)
             if events[slot] is None:
                 events[slot] = torch.cuda.Event()
@@ -123,7 +133,8 @@ class Adan(Optimizer):
 
     @torch.no_grad()
     def launch_step(self, clip=1.0):
-        """Device side of a step: one fused kernel per <=48 tensors.  No host<->device traffic, no sync."""
+        """Device side of a step: ONE fused launch over a device-resident descriptor table (any number of tensors).  No sync; the
+        only host<->device traffic is the table upload when a tensor address changed (never in a replayed step)."""
         lib = L.load()
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
@@ -134,32 +145,52 @@ class Adan(Optimizer):
             sts = [self._ensure_state(p, group.get("step", 1), clip) for p in ps]
             key = tuple((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                          st["exp_avg_diff"].data_ptr(), st["neg_pre_grad"].data_ptr()) for p, st in zip(ps, sts))
-            cached = self._chunk_cache.get(gi)
+            capturing = torch.cuda.is_current_stream_capturing()
+            ck = (gi, capturing)        # a captured launch owns its table: an eager step in between must not rewrite the addresses it replays with
+            cached = self._chunk_cache.get(ck)
             if cached is None or cached[0] != key:
-                chunks = []
                 # (not p.grad: it is alive whenever the step launches, and pinning it would move the next eager gradient elsewhere)
                 keep = [(p, st["exp_avg"], st["exp_avg_sq"], st["exp_avg_diff"], st["neg_pre_grad"]) for p, st in zip(ps, sts)]
-                for i0 in range(0, len(ps), L.ADAN_MAX_TENSORS):
-                    ck = L.AdanChunk()
-                    sub = ps[i0:i0 + L.ADAN_MAX_TENSORS]
-                    for j, p in enumerate(sub):
-                        if not (p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32 and p.grad.dtype == torch.float32):
-                            raise L.BnervError("fused Adan needs contiguous fp32 parameters and gradients")
-                        st = sts[i0 + j]
-                        ck.p[j], ck.g[j] = p.data_ptr(), p.grad.data_ptr()
-                        ck.exp_avg[j], ck.exp_avg_sq[j] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                        ck.exp_avg_diff[j], ck.neg_pre_grad[j] = st["exp_avg_diff"].data_ptr(), st["neg_pre_grad"].data_ptr()
-                        ck.n[j] = p.numel()
-                    ck.n_tensors = len(sub)
-                    chunks.append(ck)
-                self._chunk_cache[gi] = (key, chunks, keep)
-            else:
-                chunks = cached[1]
+                tab = (L.AdanEntry * len(ps))()
+                blocks = 0
+                for j, (p, st) in enumerate(zip(ps, sts)):
+                    if not (p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32 and p.grad.dtype == torch.float32):
+                        raise L.BnervError("fused Adan needs contiguous fp32 parameters and gradients")
+                    e = tab[j]
+                    e.p, e.g = p.data_ptr(), p.grad.data_ptr()
+                    e.exp_avg, e.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                    e.exp_avg_diff, e.neg_pre_grad = st["exp_avg_diff"].data_ptr(), st["neg_pre_grad"].data_ptr()
+                    e.n, e.bstart = p.numel(), blocks
+                    blocks += lib.bnerv_adan_table_blocks(p.numel())
+                raw = bytes(tab)
+                if capturing:
+                    # nothing may allocate pinned or device memory inside a capture: prepare_step() (always called before it) set both aside
+                    host, dev_tab = self._cap_tab[gi]
+                    if host.numel() < len(raw):
+                        raise L.BnervError("fused Adan: the capture-time descriptor table is larger than the one prepare_step() reserved")
+                    C.memmove(host.data_ptr(), raw, len(raw))
+                else:
+                    host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
+                    # ONE device table per group, reused while the tensor count does not change
+                    dev_tab = cached[1] if (cached is not None and cached[1].numel() == host.numel()) else torch.empty(host.numel(), dtype=torch.uint8, device=ps[0].device)
+                cached = [key, dev_tab, len(ps), blocks, keep, host]
+                self._chunk_cache[ck] = cached
+            if cached[5] is not None and not capturing:
+                cached[1].copy_(cached[5], non_blocking=True)      # stream-ordered before the launch below
+                cached[5] = None                                   # (inside a capture the upload waits for finish_capture(): a copy node would replay every step)
             beta1, beta2, beta3 = group["betas"]
             hyper = L.AdanHyper(beta1, beta2, beta3, group["eps"], group["weight_decay"], clip, int(group["no_prox"]),
                                 self._sched[gi][1].data_ptr())
-            for ck in chunks:
-                L.check(lib.bnerv_adan_multi_tensor(L.stream(), C.byref(ck), C.byref(hyper)), "bnerv_adan_multi_tensor")
+            L.check(lib.bnerv_adan_table(L.stream(), cached[1].data_ptr(), cached[2], cached[3], C.byref(hyper)), "bnerv_adan_table")
+
+    def finish_capture(self):
+        """After a hipGraph capture that contained launch_step(): upload the descriptor tables that capture referenced (the captured
+        launch holds the table's ADDRESS; its content is written here, once, outside the graph)."""
+        for cached in self._chunk_cache.values():
+            if cached[5] is not None:
+                cached[1].copy_(cached[5], non_blocking=True)
+                torch.cuda.current_stream().synchronize()          # the pinned buffer is rewritten by the next capture
+                cached[5] = None
 
     @torch.no_grad()
     def step(self, closure=None):

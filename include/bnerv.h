@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BNERV_ABI_VERSION 4
+#define BNERV_ABI_VERSION 5
 
 #define BNERV_OK 0
 #define BNERV_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -377,6 +377,29 @@ typedef struct {
 } bnerv_adan_hyper;
 
 int bnerv_adan_multi_tensor(void* stream, const bnerv_adan_chunk* chunk, const bnerv_adan_hyper* h);
+
+/* Table form of the same step (ABI 5): the descriptors of ALL tensors live in DEVICE memory, so one launch serves any number of
+ * tensors (the chunk form passes 48 descriptors by value: C1's 186 tensors were four dependent launches per step).  The caller
+ * fills the table on the host -- entry i owns blocks [bstart, bstart + bnerv_adan_table_blocks(n)) of the grid, bstart = running
+ * sum -- and uploads it once; it stays valid while the tensors keep their addresses.  Same arithmetic, same order. */
+typedef struct {
+    float* p;
+    const float* g;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float* exp_avg_diff;
+    float* neg_pre_grad;
+    int n;
+    int bstart;
+} bnerv_adan_entry;
+int bnerv_adan_table_blocks(int n);
+int bnerv_adan_table(void* stream, const bnerv_adan_entry* table_dev, int n_tensors, int total_blocks, const bnerv_adan_hyper* h);
+
+/* Frame fetch of a step whose clip is resident in device memory (train_nerv_all.py:329 moves one frame host -> device per step; with
+ * the clip in HBM the step only needs to know WHICH frame): copies frame k = (int)sel_dev[0] of clip [N][frame_elems] to dst_img
+ * and norm[k] (fp64, hnerv_utils.py:47) to dst_norm.  sel_dev is device memory, so a captured step replays with a moving index. */
+int bnerv_fetch_frame(void* stream, const float* clip, const double* norms, const float* sel_dev, int n_frames, size_t frame_elems,
+                      float* dst_img, double* dst_norm);
 
 /* flat-bucket helpers for the data-parallel gradient exchange (replaces DDP's bucket copy, train_nerv_all.py:254):
  * gather `n_tensors` gradients into one contiguous bucket scaled by `scale`, and scatter it back. */

@@ -300,6 +300,43 @@ def test_weight_fragment_plan_changes_no_bit(monkeypatch):
         assert torch.equal(sd1[k], sd0[k]), k
 
 
+def test_step_frame_on_resident_clip_equals_step_on_copies():
+    """TrainStep.bind_clip / step_frame (the frame is fetched by the first launch of the captured step from a clip resident in HBM;
+    its index travels in the optimizer's 32-byte schedule record) trains exactly what __call__(frames[i:i+1], norms[i:i+1]) trains:
+    losses and parameters after 7 steps (eager warm-up, capture, replays, moving frames and learning rate) are bit-equal.  Also
+    covers the table form of the fused Adan launch (ONE launch, descriptors in device memory) across capture and replay."""
+    from boosting_nerv_amd.engine import TrainStep
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    from boosting_nerv_amd.optimizer import Adan
+    from boosting_nerv_amd.synth import SyntheticVideo
+    vid = SyntheticVideo(4, 180, 320)
+    fd = torch.stack([vid.frame(i) for i in range(4)]).to(DEV)
+    nd = torch.tensor([(i + 1) / 4 for i in range(4)], dtype=torch.float64).to(DEV)
+    order = [2, 0, 3, 1, 1, 2, 0]
+
+    def run(by_index):
+        torch.manual_seed(1)
+        model = NeRV_Boost(1, args=configs.tiny_nerv()).to(DEV)
+        opt = Adan(model.parameters(), lr=0.003)
+        step = TrainStep(model, opt, "Fusion10_freq", False, (1, 3, 180, 320), torch.device(DEV), use_graph=True, warmup_eager=2)
+        if by_index:
+            step.bind_clip(fd, nd)
+        losses, psnrs = [], []
+        for s, i in enumerate(order):
+            for g in opt.param_groups:
+                g["lr"] = 0.003 * (0.5 + 0.1 * s)
+            loss, ps = step.step_frame(i) if by_index else step(fd[i:i + 1], nd[i:i + 1])
+            losses.append(loss.item())
+            psnrs.append(ps.item())
+        assert step.graph_a is not None
+        return losses, psnrs, {k: v.detach().clone() for k, v in model.state_dict().items()}
+    l1, p1, sd1 = run(True)
+    l0, p0, sd0 = run(False)
+    assert l1 == l0 and p1 == p0, (l1, l0)
+    for k in sd1:
+        assert torch.equal(sd1[k], sd0[k]), k
+
+
 def test_short_schedule_end_psnr_matches_oracle():
     """SURVEY 8(d) parity gate: train the tiny NeRV_Boost for 3 epochs over 6 synthetic frames with the cosine schedule, same
     init and frame order on both sides, then evaluate every frame: the end PSNR (mean over frames, fp32 model) of the HIP

@@ -14,12 +14,13 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 if len(marks) < 3:
     sys.exit(f"marker {marker!r} found {len(marks)} times in {f}")
-a, b = marks[-3], marks[-2]           # one full step: from just after one marker to the next (marker = end of the loss)
+m = len(marks) // 2 if '--mid' in sys.argv else -3   # --mid: a step from the middle of the run (replayed graph steps of a --steps_only run)
+a, b = marks[m], marks[m + 1]        # one full step: from just after one marker to the next (marker = end of the loss)
 seg = rows[a + 1:b + 1]
 t0 = int(seg[0]["Start_Timestamp"])
 prev_end = t0
 busy = 0
-print(f"# one eager step: {len(seg)} launches, wall {(int(seg[-1]['End_Timestamp']) - t0) / 1e3:.1f} us")
+print(f"# one step: {len(seg)} launches, wall {(int(seg[-1]['End_Timestamp']) - t0) / 1e3:.1f} us")
 print("| # | start us | dur us | gap us | blocks | wg | lds | vgpr | kernel |\n|---|---|---|---|---|---|---|---|---|")
 for i, r in enumerate(seg):
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])

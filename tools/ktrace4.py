@@ -17,8 +17,16 @@ x = torch.randn(B, Cc, H, W, device=dev)
 w, b = torch.randn(Cc, Cc, 3, 3, device=dev) / 10, torch.randn(Cc, device=dev)
 sc, sh = torch.randn(B, Cc, device=dev) * 0.1, torch.randn(B, Cc, device=dev) * 0.1
 out = torch.empty_like(x)
+mode = sys.argv[1] if len(sys.argv) > 1 else "bias"
+y0, g2, v2 = torch.randn_like(x), torch.randn_like(x), torch.randn_like(x)
+part = torch.empty(L.load().bnerv_conv_tiles(H, W), B, 2, Cc, device=dev)
 for _ in range(4):
-    ops._conv(x, w, b, out, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS, scale=sc, shift=sh)
+    if mode == "bias":
+        ops._conv(x, w, b, out, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS)
+    elif mode == "sin":
+        ops._conv(x, w, b, out, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_SIN, out2=y0)
+    else:
+        ops._conv(x, w, None, out, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN, transposed=1, aux0=y0, aux1=g2, aux2=v2, scale=sc, partial=part)
 torch.cuda.synchronize()
 lib = L.load()
 buf = np.zeros(1024 * 4 * 6 * 8, dtype=np.uint64)
@@ -43,7 +51,7 @@ if (pp[:, 2] > 0).all():
     for nm, a_, b_ in (("entry -> slot constants done", 0, 2), ("issue first tile", 2, 3), ("weight loads issued", 3, 4), ("weights in LDS (waits for them)", 4, 5), ("84 weight registers", 5, 6), ("commit (waits for the tile)", 6, 1)):
         print(f"   {nm:34s} median {np.median(pp[:, b_] - pp[:, a_]):7.0f} cycles")
 valid[:, :, 5] = False
-names = ["top->barA", "issue", "K loop", "barB wait", "commit", "epilogue", "-"]
+names = ["advance", "issue DMA", "K loop", "-", "-", "epilogue", "wait DMA + barrier"]
 for it in range(6):
     v = valid[:, :, it]
     if not v.any():
