@@ -245,6 +245,48 @@ def cpu_baseline(args, model_cpu_sd, frames, norm_idxs, budget_s=30.0, warmup=3,
                       f"oracle/cpu_ref.py on torch CPU fp32, {torch.get_num_threads()} threads, timed budget {budget_s:.0f} s"}
 
 
+def parity_leg(args, model, opt, step_fn, frames, norm, takes_image, s0, n_iter, set_lr, K=3, budget_s=60.0):
+    """Checker leg (like cpu_baseline: the oracle is only the yardstick here).  From the state the timed steps left behind -- parameters
+    AND optimizer state -- K further train steps on the HIP path and on oracle/cpu_ref.py (same frames, same learning rates), compared
+    step by step: max |image difference| of the forward at the step's parameters, relative loss difference, train-PSNR difference in
+    dB.  north_star's gate: PSNR within +-0.02 dB, per-pixel fp32 rtol 1e-3."""
+    from oracle import cpu_ref
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    named = dict(model.named_parameters())
+    sd = {k: v.detach().cpu().clone().float().requires_grad_(True) for k, v in model.state_dict().items()}
+    adan = cpu_ref.AdanState(list(sd.values()), lr=args.lr)
+    for i, k in enumerate(sd):
+        st = opt.state.get(named.get(k), {})
+        if "exp_avg" in st:
+            adan.m[i], adan.n[i], adan.d[i] = st["exp_avg"].cpu().clone(), st["exp_avg_sq"].cpu().clone(), st["exp_avg_diff"].cpu().clone()
+            adan.prev[i] = -st["neg_pre_grad"].cpu()
+    adan.step_n = int(opt.param_groups[0].get("step", 0))
+    rows, t0 = [], time.time()
+    for j in range(K):
+        if j > 0 and time.time() - t0 > budget_s:
+            break
+        s = s0 + j
+        i = s % n_iter
+        set_lr(s, i)
+        adan.lr = float(opt.param_groups[0]["lr"])
+        with torch.no_grad():
+            model.eval()
+            img_h = model(frames[i:i + 1] if takes_image else norm[i:i + 1], norm_idx=norm[i:i + 1])[0].float().cpu()
+            model.train()
+        loss_h, psnr_h = step_fn(i)
+        loss_h, psnr_h = float(loss_h.item()), float(psnr_h.mean().item())
+        loss_c, psnr_c, img_c = cpu_ref.train_step(args.model, sd, adan, frames[i:i + 1].cpu(), norm[i:i + 1].cpu(), args.loss)
+        rows.append({"max_abs_img": float((img_h - img_c).abs().max()), "max_rel_img": float(((img_h - img_c).abs() / (1e-5 / 1e-3 + img_c.abs())).max()),
+                     "rel_loss": abs(loss_h - float(loss_c)) / max(abs(float(loss_c)), 1e-12), "dpsnr_db": psnr_h - float(psnr_c.mean())})
+    worst = {"max_abs_img": max(r["max_abs_img"] for r in rows), "rel_loss": max(r["rel_loss"] for r in rows), "dpsnr_db": max((r["dpsnr_db"] for r in rows), key=abs)}
+    ok = all(r["max_rel_img"] <= 1e-3 for r in rows) and abs(worst["dpsnr_db"]) <= 0.02
+    return {"max_abs_img": float(f"{worst['max_abs_img']:.3e}"), "rel_loss": float(f"{worst['rel_loss']:.3e}"), "dpsnr_db": round(worst["dpsnr_db"], 5),
+            "steps": len(rows), "per_step": [{k: float(f"{v:.3e}") for k, v in r.items()} for r in rows],
+            "gate": "every pixel |hip - oracle| <= 1e-5 + 1e-3 |oracle| and |dPSNR| <= 0.02 dB", "within_gate": bool(ok),
+            "what": f"{len(rows)} further train steps after the timed region, HIP path vs oracle/cpu_ref.py (CPU fp32) from the SAME parameters and Adan state, "
+                    f"same frames and learning rates, {args.loss}"}
+
+
 @torch.no_grad()
 def eval_psnr(model, frames, norm, takes_image, n_eval=8):
     """pred_seen_psnr of evaluate() (train_nerv_all.py:527-550 of the reference) on the first frames of this rank's shard, fp32 model,
@@ -424,9 +466,14 @@ def main():
         out["step_roofline"] = {"flops_per_frame": fl, "bytes_per_frame": by, "t_roof_ms": round(t_roof * 1e3, 4), "bound": "mfma" if fl / (PEAK_FP32_MFMA_TFLOPS * 1e12) >= by / (PEAK_HBM_GBS * 1e9) else "hbm",
                                 "achieved_TFLOPs": round(fl / t_step / 1e12, 2), "achieved_GBs": round(by / t_step / 1e9, 1), "frac_of_t_roof": round(t_roof / t_step, 4),
                                 "note": "algorithmic conv+dense work of one trained frame (BASELINE.md section 3) against the whole measured step, loss / optimizer / launches included"}
+        if world == 1 and not a.no_cpu_baseline and a.config != "c5":
+            def set_lr(sg, ig):
+                adjust_lr(opt, (sg / n_iter) / args.epochs, ig, args)
+            out["parity"] = parity_leg(args, model, opt, (lambda ig: step.step_frame(ig)) if by_index else (lambda ig: step(frames[ig:ig + 1], norm[ig:ig + 1])),
+                                       frames, norm, takes_image, max(a.warmup, 5) + a.steps, n_iter, set_lr, K=3 if r["h"] <= 720 else 2)
         ev, nev = eval_psnr(model, frames, norm, takes_image)
         out["eval_psnr_db"] = round(ev, 3)
-        out["config"]["eval"] = f"pred_seen_psnr over the first {nev} frames of the shard after {max(a.warmup, 5) + a.steps} train steps from random init (fp32 model)"
+        out["config"]["eval"] = f"pred_seen_psnr over the first {nev} frames of the shard after {max(a.warmup, 5) + a.steps + (out['parity']['steps'] if 'parity' in out else 0)} train steps from random init (fp32 model)"
         if world == 1 and not a.no_cpu_baseline:
             fcpu = torch.stack([vid.frame(i) for i in keep[:4]])
             ncpu = torch.tensor([(i + 1) / r["n"] for i in keep[:4]], dtype=torch.float64)
