@@ -457,7 +457,9 @@ def main():
                                       f"{'flat-bucket RCCL all-reduce + ' if world > 1 else ''}fused Adan; frames resident in HBM",
                           "baseline_config": {"c1": "configs[1]", "c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]"}[a.config], "global_batch": per_gpu_batch * world,
                           "per_gpu_batch": per_gpu_batch, "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
-                          "last_loss": round(loss, 4), "last_train_psnr_db": round(psnr, 3)}}
+                          "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else 0),
+                          "collective_in_graph": bool(getattr(step, "collective_in_graph", False)),
+                          "last_loss": round(loss, 6), "last_train_psnr_db": round(psnr, 4)}}
         c_last = last_stage_channels(model)
         out["roofline"] = step_kernel_roofline(dev, c_last, r["h"], r["w"], reps=20 if r["h"] <= 720 else 8)
         fl, by = STEP_WORK[a.config]

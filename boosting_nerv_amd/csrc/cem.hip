@@ -49,10 +49,10 @@ __global__ __launch_bounds__(CEM_THREADS) void cem_fwd_a_kernel(const bnerv_cem_
     const bnerv_cem_item it = ck.it[blockIdx.y];
     const int i0 = blockIdx.x * CEM_CHUNK, i1 = min(it.n, i0 + CEM_CHUNK);
     if (i0 >= it.n) return;
-    const float inv_s = 1.0f / it.scale[0];
+    const float s_ = it.scale[0];                             // true division below: code = w / s must round exactly as torch's (round() sits on it)
     double s1 = 0.0, s2 = 0.0;
     for (int i = i0 + threadIdx.x; i < i1; i += CEM_THREADS) {
-        const float c = it.w[i] * inv_s;
+        const float c = it.w[i] / s_;
         s1 += (double)c;
         s2 += (double)c * (double)c;
     }
@@ -80,11 +80,11 @@ __global__ __launch_bounds__(CEM_THREADS) void cem_fwd_b_kernel(const bnerv_cem_
     double* part = ws + (size_t)blockIdx.y * max_chunks * 3;
     float mu, sigma;
     cem_moments(part, (n + CEM_CHUNK - 1) / CEM_CHUNK, n, red, mu, sigma);
-    const float s = it.scale[0], inv_s = 1.0f / s;
+    const float s = it.scale[0];
     const float sg = fminf(fmaxf(sigma, 1e-5f), 1e10f), inv_sg = 1.0f / sg;
     double bits = 0.0;
     for (int i = i0 + threadIdx.x; i < i1; i += CEM_THREADS) {
-        const float c = it.w[i] * inv_s;
+        const float c = it.w[i] / s;
         const float q = rintf(c);                          // torch.round: half to even
         if (it.dequant) it.dequant[i] = q * s;
         const float x = ck.training ? c + it.noise[i] : q;
@@ -120,14 +120,14 @@ __global__ __launch_bounds__(CEM_THREADS) void cem_bwd_a_kernel(const bnerv_cem_
     const bnerv_cem_item_bwd it = ck.it[blockIdx.y];
     const int n = it.n, item = ck.first + blockIdx.y, i0 = blockIdx.x * CEM_CHUNK, i1 = min(n, i0 + CEM_CHUNK);
     if (i0 >= n) return;
-    const float inv_s = 1.0f / it.scale[0];
+    const float s_ = it.scale[0];
     const float mu = stats[(size_t)item * 4 + 1], sigma = stats[(size_t)item * 4 + 2];
     const float sg = fminf(fmaxf(sigma, 1e-5f), 1e10f), inv_sg = 1.0f / sg;
     const float g = d_bits ? d_bits[item] : 0.0f;
     double gmu = 0.0, gsg = 0.0;
     if (g != 0.0f) {                                        // block-uniform
         for (int i = i0 + threadIdx.x; i < i1; i += CEM_THREADS) {
-            const float c = it.w[i] * inv_s;
+            const float c = it.w[i] / s_;
             const float x = ck.training ? c + it.noise[i] : rintf(c);
             const float up = (x + 0.5f - mu) * inv_sg, um = (x - 0.5f - mu) * inv_sg;
             const float p = ncdf(up) - ncdf(um);
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(CEM_THREADS) void cem_bwd_b_kernel(const bnerv_cem_
     double* part = ws + (size_t)blockIdx.y * max_chunks * 3;
     const int nchunks = (n + CEM_CHUNK - 1) / CEM_CHUNK;
     const double gmu = chunk_total(part, nchunks, 0, red), gsg = chunk_total(part, nchunks, 1, red);
-    const float s = it.scale[0], inv_s = 1.0f / s;
+    const float s = it.scale[0];
     const float mu = stats[(size_t)item * 4 + 1], sigma = stats[(size_t)item * 4 + 2];
     const bool sigma_free = sigma >= 1e-5f && sigma <= 1e10f;              // clamp passes the gradient only inside its range
     const float sg = fminf(fmaxf(sigma, 1e-5f), 1e10f), inv_sg = 1.0f / sg;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(CEM_THREADS) void cem_bwd_b_kernel(const bnerv_cem_
     const float c_sg = (sigma_free && n > 1 && sigma > 0.f) ? (float)(gsg / ((double)(n - 1) * (double)sigma)) : 0.0f;
     double ds = 0.0;
     for (int i = i0 + threadIdx.x; i < i1; i += CEM_THREADS) {
-        const float w = it.w[i], c = w * inv_s, q = rintf(c);
+        const float w = it.w[i], c = w / s, q = rintf(c);
         float dc = 0.0f;
         if (g != 0.0f) {
             const float x = ck.training ? c + it.noise[i] : q;
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(CEM_THREADS) void cem_bwd_b_kernel(const bnerv_cem_
             dc = g * (dbx + c_mu + c_sg * (c - mu));
         }
         const float dd = it.d_dequant ? it.d_dequant[i] : 0.0f;
-        if (it.dw) it.dw[i] = dc * inv_s + dd;                             // d code / d w = 1/s;  d dequant / d w = 1 (STE)
-        ds += (double)(dc * (-c * inv_s)) + (double)(dd * (q - c));        // d code / d s = -c/s; d dequant / d s = round(c) - c
+        if (it.dw) it.dw[i] = dc / s + dd;                             // d code / d w = 1/s;  d dequant / d w = 1 (STE)
+        ds += (double)(dc * (-c / s)) + (double)(dd * (q - c));        // d code / d s = -c/s; d dequant / d s = round(c) - c
     }
     ds = block_sum_d(ds, red);
     if (threadIdx.x == 0) part[(size_t)blockIdx.x * 3 + 2] = ds;

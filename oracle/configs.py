@@ -45,5 +45,12 @@ def tiny_hnerv_quant():  # the same model built for the CEM compression path (sc
     return a
 
 
+def c5():      # C3's model built for the CEM compression path (scripts/compression/hnerv_boost.sh:7-16 quantiser flags), BASELINE configs[4]
+    a = c3()
+    a.__dict__.update(quant=True, quant_model_bit=8, quant_bias_bit=8, quant_embed_bit=8, per_channel_w=False, per_channel_b=False,
+                      per_channel_e=False, quantizer_w="scale", quantizer_b="scale", quantizer_e="scalebeta", embed_entropy=True)
+    return a
+
+
 def tiny_enerv():
     return _base(model="ENeRV_Boost", dec_strds=[5, 2, 2], dec_blks=[1, 1, 2], fc_dim=8, lower_width=6, block_dim=64)

@@ -432,12 +432,55 @@ def gen_cem_model(R):
     np.savez_compressed(os.path.join(OUT, "cem_model.npz"), **out)
 
 
+def gen_full_c5(R):
+    """BASELINE configs[4] at full size: the hooks of ONE compression train step (train_nerv_compression.py:354-367) on the C3 model
+    built with --quant at 1080x1920 -- init_data, cal_params(entropy_model) in train mode (uniform rate noise from the seeded CPU
+    generator, in module order), forward(entropy_model=...), get_bitrate_sum -- with loss = L1 + 1e-6 * bits.  Stored: the rate terms,
+    EVERY module's (bits, mean, std) for weight and bias, the quantiser scales after init_data, image summary, every gradient norm.
+    The seeded weights equal full_c3.npz's (same constructor order; the quantisers draw no random numbers): recorded as a flag."""
+    args = configs.c5()
+    torch.manual_seed(1)
+    m = R.model_hnerv.HNeRV_Boost(args)
+    out = {}
+    c3 = np.load(os.path.join(OUT, "full_c3.npz"))
+    sd = m.state_dict()
+    out["enc_equals_full_c3"] = np.int64(all(np.array_equal(npf(sd[k[len("enc_sd/"):]]), c3[k]) for k in c3.files if k.startswith("enc_sd/")))
+    out["dec_sha256"] = np.array(sd_hash({k: v for k, v in sd.items() if not k.startswith("encoder.") and "quantizer" not in k}))
+    m.init_data()
+    em = R.lib_entropy_model.DiffEntropyModel(distribution="gaussian")
+    frame = torch.rand(1, 3, 1080, 1920, generator=torch.Generator().manual_seed(5))
+    norm_idx = torch.tensor([37 / 600], dtype=torch.float64)
+    m.train()
+    torch.manual_seed(9)
+    m.cal_params(em)
+    img, _, _ = m(frame, entropy_model=em, norm_idx=norm_idx)
+    bits_w = m.get_bitrate_sum(name="bitrate")
+    bits_e = m.bitrate_e_dict["bitrate"]
+    loss = (img - frame).abs().mean() + 1e-6 * (bits_w + bits_e)
+    loss.backward()
+    out.update({"frame_seed": np.int64(5), "norm_idx": npf(norm_idx), "bits_w": npf(bits_w), "bits_e": npf(bits_e), "loss": npf(loss)})
+    for k, v in m.state_dict().items():
+        if "quantizer" in k:
+            out[f"q/{k}"] = npf(v)
+    for name, mod in m.named_modules():
+        if hasattr(mod, "bitrate_w_dict") and "bitrate" in getattr(mod, "bitrate_w_dict", {}):
+            d = mod.bitrate_w_dict
+            out[f"bw/{name}"] = np.array([d["bitrate"].item(), d["mean"].item(), d["std"].item(), mod.weight.numel()], dtype=np.float64)
+            if "bitrate" in mod.bitrate_b_dict:
+                d = mod.bitrate_b_dict
+                out[f"bb/{name}"] = np.array([d["bitrate"].item(), d["mean"].item(), d["std"].item(), mod.bias.numel()], dtype=np.float64)
+    summary(img, "img", out, 2048)
+    for pn, p in m.named_parameters():
+        out[f"gnorm/{pn}"] = np.float64(p.grad.double().norm().item()) if p.grad is not None else np.float64(-1)
+    np.savez_compressed(os.path.join(OUT, "full_c5.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = ref_harness.load_reference()
-    which = sys.argv[1:] or ["pe", "blocks", "cnx", "tiny", "full", "full1080", "loss", "optim", "host", "cem", "cem_model"]
-    fns = dict(pe=gen_pe, blocks=gen_blocks, cnx=gen_convnext_blocks, tiny=gen_tiny_models, full=gen_full_models, full1080=gen_full_1080, loss=gen_loss, optim=gen_optim, host=gen_host, cem=gen_cem, cem_model=gen_cem_model)
+    which = sys.argv[1:] or ["pe", "blocks", "cnx", "tiny", "full", "full1080", "loss", "optim", "host", "cem", "cem_model", "full_c5"]
+    fns = dict(pe=gen_pe, blocks=gen_blocks, cnx=gen_convnext_blocks, tiny=gen_tiny_models, full=gen_full_models, full1080=gen_full_1080, loss=gen_loss, optim=gen_optim, host=gen_host, cem=gen_cem, cem_model=gen_cem_model, full_c5=gen_full_c5)
     for w in which:
         print("generating", w, flush=True)
         fns[w](R)

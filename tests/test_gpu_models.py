@@ -217,6 +217,126 @@ def test_big_models_full_size_against_reference_golden(name, cfg):
     assert all(torch.isfinite(p).all().item() for p in model.parameters())
 
 
+def test_c5_full_size_against_reference_golden():
+    """BASELINE configs[4] at its own size: ONE compression train step's hooks (train_nerv_compression.py:354-367) on the C3 model built
+    with --quant at 1080x1920 against the reference's CPU run (oracle/make_goldens.py gen_full_c5): quantiser scales after init_data,
+    the (bits, mean, std) of EVERY weight and bias tensor -- 1.1 M-element up-conv matrices and 3-element biases alike -- from the
+    fused CEM kernels, both rate totals, loss, image, every gradient norm; per-tensor statistics also against oracle/cem_ref.py on the
+    same noise; dequantised tensors bit-equal to round(w / scale) * scale.  Then engine.CompressionStep: three steps eager == three
+    steps with the captured graph, bit for bit (a deterministic noise source replaces the generator so the two runs share the numbers)."""
+    import hashlib
+    from boosting_nerv_amd.engine import CompressionStep
+    from boosting_nerv_amd.lib.entropy_model import DiffEntropyModel
+    from boosting_nerv_amd.lib.quant_ops import CustomConv2d, CustomLinear
+    from boosting_nerv_amd.model_hnerv import HNeRV_Boost
+    from boosting_nerv_amd.optimizer import Adan
+    from oracle import cem_ref
+    npz, c3 = load_golden("full_c5.npz"), load_golden("full_c3.npz")
+    assert int(npz["enc_equals_full_c3"]) == 1
+    args = configs.c5()
+
+    def build():
+        torch.manual_seed(1)
+        m = HNeRV_Boost(args)
+        sd = m.state_dict()
+        h = hashlib.sha256()
+        for k, v in sd.items():
+            if not k.startswith("encoder.") and "quantizer" not in k:
+                h.update(k.encode())
+                h.update(v.numpy().tobytes())
+        assert h.hexdigest() == str(npz["dec_sha256"])
+        m.load_state_dict({**sd, **group(c3, "enc_sd/")})
+        m = m.to(DEV)
+        m.init_data()
+        return m
+    model = build()
+    for k, v in model.state_dict().items():
+        if ("weight_quantizer" in k or "bias_quantizer" in k) and f"q/{k}" in npz.files:
+            torch.testing.assert_close(v.cpu(), torch.from_numpy(npz[f"q/{k}"]), rtol=1e-6, atol=0, msg=k)
+    em = DiffEntropyModel("gaussian")
+    noises = {}
+
+    def cpu_noise(code):                         # the reference's draw order: torch.empty_like(code).uniform_ from the seeded CPU generator
+        n = torch.empty(code.shape).uniform_(-0.5, 0.5)
+        noises[code.data_ptr()] = n
+        return n.to(code.device)
+    em.noise_source = cpu_noise
+    frame = torch.rand(1, 3, 1080, 1920, generator=torch.Generator().manual_seed(int(npz["frame_seed"]))).to(DEV)
+    norm_idx = torch.from_numpy(npz["norm_idx"]).to(DEV)
+    model.train()
+    torch.manual_seed(9)
+    model.cal_params(em)
+    img, _, _ = model(frame, entropy_model=em, norm_idx=norm_idx)
+    bits_w, bits_e = model.get_bitrate_sum(name="bitrate"), model.bitrate_e_dict["bitrate"]
+    loss = (img - frame).abs().mean() + 1e-6 * (bits_w + bits_e)
+    loss.backward()
+    assert abs(bits_w.item() - float(npz["bits_w"])) <= 1e-4 * float(npz["bits_w"]), (bits_w.item(), float(npz["bits_w"]))
+    assert abs(bits_e.item() - float(npz["bits_e"])) <= 1e-3 * float(npz["bits_e"])
+    assert abs(loss.item() - float(npz["loss"])) <= 1e-4 * float(npz["loss"])
+    check_summary(img, npz, "img", rtol=1e-3, atol=1e-4)
+    n_checked = 0
+    for name, mod in model.named_modules():
+        if type(mod) not in (CustomConv2d, CustomLinear) or f"bw/{name}" not in npz.files:
+            continue
+        for tag, d, t, q in (("bw", mod.bitrate_w_dict, mod.weight, mod.weight_quantizer), ("bb", mod.bitrate_b_dict, mod.bias, getattr(mod, "bias_quantizer", None))):
+            if f"{tag}/{name}" not in npz.files:
+                continue
+            gb, gm, gs, gn = npz[f"{tag}/{name}"]
+            assert int(gn) == t.numel()
+            assert abs(d["bitrate"].item() - gb) <= 2e-4 * gb + 1e-2, (tag, name, d["bitrate"].item(), gb)
+            assert abs(d["mean"].item() - gm) <= 1e-4 * abs(gm) + 1e-4 and abs(d["std"].item() - gs) <= 1e-4 * gs + 1e-5, (tag, name)
+            n_checked += 1
+        # dequantised weight = ste(w / scale) * scale, bit for bit (lib/transform_ops.py:239-251)
+        sc = mod.weight_quantizer.scale.detach()
+        want = torch.round(mod.weight.detach() / sc) * sc
+        assert torch.equal(mod.dequant_w.detach(), want), name
+    assert n_checked >= 150, n_checked
+    # the restatement on the same code + noise for a sample of tensors incl. the largest ones (oracle/cem_ref.py cal_bitrate)
+    mods = [(n, m) for n, m in model.named_modules() if type(m) in (CustomConv2d, CustomLinear)]
+    mods.sort(key=lambda nm: -nm[1].weight.numel())
+    for name, mod in mods[:6] + mods[len(mods) // 2:len(mods) // 2 + 10] + mods[-6:]:
+        w, sc = mod.weight.detach().cpu(), mod.weight_quantizer.scale.detach().cpu()
+        code, quant, _ = cem_ref.scale_t(w, sc)
+        stats = cem_ref.cal_bitrate(code, quant, False)
+        d_eval = em.cal_bitrate(mod.weight.detach() / mod.weight_quantizer.scale.detach(), torch.round(mod.weight.detach() / mod.weight_quantizer.scale.detach()), False)
+        assert abs(d_eval["bitrate"].item() - stats["bitrate"].item()) <= 2e-4 * stats["bitrate"].item() + 1e-2, name
+    for k, p in model.named_parameters():
+        g = float(npz[f"gnorm/{k}"])
+        if g < 0:
+            assert p.grad is None, k
+        else:
+            assert abs(p.grad.double().norm().item() - g) <= 5e-3 * g + 1e-6, (k, p.grad.double().norm().item(), g)
+    del model, img, loss
+    torch.cuda.empty_cache()
+
+    # ---- the captured step replays what the eager step computes
+    a2 = configs.c5()
+    a2.__dict__.update(loss="Fusion10_freq", embed_entropy=True, lambda_rate=0.5, final_size=1080 * 1920, full_data_length=600, target_bpp=1e-9, model="HNeRV_Boost")
+    frames = torch.rand(2, 3, 1080, 1920, generator=torch.Generator().manual_seed(3)).to(DEV)
+    norms = torch.tensor([1 / 600, 2 / 600], dtype=torch.float64, device=DEV)
+
+    def run(use_graph):
+        m = build()
+        m.train()
+        e = DiffEntropyModel("gaussian")
+        e.noise_source = lambda code: torch.frac(code.detach() * 12.9898 + 0.37).abs() - 0.5        # deterministic, capture-safe "noise"
+        opt = Adan(m.parameters(), lr=5e-4)
+        step = CompressionStep(m, opt, e, a2, (1, 3, 1080, 1920), torch.device(DEV), use_graph=use_graph, warmup_eager=1)
+        out = []
+        for s in range(3):
+            l, ps = step(frames[s % 2:s % 2 + 1], norms[s % 2:s % 2 + 1])
+            out.append((l.item(), step.bpp_out.item(), ps.item()))
+        assert all(np.isfinite(v) for t in out for v in t), out
+        if use_graph:
+            assert step.graph_a is not None
+        return out, {k: v.detach().clone() for k, v in m.state_dict().items()}
+    o_e, sd_e = run(False)
+    o_g, sd_g = run(True)
+    assert o_e == o_g, (o_e, o_g)
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
+
+
 def _oracle_trajectory(sd0, frames, norm_idxs, order, lrs, loss_type):
     sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
     adan = cpu_ref.AdanState(list(sd.values()), lr=lrs[0])
@@ -651,3 +771,32 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
     assert out["scaling"] == "weak" and out["value"] > 0 and out["cpu_baseline"] is None and out["roofline"]["frac"] > 0
     assert "eval_psnr_db" in out and "step_roofline" in out
+
+
+def test_bench_two_ranks_over_rccl(tmp_path):
+    """bench.py --gpus 2 exactly as the driver launches it, over RCCL (backend nccl), one rank per GPU -- runs only where two devices
+    are visible (the build box has one: skipped there).  The flat-bucket all-reduce is captured INSIDE the step graph
+    (`collective_in_graph`), and the trajectory equals the two-graph form (BNERV_DP_INGRAPH=0: graph A -> eager all-reduce -> graph B)
+    to the last printed digit of loss and train PSNR."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL over xGMI)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(ingraph, port):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", BNERV_DP_INGRAPH="1" if ingraph else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("BNERV_BENCH_SHARE_GPU", None)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "5", "--no_cpu_baseline"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+    a, b = run(True, 29681), run(False, 29683)
+    assert a["n_gpus"] == 2 and a["config"]["rccl_ranks"] == 2 and a["config"]["collective_in_graph"] is True
+    assert b["config"]["rccl_ranks"] == 2 and b["config"]["collective_in_graph"] is False
+    assert a["config"]["last_loss"] == b["config"]["last_loss"] and a["config"]["last_train_psnr_db"] == b["config"]["last_train_psnr_db"]
