@@ -1711,7 +1711,7 @@ extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
     }
     // split-bf16 kernels (convbf.hip) first: the wide layers (with the same split-K plan: its slabs are reduced below), opt-in 12-channel ones
     int rc = bnerv_convbf_try(st, d, ka.vec, ka.ksplit, ka.chunks_per_split);
-    if (rc == -1) {
+    if (rc == 1) {                                         // +1: not the split kernels' layer (negative values are real errors)
         ka.magic_tiles = ka.magic_tiles_x = 0;
         rc = bnerv_conv4_try(st, ka);                      // <= 12-channel 3x3 layers on the 4x4x1 MFMA family
         if (rc == 1) rc = d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);

@@ -12,6 +12,8 @@
 #include <string.h>
 #include <type_traits>
 
+constexpr int BF_NOT_HANDLED = 1;     // "not this family's layer" (bnerv_convbf_try and the launchers below); errors stay negative
+
 namespace {
 
 constexpr int TH = 8, TW = 32;     // spatial tile (as conv.hip)
@@ -1119,7 +1121,7 @@ int launch_mode(hipStream_t st, KArgs& ka) {
         BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DGELU_SAVED)
     }
 #undef BNERV_CASE
-    return -1;
+    return BF_NOT_HANDLED;
 }
 
 // ---- wide kernel: mode switch, launch, dispatch
@@ -1145,7 +1147,15 @@ int launch_bfw(hipStream_t st, KArgs& ka) {
     const void* scratch = wplan_lookup(d.ctx, d, nck, NTB, NS);      // a live plan prepared this call's fragments at the start of the step
     if (!scratch) {
         void* own = bnerv_ctx_scratch(d.ctx, slots * 16, st);
-        if (!own) return -1;                               // no context, or it would have to grow inside a graph capture: f32 kernels
+        if (!own) {                                         // no context, or it would have to grow inside a graph capture: f32 kernels
+            static bool warned = false;                     // (different arithmetic and speed than the eager steps had: say so, once)
+            if (!warned) {
+                warned = true;
+                fprintf(stderr, "[bnerv] wide split conv: no scratch for the weight fragments (%zu bytes; context %s) -- this call runs on the f32 MFMA kernels; "
+                                "reserve the context's scratch before capturing (bnerv_ctx_reserve)\n", slots * 16, d.ctx ? "cannot grow here" : "missing");
+            }
+            return BF_NOT_HANDLED;
+        }
         hipLaunchKernelGGL(bf_wprep_kernel<NS>, dim3(cdiv(nfrag, 256)), dim3(256), 0, st, d.w, reinterpret_cast<u32x4*>(own),
                            d.wCo, d.wCi, d.transposed, d.Cin, d.Cout, nck, NTB, nfrag);
         BNERV_LAUNCH_CHECK("bf_wprep");
@@ -1203,12 +1213,12 @@ int launch_wide_mode(hipStream_t st, KArgs& ka) {
     if (ka.d.out_s == 3 || ka.d.out_s == 5) {              // up-conv forward through PixelShuffle(3 / 5): scatter stores
         if (in == BNERV_IN_PLAIN && ep == BNERV_EP_BIAS_SIN) return launch_bfw_sp<BNERV_IN_PLAIN, BNERV_EP_BIAS_SIN, 3>(st, ka);
         if (in == BNERV_IN_PLAIN && ep == BNERV_EP_BIAS) return launch_bfw_sp<BNERV_IN_PLAIN, BNERV_EP_BIAS, 3>(st, ka);
-        return -1;
+        return BF_NOT_HANDLED;
     }
     if (ka.d.out_s == 2) {                                 // up-conv forward: conv -> bias -> PixelShuffle(2) [-> sin, cos]
         if (in == BNERV_IN_PLAIN && ep == BNERV_EP_BIAS_SIN) return launch_bfw_sp<BNERV_IN_PLAIN, BNERV_EP_BIAS_SIN, 2>(st, ka);
         if (in == BNERV_IN_PLAIN && ep == BNERV_EP_BIAS) return launch_bfw_sp<BNERV_IN_PLAIN, BNERV_EP_BIAS, 2>(st, ka);
-        return -1;
+        return BF_NOT_HANDLED;
     }
     if (in == BNERV_IN_UNSHUFFLE) return ep == BNERV_EP_PLAIN ? launch_bfw_sp<BNERV_IN_UNSHUFFLE, BNERV_EP_PLAIN>(st, ka) : -1;
 #define BNERV_CASE(I, E) if (in == I && ep == E) return launch_bfw_sp<I, E>(st, ka);
@@ -1223,7 +1233,7 @@ int launch_wide_mode(hipStream_t st, KArgs& ka) {
     BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_RES)
     BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DGELU_SAVED)
 #undef BNERV_CASE
-    return -1;
+    return BF_NOT_HANDLED;
 }
 
 }  // namespace
@@ -1302,35 +1312,36 @@ extern "C" int bnerv_ctx_wplan_entries(const bnerv_ctx* ctx) { return (ctx && ct
 extern "C" int bnerv_debug_trace_read_bf(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_bf), sizeof(g_trace_bf)); }
 #endif
 
-// Called by bnerv_conv_igemm (conv.hip) after argument validation.  Returns -1 when the shape / mode is not this kernel's
-// (the caller then takes its f32-MFMA kernels), otherwise the launch status.
+// Called by bnerv_conv_igemm (conv.hip) after argument validation.  Returns BF_NOT_HANDLED (+1: not a BNERV_E_* value, so a real
+// argument / launch error raised on this path is never mistaken for it) when the shape / mode is not this kernel's -- the caller
+// then takes its f32-MFMA kernels -- otherwise the launch status.
 int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec, int ksplit, int chunks_per_split) {
-    if (!vec || d.in_mode == BNERV_IN_TANHGRAD) return -1;
-    if (ksplit > 1 && (d.ep_mode != BNERV_EP_PLAIN || !d.partial || d.out_s != 1)) return -1;
+    if (!vec || d.in_mode == BNERV_IN_TANHGRAD) return BF_NOT_HANDLED;
+    if (ksplit > 1 && (d.ep_mode != BNERV_EP_PLAIN || !d.partial || d.out_s != 1)) return BF_NOT_HANDLED;
     const bool shuffled = d.out_s != 1 || d.in_mode == BNERV_IN_UNSHUFFLE;                // up-conv forward / its data gradient
-    if (d.out_s != 1 && !((d.out_s == 2 || d.out_s == 3 || d.out_s == 5) && d.Cout % (d.out_s * d.out_s) == 0)) return -1;
-    if ((size_t)d.B * d.Cout * d.H * d.W * 4 >= LEAN_MAX_BYTES) return -1;      // (the shuffled output is addressed as one buffer)
-    if (d.in_mode == BNERV_IN_UNSHUFFLE && (!(d.in_s == 2 || d.in_s == 3 || d.in_s == 5) || d.Cin % (d.in_s * d.in_s) != 0 || d.out_s != 1)) return -1;
+    if (d.out_s != 1 && !((d.out_s == 2 || d.out_s == 3 || d.out_s == 5) && d.Cout % (d.out_s * d.out_s) == 0)) return BF_NOT_HANDLED;
+    if ((size_t)d.B * d.Cout * d.H * d.W * 4 >= LEAN_MAX_BYTES) return BF_NOT_HANDLED;      // (the shuffled output is addressed as one buffer)
+    if (d.in_mode == BNERV_IN_UNSHUFFLE && (!(d.in_s == 2 || d.in_s == 3 || d.in_s == 5) || d.Cin % (d.in_s * d.in_s) != 0 || d.out_s != 1)) return BF_NOT_HANDLED;
     const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
-    if ((size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 >= LEAN_MAX_BYTES) return -1;
+    if ((size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 >= LEAN_MAX_BYTES) return BF_NOT_HANDLED;
     KArgs ka;
     ka.d = d;
     ka.tiles_x = cdiv(d.W, TW);
     ka.tiles_y = cdiv(d.H, TH);
     ka.ksplit = ksplit > 1 ? ksplit : 1;
     ka.cps = ksplit > 1 ? chunks_per_split : cdiv(d.Cin, 16);
-    if ((size_t)ka.ksplit * d.B * d.Cout * d.H * d.W * 4 >= LEAN_MAX_BYTES) return -1;
+    if ((size_t)ka.ksplit * d.B * d.Cout * d.H * d.W * 4 >= LEAN_MAX_BYTES) return BF_NOT_HANDLED;
     const bool narrow = d.Cout <= 16 && d.Cin <= 16 && !shuffled;
     if (narrow) {                                          // one cout tile, one K chunk: opt-in (see split_mode)
-        if (split_mode() < 0 || ksplit > 1 || d.Cin <= 8 || d.wCo > 16 || d.wCi > 16) return -1;
+        if (split_mode() < 0 || ksplit > 1 || d.Cin <= 8 || d.wCo > 16 || d.wCi > 16) return BF_NOT_HANDLED;
         return d.k == 1 ? launch_mode<1>(st, ka) : launch_mode<3>(st, ka);
     }
     // several cout tiles and / or K chunks: the wide kernel, where the image is big enough to fill the chip with its work items
-    if (wide_mode() < 0 || d.k != 3 || !d.ctx) return -1;
+    if (wide_mode() < 0 || d.k != 3 || !d.ctx) return BF_NOT_HANDLED;
     const bool affine = d.in_mode == BNERV_IN_AFFINE || d.in_mode == BNERV_IN_GELU_AFFINE;
-    if (affine && d.Cin > AFF_MAX) return -1;
+    if (affine && d.Cin > AFF_MAX) return BF_NOT_HANDLED;
     int min_tiles = 16;                                    // (measured on C1 / C3 / C4: 16 >= 32 >= 64 >= 256; below it the f32 kernels' split policies win)
     if (const char* e = getenv("BNERV_SPLIT_WIDE_MIN_TILES")) min_tiles = atoi(e);     // tests lower it to reach the kernel with small shapes
-    if (d.B * ka.tiles_x * ka.tiles_y < min_tiles) return -1;
+    if (d.B * ka.tiles_x * ka.tiles_y < min_tiles) return BF_NOT_HANDLED;
     return launch_wide_mode(st, ka);
 }

@@ -96,6 +96,11 @@ class TrainStep:
         self._wplan_entries = 0
         if type(self) is not TrainStep or os.environ.get("BNERV_WPLAN", "1") == "0":
             return
+        # the recording pass is one extra forward + backward: with BatchNorm it would move the running statistics once more than the
+        # eager / reference trajectory does, with an active Dropout it would advance the generator -- no plan for such models
+        for mod in self.model.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) or (isinstance(mod, torch.nn.modules.dropout._DropoutNd) and mod.p > 0):
+                return
         lib = L.load()
         with torch.cuda.stream(self._cap_stream), L.use_ctx(self._cap_ctx) as c:
             L.check(lib.bnerv_ctx_wplan_record(c.handle), "bnerv_ctx_wplan_record")

@@ -132,7 +132,15 @@ def load_initial_state(model, args, outf, strict_resume=True, rename=None):
         latest = os.path.join(outf, 'model_latest.pth')
         if os.path.isfile(latest):
             ckpt = torch.load(latest, map_location='cpu')
-            model.load_state_dict(ckpt['state_dict'], strict=strict_resume)
+            # a checkpoint the reference saved under DistributedDataParallel prefixes every key with 'module.' (train_nerv_all.py:253,
+            # :396); this package never wraps the model, so the prefix is stripped here exactly as for --weight
+            sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in ckpt['state_dict'].items()}
+            if rename is not None:
+                sd = {rename(k): v for k, v in sd.items()}
+            res = model.load_state_dict(sd, strict=strict_resume)
+            if not strict_resume and (res.missing_keys or res.unexpected_keys):
+                print(f"=> resume: {len(res.missing_keys)} keys missing from the checkpoint (first: {res.missing_keys[:3]}), "
+                      f"{len(res.unexpected_keys)} unexpected (first: {res.unexpected_keys[:3]})")
             print(f"=> Auto resume loaded checkpoint '{latest}' (epoch {ckpt['epoch']})")
         else:
             print(f"=> No resume checkpoint found at '{latest}'")

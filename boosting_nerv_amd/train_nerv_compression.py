@@ -160,8 +160,16 @@ def train(local_rank, args):
         # (no init_data() here: the quantiser scales come from the checkpoint -- re-initialising them from the weight range would
         #  report the rate / quality of a different model; the reference initialises them on the training path only)
         values, hw = evaluate(model, full_loader, local_rank, args, args.dump_vis, coding=True, entropy_model=entropy_model)
+        top = rt.BestTracker(args.metric_names).update(values)
+        text = f'PSNR for output {hw} for quant {args.quant_str}: ' + ''.join(
+            f'best_{n}: {rt.fmt(v, 2 if "psnr" in n else 4)} | ' for n, v in zip(args.metric_names, top))
         if is_main:
-            print(f'PSNR for output {hw} for quant {args.quant_str}: ' + ' | '.join(f'{n}: {rt.fmt(v, 4)}' for n, v in zip(args.metric_names, values)), flush=True)
+            print(text, flush=True)
+            # the files the reference's --eval_only writes under --outf (train_nerv_compression.py:311-325): eval.txt and eval.csv
+            with open(os.path.join(args.outf, 'eval.txt'), 'a') as f:
+                f.write(text + '\n\n')
+            args.train_time, args.cur_epoch = 0, args.epochs
+            rt.write_results_csv(args, top, values, [torch.tensor(0)], 'eval.csv')
         return
 
     model.init_data()                                                  # quantiser scales from the current weight ranges (:338)
