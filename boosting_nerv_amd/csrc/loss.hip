@@ -89,6 +89,7 @@ __global__ void grad_l1l2_kernel(const float* __restrict__ p, const float* __res
 constexpr int LV = BNERV_MSSSIM_LEVELS;
 constexpr int WS_ = 11, HW_ = 10;           // window size, window size - 1
 constexpr int STH = 16, STW = 32;           // ssim tile
+__device__ __forceinline__ int cdiv_d(int a, int b) { return (a + b - 1) / b; }
 
 struct Win { float g[WS_]; };
 
@@ -143,6 +144,48 @@ __global__ void avgpool2_kernel(const float* __restrict__ x0, const float* __res
     }
 }
 
+// All four coarser levels of BOTH images in one launch, for frames whose sides stay even down to level 3 (720x1280: 360, 180, 90 |
+// 640, 320, 160): a block owns a 32x32 patch of level 0 = 16x16 of level 1 = ... = 2x2 of level 4, the intermediate levels pass
+// through LDS.  Same arithmetic as avgpool2_kernel level by level (0.25 * (((a + b) + c) + d)), so the pyramid is bit-identical.
+struct PyrArgs { const float* src[2]; float* dst[2][LV]; int H[LV], W[LV]; int planes; };
+__global__ __launch_bounds__(256) void pyramid_kernel(const PyrArgs a) {
+    __shared__ float s1[16][17], s2[8][9], s3[4][5];
+    const int img = blockIdx.z & 1, pl = blockIdx.z >> 1;
+    const float* x = a.src[img] + (size_t)pl * a.H[0] * a.W[0];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    {
+        const int oy = blockIdx.y * 16 + ty, ox = blockIdx.x * 16 + tx;
+        float v = 0.f;
+        if (oy < a.H[1] && ox < a.W[1]) {
+            const float2 r0 = *reinterpret_cast<const float2*>(x + (size_t)(2 * oy) * a.W[0] + 2 * ox);
+            const float2 r1 = *reinterpret_cast<const float2*>(x + (size_t)(2 * oy + 1) * a.W[0] + 2 * ox);
+            v = 0.25f * (((r0.x + r0.y) + r1.x) + r1.y);
+            a.dst[img][1][((size_t)pl * a.H[1] + oy) * a.W[1] + ox] = v;
+        }
+        s1[ty][tx] = v;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int y = tid >> 3, xx = tid & 7, oy = blockIdx.y * 8 + y, ox = blockIdx.x * 8 + xx;
+        const float v = 0.25f * (((s1[2 * y][2 * xx] + s1[2 * y][2 * xx + 1]) + s1[2 * y + 1][2 * xx]) + s1[2 * y + 1][2 * xx + 1]);
+        if (oy < a.H[2] && ox < a.W[2]) a.dst[img][2][((size_t)pl * a.H[2] + oy) * a.W[2] + ox] = v;
+        s2[y][xx] = v;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int y = tid >> 2, xx = tid & 3, oy = blockIdx.y * 4 + y, ox = blockIdx.x * 4 + xx;
+        const float v = 0.25f * (((s2[2 * y][2 * xx] + s2[2 * y][2 * xx + 1]) + s2[2 * y + 1][2 * xx]) + s2[2 * y + 1][2 * xx + 1]);
+        if (oy < a.H[3] && ox < a.W[3]) a.dst[img][3][((size_t)pl * a.H[3] + oy) * a.W[3] + ox] = v;
+        s3[y][xx] = v;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        const int y = tid >> 1, xx = tid & 1, oy = blockIdx.y * 2 + y, ox = blockIdx.x * 2 + xx;
+        const float v = 0.25f * (((s3[2 * y][2 * xx] + s3[2 * y][2 * xx + 1]) + s3[2 * y + 1][2 * xx]) + s3[2 * y + 1][2 * xx + 1]);
+        if (oy < a.H[4] && ox < a.W[4]) a.dst[img][4][((size_t)pl * a.H[4] + oy) * a.W[4] + ox] = v;
+    }
+}
+
 struct SsimArgs {
     const float* X; const float* Y;
     float* partial;            // fwd: [BC][tiles]
@@ -160,14 +203,13 @@ struct SsimArgs {
 };
 
 // ---- forward: per-tile sum of cs (LAST=false) or ssim (LAST=true) over the valid region ----
-template <bool LAST>
-__global__ __launch_bounds__(256) void ssim_fwd_kernel(const SsimArgs a) {
+__device__ __forceinline__ void ssim_fwd_body(const SsimArgs& a, const bool LAST, const int bx, const int by, const int bc, const int nbc) {
     constexpr int WH = STH + HW_, WW = STW + HW_;        // 26 x 42 input window
     __shared__ float sX[WH][WW], sY[WH][WW];
     __shared__ float sV[5][STH][WW];
     __shared__ float red[4];
-    const int tid = threadIdx.x, bc = blockIdx.z;
-    const int oy0 = blockIdx.y * STH, ox0 = blockIdx.x * STW;
+    const int tid = threadIdx.x;
+    const int oy0 = by * STH, ox0 = bx * STW;
     const float* X = a.X + (size_t)bc * a.H * a.W;
     const float* Y = a.Y + (size_t)bc * a.H * a.W;
     for (int i = tid; i < WH * WW; i += 256) {
@@ -217,7 +259,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const SsimArgs a) {
                     dxx *= lum; dxy *= lum;
                 }
                 const size_t plane = (size_t)a.H * a.W, o = (size_t)bc * plane + (size_t)(oy0 + r) * a.W + (ox0 + c);
-                const size_t mstride = (size_t)gridDim.z * plane;
+                const size_t mstride = (size_t)nbc * plane;
                 a.G[o] = dm; a.G[mstride + o] = dxx; a.G[2 * mstride + o] = dxy;
             }
         }
@@ -225,7 +267,20 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const SsimArgs a) {
     acc = wave_sum(acc);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0) a.partial[(size_t)bc * (a.tiles_x * a.tiles_y) + blockIdx.y * a.tiles_x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (tid == 0) a.partial[(size_t)bc * (a.tiles_x * a.tiles_y) + by * a.tiles_x + bx] = red[0] + red[1] + red[2] + red[3];
+}
+template <bool LAST>
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(const SsimArgs a) { ssim_fwd_body(a, LAST, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z); }
+
+// every level's statistics in ONE launch (the levels only depend on the pyramid): block -> (level, tile) through the running tile counts
+struct SsimAllArgs { SsimArgs lv[LV]; int first[LV + 1]; };
+__global__ __launch_bounds__(256) void ssim_fwd_all_kernel(const SsimAllArgs a) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < LV; ++k) if ((int)blockIdx.x >= a.first[k]) l = k;
+    const int t = (int)blockIdx.x - a.first[l];
+    const int bx = t % a.lv[l].tiles_x, by = t / a.lv[l].tiles_x;
+    ssim_fwd_body(a.lv[l], l == LV - 1, bx, by, blockIdx.y, gridDim.y);      // (one body: its LDS arrays exist once)
 }
 
 // ---- ms_ssim per (b,c) and the chain coefficients; one block (5 waves) per (b,c) ----
@@ -269,16 +324,17 @@ __global__ __launch_bounds__(320) void ms_coef_kernel(const CoefArgs a) {
 // ---- backward from the stored statistic gradients: adjoint of the separable "valid" filter over the 3 maps, then
 //      dX = coef * (A0 + 2 x A1 + y A2) [+ 0.25 * d(coarser level)] [+ L1/L2 terms at level 0].  ~6x less arithmetic than
 //      recomputing the statistics on a 36x52 window per tile.
+struct CoarseChain { const float* own[LV]; int H[LV], W[LV]; int n; };     // level-0 form: the coarser levels' OWN terms (n of them), combined here
 template <bool LEVEL0>
-__global__ __launch_bounds__(256) void ssim_bwd_from_g_kernel(const SsimArgs a) {
+__device__ __forceinline__ void ssim_bwd_body(const SsimArgs& a, const CoarseChain* cc, const int bx, const int by, const int bc, const int nbc) {
     constexpr int GH = STH + HW_, GW = STW + HW_;        // 26 x 42 statistic-gradient region
     __shared__ float sG[3][GH][GW];
     __shared__ float sA[3][STH][GW];
-    const int tid = threadIdx.x, bc = blockIdx.z;
-    const int py0 = blockIdx.y * STH, px0 = blockIdx.x * STW;
+    const int tid = threadIdx.x;
+    const int py0 = by * STH, px0 = bx * STW;
     const int wy0 = py0 - HW_, wx0 = px0 - HW_;
     const int Hv = a.H - HW_, Wv = a.W - HW_;
-    const size_t plane = (size_t)a.H * a.W, mstride = (size_t)gridDim.z * plane;
+    const size_t plane = (size_t)a.H * a.W, mstride = (size_t)nbc * plane;
     const float* Gp = a.G + (size_t)bc * plane;
     for (int i = tid; i < GH * GW; i += 256) {
         const int r = i / GW, c = i - r * GW;
@@ -322,6 +378,16 @@ __global__ __launch_bounds__(256) void ssim_bwd_from_g_kernel(const SsimArgs a) 
         const float xv = X[(size_t)y * a.W + x], yv = Y[(size_t)y * a.W + x];
         float d = coef * (a0 + 2.f * xv * a1 + yv * a2);
         if (a.dcoarse) d += 0.25f * a.dcoarse[((size_t)bc * a.Hc + (y + a.ph) / 2) * a.Wc + (x + a.pw) / 2];
+        if (LEVEL0 && cc != nullptr && cc->n > 0) {
+            // even pyramid: the coarser levels stored only their OWN terms; d_k = own_k + 0.25 d_{k+1} is evaluated here, innermost first,
+            // exactly as the level-by-level launches did (0.25 * is exact), so the gradient keeps its bits
+            float dc = 0.f;
+            for (int k = cc->n; k >= 1; --k) {
+                const float o = cc->own[k][((size_t)bc * cc->H[k] + (y >> k)) * cc->W[k] + (x >> k)];
+                dc = (k == cc->n) ? o : o + 0.25f * dc;
+            }
+            d += 0.25f * dc;
+        }
         if (LEVEL0) {
             const float df = xv - yv;
             const float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
@@ -329,6 +395,18 @@ __global__ __launch_bounds__(256) void ssim_bwd_from_g_kernel(const SsimArgs a) 
         }
         a.dX[((size_t)bc * a.H + y) * a.W + x] = d;
     }
+}
+template <bool LEVEL0>
+__global__ __launch_bounds__(256) void ssim_bwd_from_g_kernel(const SsimArgs a) { ssim_bwd_body<LEVEL0>(a, nullptr, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z); }
+__global__ __launch_bounds__(256) void ssim_bwd_level0_chain_kernel(const SsimArgs a, const CoarseChain cc) { ssim_bwd_body<true>(a, &cc, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z); }
+// levels 1 .. LV-1 in one launch, each writing only its OWN term (no coarser contribution: the level-0 launch combines them)
+__global__ __launch_bounds__(256) void ssim_bwd_coarse_all_kernel(const SsimAllArgs a) {
+    int l = 1;
+#pragma unroll
+    for (int k = 2; k < LV; ++k) if ((int)blockIdx.x >= a.first[k]) l = k;
+    const int t = (int)blockIdx.x - a.first[l];
+    const int tx = cdiv_d(a.lv[l].W, STW);
+    ssim_bwd_body<false>(a.lv[l], nullptr, t % tx, t / tx, blockIdx.y, gridDim.y);
 }
 
 // =====================================================================================================================
@@ -748,10 +826,51 @@ static WsLayout make_layout(int B, int C, int H, int W, bool use_ms, bool use_ff
     return L;
 }
 
+static bool even_pyramid(const WsLayout& L) {         // every pooled level has even sides: no padding anywhere, aligned 2x2 cells
+    const char* e = getenv("BNERV_LOSS_FUSED");                 // A/B switch, read per call (tests compare the two forms bit for bit)
+    if (e && e[0] == '0') return false;
+    for (int l = 0; l < LV - 1; ++l) if ((L.pyr.H[l] & 1) || (L.pyr.W[l] & 1)) return false;
+    return true;
+}
+
 static int run_ms_forward(hipStream_t st, const float* X, const float* Y, float* ws, const WsLayout& L, int B, int C, float chain, bool want_g) {
     const int BC = B * C;
     const Win win = make_win();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    if (even_pyramid(L)) {
+        // 3 launches instead of 10: the pyramid, every level's statistics, the coefficients
+        static const float wts[LV] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
+        PyrArgs pa{};
+        pa.src[0] = X; pa.src[1] = Y; pa.planes = BC;
+        for (int l = 0; l < LV; ++l) {
+            pa.H[l] = L.pyr.H[l]; pa.W[l] = L.pyr.W[l];
+            if (L.pyr.H[l] <= HW_ || L.pyr.W[l] <= HW_) return bnerv_set_error(BNERV_E_ARG, "ms_ssim: level %d is %dx%d, needs > %d on both sides", l, L.pyr.H[l], L.pyr.W[l], HW_);
+            if (l > 0) { pa.dst[0][l] = ws + L.pyrX[l]; pa.dst[1][l] = ws + L.pyrY[l]; }
+        }
+        hipLaunchKernelGGL(pyramid_kernel, dim3(cdiv(L.pyr.W[1], 16), cdiv(L.pyr.H[1], 16), 2 * BC), dim3(256), 0, st, pa);
+        BNERV_LAUNCH_CHECK("pyramid");
+        SsimAllArgs sa{};
+        CoefArgs ca{};
+        int nblk = 0;
+        for (int l = 0; l < LV; ++l) {
+            SsimArgs& a = sa.lv[l];
+            a.X = l ? ws + L.pyrX[l] : X; a.Y = l ? ws + L.pyrY[l] : Y; a.partial = ws + L.ssim_part[l]; a.H = L.pyr.H[l]; a.W = L.pyr.W[l];
+            a.G = want_g ? ws + L.Gl[l] : nullptr;
+            a.tiles_x = cdiv(a.W - HW_, STW); a.tiles_y = cdiv(a.H - HW_, STH); a.C1 = C1; a.C2 = C2; a.win = win;
+            sa.first[l] = nblk;
+            nblk += a.tiles_x * a.tiles_y;
+            ca.partial[l] = ws + L.ssim_part[l]; ca.tiles[l] = L.tiles[l];
+            ca.inv_nvalid[l] = 1.0f / ((float)(a.H - HW_) * (float)(a.W - HW_));
+            ca.weights[l] = wts[l];
+        }
+        sa.first[LV] = nblk;
+        hipLaunchKernelGGL(ssim_fwd_all_kernel, dim3(nblk, BC), dim3(256), 0, st, sa);
+        BNERV_LAUNCH_CHECK("ssim_fwd_all");
+        ca.msval = ws + L.msval; ca.coef = ws + L.coef; ca.BC = BC; ca.chain = chain;
+        hipLaunchKernelGGL(ms_coef_kernel, dim3(BC), dim3(320), 0, st, ca);
+        BNERV_LAUNCH_CHECK("ms_coef");
+        return BNERV_OK;
+    }
     const float* Xl = X; const float* Yl = Y;
     CoefArgs ca{};
     static const float weights[LV] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
@@ -786,6 +905,28 @@ static int run_ms_forward(hipStream_t st, const float* X, const float* Y, float*
 static int run_ms_backward(hipStream_t st, const float* X, const float* Y, float* grad, float* ws, const WsLayout& L, int B, int C, float k_l1, float k_l2) {
     const int BC = B * C;
     const Win win = make_win();
+    if (even_pyramid(L)) {
+        // 2 launches instead of 5: the coarser levels' own terms together, then level 0 with the 0.25-chain over them
+        SsimAllArgs sa{};
+        CoarseChain cc{};
+        int nblk = 0;
+        for (int l = 0; l < LV; ++l) {
+            SsimArgs& a = sa.lv[l];
+            a.X = l ? ws + L.pyrX[l] : X; a.Y = l ? ws + L.pyrY[l] : Y; a.coef = ws + L.coef + (size_t)l * BC;
+            a.dX = l ? ws + L.dXl[l] : grad; a.H = L.pyr.H[l]; a.W = L.pyr.W[l]; a.C1 = 0.01f * 0.01f; a.C2 = 0.03f * 0.03f; a.win = win;
+            a.k_l1 = k_l1; a.k_l2 = k_l2; a.G = ws + L.Gl[l];
+            sa.first[l] = nblk;
+            if (l >= 1) nblk += cdiv(a.W, STW) * cdiv(a.H, STH);
+            cc.own[l] = l ? ws + L.dXl[l] : nullptr; cc.H[l] = a.H; cc.W[l] = a.W;
+        }
+        sa.first[LV] = nblk;
+        cc.n = LV - 1;
+        hipLaunchKernelGGL(ssim_bwd_coarse_all_kernel, dim3(nblk, BC), dim3(256), 0, st, sa);
+        BNERV_LAUNCH_CHECK("ssim_bwd_coarse_all");
+        hipLaunchKernelGGL(ssim_bwd_level0_chain_kernel, dim3(cdiv(L.pyr.W[0], STW), cdiv(L.pyr.H[0], STH), BC), dim3(256), 0, st, sa.lv[0], cc);
+        BNERV_LAUNCH_CHECK("ssim_bwd_level0");
+        return BNERV_OK;
+    }
     for (int l = LV - 1; l >= 0; --l) {
         const int Hl = L.pyr.H[l], Wl = L.pyr.W[l];
         SsimArgs a{};

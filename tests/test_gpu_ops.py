@@ -689,6 +689,26 @@ def test_wide_split_kernels_keep_the_f32_contract():
     assert r3.returncode == 1 and "OUTSIDE" in r3.stdout, r3.stdout[-3000:] + r3.stderr[-2000:]
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 720, 1280), (2, 3, 176, 208), (1, 1, 192, 352)])
+def test_fused_msssim_launches_equal_the_level_by_level_form(ops, shape, monkeypatch):
+    """Frames whose pyramid has even sides take the fused MS-SSIM launches (one pyramid kernel, one statistics launch for all five
+    levels, the coarser levels' gradients in one launch and their 0.25-chain evaluated inside the level-0 launch: 5 launches instead of
+    15).  Same formulas on the same data; the compiler contracts a few multiply-adds differently in the two forms, so the comparison
+    with the level-by-level form (BNERV_LOSS_FUSED=0) allows rounding: values to 4 ulp, the gradient to 3e-5 of its largest entry."""
+    g = torch.Generator().manual_seed(sum(shape))
+    tgt = torch.rand(*shape, generator=g).to(DEV)
+    pred = (tgt + 0.1 * torch.randn(*shape, generator=g).to(DEV)).clamp(0, 1)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BNERV_LOSS_FUSED", mode)
+        loss, stats, grad = ops.loss_value_grad_stats(pred, tgt, "Fusion10_freq")
+        out[mode] = (loss.clone(), stats.clone(), ops.msssim(pred, tgt).clone(), grad.clone())
+    for a, b in zip(out["1"][:3], out["0"][:3]):
+        torch.testing.assert_close(a, b, rtol=5e-7, atol=0)
+    ga, gb = out["1"][3], out["0"][3]
+    assert (ga - gb).abs().max().item() <= 3e-5 * gb.abs().max().item()      # (a0 + 2 x a1 + y a2 cancels: a different contraction shows at 1e-5 of the largest entry)
+
+
 def test_msssim_kernel_against_independent_form(ops):
     """bnerv_msssim (the kernels behind the 0.3 * (1 - ms_ssim) term of Fusion10_freq, hnerv_utils.py:369-370, and the MS-SSIM eval
     metric, :410-412) against the independent float64 form of tests/msssim_independent.py -- direct 2-D window, written from the
