@@ -69,7 +69,12 @@ class TrainStep:
         # loss_fn(...).backward() + psnr_fn_single(...) of train_nerv_all.py:337-347 as ONE fused launch sequence: the loss
         # gradient seeds backward directly and the per-sample PSNR comes from the same L2 sums (stats[:, 4])
         loss, stats, grad = ops.loss_value_grad_stats(img_out, self.static_img, self.loss_type)
-        img_out.backward(grad)
+        import os
+        if os.environ.get("BNERV_LAZY_FLUSH", "1") != "0" and getattr(self.model, "lazy_flush_ok", False):
+            with ops.lazy_flush():              # the blocks' slab reductions are flushed by their first reader, not once per block
+                img_out.backward(grad)
+        else:
+            img_out.backward(grad)
         self.loss_out = loss
         self.psnr_out = stats[:, 4]
 

@@ -100,6 +100,7 @@ class Conv_Up_Block(nn.Module):                                                 
 
 
 class ENeRV_Boost(_CEMHooks, nn.Module):
+    lazy_flush_ok = True     # (engine.TrainStep: deferred slab reductions are flushed by their first reader; all readers are this package's operators)
     def __init__(self, expansion=3, args=None):
         super().__init__()
         self.encoder = nn.Identity()

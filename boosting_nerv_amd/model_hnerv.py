@@ -22,6 +22,7 @@ class HNeRVDecoder(nn.Module):
 
 
 class HNeRV_Boost(_CEMHooks, nn.Module):
+    lazy_flush_ok = True     # (engine.TrainStep: deferred slab reductions are flushed by their first reader; all readers are this package's operators)
     def __init__(self, args):
         super().__init__()
         self.embed = args.embed

@@ -102,6 +102,7 @@ def decoder_layers_forward(layers, output, t_embed, out_list):
 
 
 class NeRV_Boost(_CEMHooks, nn.Module):
+    lazy_flush_ok = True     # every reader of a deferred slab reduction in this model's backward is an operator of this package (engine.TrainStep)
     def __init__(self, expansion=1, args=None):
         super().__init__()
         self.encoder = nn.Identity()

@@ -75,10 +75,35 @@ def _reduce_slabs(slabs, n_slabs, count, out, defer=False):
     L.check(L.load().bnerv_reduce_slabs(L.stream(), L.ptr(slabs), n_slabs, count, L.ptr(out)), "bnerv_reduce_slabs")
 
 
-def _flush_deferred():
+_lazy_depth = 0       # > 0: inside lazy_flush() -- the per-block flushes are postponed to the first consumer of a deferred result
+
+
+def _flush_deferred(force=True, block_end=False):
+    """Launch whatever slab reductions are still queued on this stream's context.  `block_end`: the call that closes a block's
+    backward -- inside lazy_flush() it is skipped, because the queued results (weight / bias gradients, the per-channel TAT sums) have
+    no reader until the grouped dense backward or the optimizer, and both flush first: ~5 small dependent launches per step less."""
+    if block_end and _lazy_depth > 0:
+        return
     c = L.ctx()
     L.check(L.load().bnerv_flush_deferred(c.handle, L.stream()), "bnerv_flush_deferred")
     c.keep.clear()
+
+
+class lazy_flush:
+    """with lazy_flush(): backward()  -- postpone the end-of-block flushes of the deferred slab reductions; every consumer inside this
+    package (grouped dense / dense GEMM / stand-alone affine backward) flushes on entry, and leaving the context flushes the rest."""
+
+    def __enter__(self):
+        global _lazy_depth
+        _lazy_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _lazy_depth
+        _lazy_depth -= 1
+        if _lazy_depth == 0:
+            _flush_deferred()
+        return False
 
 
 def _tiles(H, W):
@@ -149,6 +174,8 @@ class _DenseGrouped(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dys):
+        if _lazy_depth > 0:
+            _flush_deferred()               # the incoming gradients may be deferred slab reductions (the TAT blocks' channel sums)
         n, B, acts = ctx.n, ctx.B, ctx.acts
         sv = ctx.saved_tensors
         xc, wc, ys, auxs = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:4 * n]
@@ -230,6 +257,8 @@ class _DenseGemm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if _lazy_depth > 0:
+            _flush_deferred()
         x2, w2, y, aux = ctx.saved_tensors
         B, I = x2.shape
         O = w2.shape[0]
@@ -291,7 +320,7 @@ class _Conv2dPS(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _conv(g, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1)
-        _flush_deferred()
+        _flush_deferred(block_end=True)
         return dx, dw, db, None
 
 
@@ -354,7 +383,7 @@ class _TATBlock(torch.autograd.Function):
     def backward(ctx, dout):
         x0, h, gp, s0, t0, s1, t1, w0, w1 = ctx.saved_tensors
         dx0, ds0, dt0, ds1, dt1, dw0, db0, dw1, db1 = _tat_backward(L.f32c(dout), x0, None, h, gp, s0, t0, s1, t1, w0, w1)
-        _flush_deferred()
+        _flush_deferred(block_end=True)
         m = ctx.mshape
         return dx0, ds0.reshape(m), dt0.reshape(m), ds1.reshape(m), dt1.reshape(m), dw0, db0, dw1, db1
 
@@ -399,7 +428,7 @@ class _SNeRVBlock(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _conv(du, wu, None, dx, B=B, Cin=Ct, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1)
-        _flush_deferred()
+        _flush_deferred(block_end=True)
         m = ctx.mshape
         return dx, dwu, dbu, ds0.reshape(m), dt0.reshape(m), ds1.reshape(m), dt1.reshape(m), dw0, db0, dw1, db1, None
 
@@ -427,6 +456,8 @@ class _SFTAffine(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if _lazy_depth > 0:
+            _flush_deferred()
         x, sc = ctx.saved_tensors
         g = L.f32c(g)
         B, Cc = x.shape[:2]
@@ -471,7 +502,7 @@ class _HeadTanh(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _conv(g, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_TANHGRAD, ep_mode=L.EP_PLAIN, transposed=1, aux0=img)
-        _flush_deferred()
+        _flush_deferred(block_end=True)
         return dx, dw, db
 
 

@@ -457,6 +457,35 @@ def test_step_frame_on_resident_clip_equals_step_on_copies():
         assert torch.equal(sd1[k], sd0[k]), k
 
 
+@pytest.mark.parametrize("name,cfg", [("nerv", configs.tiny_nerv), ("hnerv", configs.tiny_hnerv), ("enerv", configs.tiny_enerv)])
+def test_lazy_flush_of_deferred_reductions_changes_no_bit(name, cfg, monkeypatch):
+    """engine.TrainStep postpones the end-of-block flushes of the deferred slab reductions (weight / bias gradients, TAT channel sums)
+    to their first reader (ops.lazy_flush): ~5 small dependent launches per step less.  Same reductions in the same order: losses and
+    parameters after 5 steps (eager, capture, replays) are bit-equal to the step that flushes after every block (BNERV_LAZY_FLUSH=0),
+    for all three model families."""
+    from boosting_nerv_amd.engine import TrainStep
+    from boosting_nerv_amd.optimizer import Adan
+    from boosting_nerv_amd.synth import SyntheticVideo
+    vid = SyntheticVideo(3, 180, 320)
+    fd = torch.stack([vid.frame(i) for i in range(3)]).to(DEV)
+    nd = torch.tensor([(i + 1) / 3 for i in range(3)], dtype=torch.float64).to(DEV)
+
+    def run(lazy):
+        monkeypatch.setenv("BNERV_LAZY_FLUSH", "1" if lazy else "0")
+        torch.manual_seed(1)
+        args = cfg()
+        model = _build(name, args).to(DEV)
+        opt = Adan(model.parameters(), lr=0.002)
+        step = TrainStep(model, opt, "Fusion10_freq", args.model == "HNeRV_Boost", (1, 3, 180, 320), torch.device(DEV), use_graph=True, warmup_eager=1)
+        losses = [step(fd[s % 3:s % 3 + 1], nd[s % 3:s % 3 + 1])[0].item() for s in range(5)]
+        return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}
+    l1, sd1 = run(True)
+    l0, sd0 = run(False)
+    assert l1 == l0, (l1, l0)
+    for k in sd1:
+        assert torch.equal(sd1[k], sd0[k]), k
+
+
 def test_short_schedule_end_psnr_matches_oracle():
     """SURVEY 8(d) parity gate: train the tiny NeRV_Boost for 3 epochs over 6 synthetic frames with the cosine schedule, same
     init and frame order on both sides, then evaluate every frame: the end PSNR (mean over frames, fp32 model) of the HIP
