@@ -101,6 +101,7 @@ SYMBOLS = {
     "bnerv_build_arch": (C.c_char_p, []),
     "bnerv_pe_fwd_f32": (_I, [_V, _V, _V, _V, _I, _I]),
     "bnerv_pe_fwd_f64": (_I, [_V, _V, _V, _V, _I, _I]),
+    "bnerv_pe_fwd_f32_from_f64": (_I, [_V, _V, _V, _V, _I, _I]),
     "bnerv_dense_grouped_fwd": (_I, [_V, C.POINTER(DenseFwdDesc), _I, _I]),
     "bnerv_dense_grouped_bwd": (_I, [_V, C.POINTER(DenseBwdDesc), _I, _I]),
     "bnerv_sft_affine_fwd": (_I, [_V, _V, _V, _V, _V, _I, _I, _I]),

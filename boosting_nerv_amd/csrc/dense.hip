@@ -18,6 +18,15 @@ __global__ void pe_f32_kernel(const float* __restrict__ pos, const float* __rest
     out[(size_t)n * 2 * L + l] = sinf(v);
     out[(size_t)n * 2 * L + L + l] = cosf(v);
 }
+// the same with the fp64 -> fp32 rounding of the position done here (`input[:, None].float()` of model_nerv.py:47 was a launch of its own)
+__global__ void pe_f32_from_f64_kernel(const double* __restrict__ pos, const float* __restrict__ bases, float* __restrict__ out, int N, int L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * L) return;
+    const int n = i / L, l = i - n * L;
+    const float v = __fmul_rn((float)pos[n], bases[l]);
+    out[(size_t)n * 2 * L + l] = sinf(v);
+    out[(size_t)n * 2 * L + L + l] = cosf(v);
+}
 __global__ void pe_f64_kernel(const double* __restrict__ pos, const float* __restrict__ bases, float* __restrict__ out, int N, int L) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * L) return;
@@ -65,15 +74,15 @@ struct BwdArgs { bnerv_dense_bwd_desc g[BNERV_MAX_DENSE_GROUPS]; int B; };
 // split over blockIdx.z in chunks of DW_CHUNK columns -- a single wave walking the whole row is a serial chain of ~140 dependent
 // load/store rounds (70 us per launch at C4); 4 independent columns per lane and round keep the loads in flight.
 constexpr int DW_CHUNK = 1024;
-__global__ __launch_bounds__(256) void dense_bwd_w_kernel(const BwdArgs a) {
+__device__ __forceinline__ void dense_bwd_w_body(const BwdArgs& a, const int bx, const int by, const int bz) {
     const BwdArgs* ap = &a;
-    const bnerv_dense_bwd_desc g = a.g[blockIdx.y];
+    const bnerv_dense_bwd_desc g = a.g[by];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int o = blockIdx.x * 4 + wave;
-    const int i0 = blockIdx.z * DW_CHUNK;
-    if (o >= g.O || (i0 >= g.I && blockIdx.z != 0)) return;
+    const int o = bx * 4 + wave;
+    const int i0 = bz * DW_CHUNK;
+    if (o >= g.O || (i0 >= g.I && bz != 0)) return;
     const int B = ap->B;
-    if (blockIdx.z == 0) {
+    if (bz == 0) {
         float dbsum = 0.f;
         for (int b = 0; b < B; ++b) {
             const size_t k = (size_t)b * g.O + o;
@@ -107,18 +116,28 @@ __global__ __launch_bounds__(256) void dense_bwd_w_kernel(const BwdArgs a) {
     }
 }
 
-// phase 2: dx_part[chunk][b][i] = sum_{o in chunk} dpre[b][o] * w[o][i]      (threads over i: coalesced rows of w)
-__global__ __launch_bounds__(256) void dense_bwd_x_kernel(const BwdArgs a) {
+// phase 2: dx_part[chunk][b][i] = sum_{o in chunk} dpre[b][o] * w[o][i]      (threads over i: coalesced rows of w).  dpre is rebuilt
+// from dy and the saved activation here (one value per row), so the two phases do not depend on each other and share ONE launch.
+__device__ __forceinline__ void dense_bwd_x_body(const BwdArgs& a, const int bx, const int by, const int bz) {
     const BwdArgs* ap = &a;
-    const bnerv_dense_bwd_desc g = a.g[blockIdx.z];
+    const bnerv_dense_bwd_desc g = a.g[bz];
     if (!g.dx_part) return;
-    const int chunk = blockIdx.x;
+    const int chunk = bx;
     const int o0 = chunk * BNERV_DENSE_DX_CHUNK;
     if (o0 >= g.O) return;
     const int o1 = min(o0 + BNERV_DENSE_DX_CHUNK, g.O);
-    const int b = blockIdx.y;
+    const int b = by;
     __shared__ float s_dp[BNERV_DENSE_DX_CHUNK];
-    if ((int)threadIdx.x < BNERV_DENSE_DX_CHUNK) s_dp[threadIdx.x] = (int)threadIdx.x < o1 - o0 ? g.dpre[(size_t)b * g.O + o0 + threadIdx.x] : 0.f;
+    if ((int)threadIdx.x < BNERV_DENSE_DX_CHUNK) {
+        float dp = 0.f;
+        if ((int)threadIdx.x < o1 - o0) {
+            const size_t k = (size_t)b * g.O + o0 + threadIdx.x;
+            dp = g.dy[k];
+            if (g.act == BNERV_ACT_RELU) dp = g.y[k] > 0.f ? dp : 0.f;
+            else if (g.act == BNERV_ACT_SIN) dp *= g.aux[k];
+        }
+        s_dp[threadIdx.x] = dp;
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < g.I; i += 256) {
         float wv[BNERV_DENSE_DX_CHUNK];                    // all rows of the chunk in flight, then the (fixed-order) dot product
@@ -128,6 +147,20 @@ __global__ __launch_bounds__(256) void dense_bwd_x_kernel(const BwdArgs a) {
 #pragma unroll
         for (int r = 0; r < BNERV_DENSE_DX_CHUNK; ++r) s = fmaf(s_dp[r], wv[r], s);
         g.dx_part[((size_t)chunk * ap->B + b) * g.I + i] = s;
+    }
+}
+
+struct BwdGrid { int wx, wy, wz, xx, xy, xz; };
+__global__ __launch_bounds__(256) void dense_bwd_kernel(const BwdArgs a, const BwdGrid q) {
+    const int nw = q.wx * q.wy * q.wz;
+    int t = blockIdx.x;
+    if (t < nw) {                                          // block-uniform
+        const int bx = t % q.wx; t /= q.wx;
+        dense_bwd_w_body(a, bx, t % q.wy, t / q.wy);
+    } else {
+        t -= nw;
+        const int bx = t % q.xx; t /= q.xx;
+        dense_bwd_x_body(a, bx, t % q.xy, t / q.xy);
     }
 }
 
@@ -200,6 +233,13 @@ extern "C" int bnerv_pe_fwd_f32(void* stream, const float* pos, const float* bas
     return BNERV_OK;
 }
 
+extern "C" int bnerv_pe_fwd_f32_from_f64(void* stream, const double* pos, const float* bases, float* out, int N, int L) {
+    BNERV_REQUIRE(pos && bases && out && N > 0 && L > 0, "pe_fwd_f32_from_f64: bad args");
+    hipLaunchKernelGGL(pe_f32_from_f64_kernel, dim3(cdiv(N * L, 256)), dim3(256), 0, (hipStream_t)stream, pos, bases, out, N, L);
+    BNERV_LAUNCH_CHECK("pe_f32_from_f64");
+    return BNERV_OK;
+}
+
 extern "C" int bnerv_pe_fwd_f64(void* stream, const double* pos, const float* bases, float* out, int N, int L) {
     BNERV_REQUIRE(pos && bases && out && N > 0 && L > 0, "pe_fwd_f64: bad args");
     hipLaunchKernelGGL(pe_f64_kernel, dim3(cdiv(N * L, 256)), dim3(256), 0, (hipStream_t)stream, pos, bases, out, N, L);
@@ -242,12 +282,10 @@ extern "C" int bnerv_dense_grouped_bwd(void* stream, const bnerv_dense_bwd_desc*
         any_dx |= g.dx_part != nullptr;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dense_bwd_w_kernel, dim3(cdiv(maxO, 4), n_groups, cdiv(maxI, DW_CHUNK)), dim3(256), 0, st, a);
-    BNERV_LAUNCH_CHECK("dense_bwd_w");
-    if (any_dx) {
-        hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(cdiv(maxO, BNERV_DENSE_DX_CHUNK), B, n_groups), dim3(256), 0, st, a);
-        BNERV_LAUNCH_CHECK("dense_bwd_x");
-    }
+    BwdGrid q{cdiv(maxO, 4), n_groups, cdiv(maxI, DW_CHUNK), 0, 0, 0};
+    if (any_dx) { q.xx = cdiv(maxO, BNERV_DENSE_DX_CHUNK); q.xy = B; q.xz = n_groups; }
+    hipLaunchKernelGGL(dense_bwd_kernel, dim3(q.wx * q.wy * q.wz + q.xx * q.xy * q.xz), dim3(256), 0, st, a, q);
+    BNERV_LAUNCH_CHECK("dense_bwd");
     return BNERV_OK;
 }
 

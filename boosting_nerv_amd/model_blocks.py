@@ -91,12 +91,13 @@ class PositionEncoding(nn.Module):
             self.embed_length = int(2 * levels)
             self._dev_bases = None
 
-    def forward(self, pos):
+    def forward(self, pos, round_to_f32=False):
+        """round_to_f32: `pos` is the fp64 index the caller would pass as pos.float() (model_nerv.py:47): rounded inside the kernel."""
         if "pe" not in self.pe_embed:
-            return pos
+            return pos.float() if round_to_f32 else pos
         if self._dev_bases is None or self._dev_bases.device != pos.device:
             self._dev_bases = self.pe_bases.to(pos.device)
-        return ops.positional_encoding(pos, self._dev_bases)
+        return ops.positional_encoding(pos, self._dev_bases, round_to_f32=round_to_f32)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

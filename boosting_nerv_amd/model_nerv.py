@@ -133,8 +133,7 @@ class NeRV_Boost(_CEMHooks, nn.Module):
 
     def forward(self, input, input_embed=None, norm_idx=None):
         dec_start = time.time()
-        t = input[:, None].float()
-        t_embed = self.pe_t(t)
+        t_embed = self.pe_t(input[:, None], round_to_f32=True)         # pe_t(input[:, None].float()) without the conversion launch
         output, t_embed = mlp_pair_forward([self.stem, self.stem_t], [t_embed, t_embed])
         output = output.view(output.size(0), self.fc_dim, self.fc_h, self.fc_w)
         out_list = []

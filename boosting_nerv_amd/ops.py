@@ -119,15 +119,18 @@ def _bc(t, B, Cc):
 # ----------------------------------------------------------------------------------------------------------------------
 # positional encoding (no gradient: positions are data)
 # ----------------------------------------------------------------------------------------------------------------------
-def positional_encoding(pos, bases):
+def positional_encoding(pos, bases, round_to_f32=False):
     """pos [N,1] fp32 or fp64 on the device; bases fp32 [L] (built on the host by the reference expression).
-    Returns [N, 2L, 1, 1] fp32 = cat[sin(pos*bases), cos(pos*bases)]; fp64 positions use the fp64 product form."""
+    Returns [N, 2L, 1, 1] fp32 = cat[sin(pos*bases), cos(pos*bases)]; fp64 positions use the fp64 product form -- unless
+    round_to_f32: then they are rounded to fp32 first, i.e. positional_encoding(pos.float(), bases) without the conversion launch."""
     L.require_device(pos, "pos")
     N, Lv = pos.shape[0], bases.numel()
     bases = bases.to(device=pos.device, dtype=torch.float32).contiguous()
     out = torch.empty(N, 2 * Lv, 1, 1, dtype=torch.float32, device=pos.device)
     lib = L.load()
-    if pos.dtype == torch.float64:
+    if pos.dtype == torch.float64 and round_to_f32:
+        L.check(lib.bnerv_pe_fwd_f32_from_f64(L.stream(), L.ptr(pos.contiguous()), L.ptr(bases), L.ptr(out), N, Lv), "bnerv_pe_fwd_f32_from_f64")
+    elif pos.dtype == torch.float64:
         L.check(lib.bnerv_pe_fwd_f64(L.stream(), L.ptr(pos.contiguous()), L.ptr(bases), L.ptr(out), N, Lv), "bnerv_pe_fwd_f64")
     else:
         p = pos.contiguous() if pos.dtype == torch.float32 else pos.float().contiguous()

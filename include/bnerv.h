@@ -47,6 +47,8 @@ const char* bnerv_build_arch(void);
  * ------------------------------------------------------------------------------------------------------------------ */
 int bnerv_pe_fwd_f32(void* stream, const float* pos, const float* bases, float* out, int N, int L);
 int bnerv_pe_fwd_f64(void* stream, const double* pos, const float* bases, float* out, int N, int L);
+/* f32 form on fp64 positions: pos is rounded to fp32 first (the `input[:, None].float()` of model_nerv.py:47 / model_enerv.py:286), then as _f32 */
+int bnerv_pe_fwd_f32_from_f64(void* stream, const double* pos, const float* bases, float* out, int N, int L);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Grouped dense layers on [B, I] vectors (1x1 convs on [B,C,1,1]).  Replaces the CustomConv2d(kernel_size=1) calls of
