@@ -26,6 +26,10 @@ __global__ __launch_bounds__(256) void side_flush_kernel(const SidePack sp) {
     __shared__ float red[256];
     side_slice(sp, blockIdx.x, red);
 }
+__global__ __launch_bounds__(256) void side_flush_many_kernel(const SideFlushPack sp) {
+    __shared__ float red[256];
+    side_slice(sp, blockIdx.x, red);
+}
 
 SideJob make_job(const void* src, int n_slabs, int count, int ncols, float* out, float* out2) {
     SideJob j;
@@ -72,10 +76,19 @@ void bnerv_side_take(bnerv_ctx* ctx, SidePack* sp, int max_slices) {
 int bnerv_side_pending(const bnerv_ctx* ctx) { return ctx ? (int)ctx->queue.size() : 0; }
 
 int bnerv_side_flush(bnerv_ctx* ctx, hipStream_t st) {
-    while (ctx && !ctx->queue.empty()) {
-        SidePack sp;
-        bnerv_side_take(ctx, &sp, 0x7fffffff);
-        hipLaunchKernelGGL(side_flush_kernel, dim3(sp.n_slices), dim3(256), 0, st, sp);
+    while (ctx && !ctx->queue.empty()) {                   // up to SIDE_FLUSH_JOBS queued reductions per launch, in issue order
+        SideFlushPack sp;
+        std::vector<SideJob>& q = ctx->queue;
+        int n = 0;
+        sp.n_slices = 0;
+        while (n < (int)q.size() && n < SIDE_FLUSH_JOBS) {
+            sp.j[n] = q[n];
+            sp.n_slices += q[n].slices;
+            ++n;
+        }
+        sp.n_jobs = n;
+        q.erase(q.begin(), q.begin() + n);
+        hipLaunchKernelGGL(side_flush_many_kernel, dim3(sp.n_slices), dim3(256), 0, st, sp);
         BNERV_LAUNCH_CHECK("side_flush");
     }
     return BNERV_OK;

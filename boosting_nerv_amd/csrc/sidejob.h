@@ -28,6 +28,11 @@ struct SidePack {
     SideJob j[SIDE_MAX_JOBS];
     int n_jobs, n_slices;
 };
+constexpr int SIDE_FLUSH_JOBS = 32;    // the stand-alone flush takes many more jobs per launch (it is all the launch does)
+struct SideFlushPack {
+    SideJob j[SIDE_FLUSH_JOBS];
+    int n_jobs, n_slices;
+};
 
 // the caller-owned context of one stream (include/bnerv.h): the deferred-reduction queue and a scratch buffer in device memory
 #include <vector>
@@ -51,7 +56,8 @@ int bnerv_side_flush(bnerv_ctx* ctx, hipStream_t st);    // standalone launch(es
 int bnerv_side_pending(const bnerv_ctx* ctx);
 
 // one slice (256 threads, `red` = 256 floats of LDS the caller no longer needs; caller guarantees a barrier before)
-__device__ __forceinline__ void side_slice(const SidePack& sp, int s, float* red) {
+template <class Pack>
+__device__ __forceinline__ void side_slice(const Pack& sp, int s, float* red) {
     int j = 0;
     while (j < sp.n_jobs - 1 && s >= sp.j[j].slices) { s -= sp.j[j].slices; ++j; }
     const SideJob& job = sp.j[j];
