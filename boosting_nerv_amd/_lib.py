@@ -124,6 +124,7 @@ SYMBOLS = {
     "bnerv_conv_splitk_ws_bytes": (_Z, [C.POINTER(ConvDesc)]),
     "bnerv_conv_partial_rows": (_I, [C.POINTER(ConvDesc)]),
     "bnerv_conv_wgrad_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "bnerv_conv_wgrad_pair": (_I, [_V, C.POINTER(ConvDesc), C.POINTER(WgradDesc)]),
     "bnerv_conv_wgrad": (_I, [_V, C.POINTER(WgradDesc)]),
     "bnerv_cem_ws_bytes": (_Z, [_I, _I]),
     "bnerv_cem_scale_fwd": (_I, [_V, C.POINTER(CemChunk), _V, _V, _Z]),

@@ -100,8 +100,9 @@ __device__ __forceinline__ void side_slice(const Pack& sp, int s, float* red) {
 }
 
 // the slices a hosting block executes: blocks are ranked from the END of the grid (they own the fewest tiles)
-__device__ __forceinline__ void side_run_hosted(const SidePack& sp, float* red) {
+__device__ __forceinline__ void side_run_hosted(const SidePack& sp, float* red, int vb, int vgrid) {     // (vb of vgrid: a launch that runs two kernels' blocks)
     if (sp.n_slices == 0) return;
     __syncthreads();
-    for (int s = (int)(gridDim.x - 1 - blockIdx.x); s < sp.n_slices; s += (int)gridDim.x) side_slice(sp, s, red);
+    for (int s = vgrid - 1 - vb; s < sp.n_slices; s += vgrid) side_slice(sp, s, red);
 }
+__device__ __forceinline__ void side_run_hosted(const SidePack& sp, float* red) { side_run_hosted(sp, red, (int)blockIdx.x, (int)gridDim.x); }

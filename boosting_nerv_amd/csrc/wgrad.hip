@@ -18,6 +18,7 @@
 #include "common.h"
 #include "sidejob.h"
 #include "split16.h"
+#include "conv4_body.h"     // the 4x4x1 conv body: paired conv + weight-gradient launches (bnerv_conv_wgrad_pair, bottom of this file)
 #include <stdlib.h>
 #include <type_traits>
 #include <string.h>
@@ -420,7 +421,8 @@ __device__ unsigned long long g_trace_w[1024 * 4 * 8 * 8];
 #endif
 // GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient (two float4 per channel PAIR), 2 = tanh-grad (g, gaux)
 template <int KS, int IN, int GM2>
-__global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(const WArgs wa, const int n_grows /* s_g rows kept */, const SidePack side) {
+__device__ __forceinline__ void wgrad_lean_body(const WArgs& wa, const int n_grows /* s_g rows kept */, const SidePack& side, const int vb, const int vgrid) {
+    // (vb of vgrid: this launch's block index / size, or the weight-gradient part of a paired launch)
     using G = Geo<KS>;
     constexpr int NTW = (KS == 3) ? 7 : 1;
     constexpr int NPLL = (KS == 3) ? 12 : 15;                                // data planes (input channels) of this kernel
@@ -446,9 +448,9 @@ __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(cons
 
     // XCD x owns a contiguous slice of the tile list; its blocks take it round-robin
     const int total = d.B * tiles_x * tiles_y;
-    const int nx = min(8, (int)gridDim.x);                                   // (a grid of fewer than 8 blocks has fewer slices)
-    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx;
-    const int nlb = (gridDim.x - xcd + nx - 1) / nx;
+    const int nx = min(8, vgrid);                                            // (a grid of fewer than 8 blocks has fewer slices)
+    const int xcd = vb % nx, lb = vb / nx;
+    const int nlb = (vgrid - xcd + nx - 1) / nx;
     const int per = total / nx, extra = total % nx;
     const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
     int itx = r0 + lb;
@@ -702,15 +704,34 @@ __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(cons
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_red[wave * RSZ + (4 * kq + r) * RW + n * 16 + li] = acc[n][r];
     __syncthreads();
-    float* slab = wa.slab + (size_t)blockIdx.x * Cout * wa.ncols;
+    float* slab = wa.slab + (size_t)vb * Cout * wa.ncols;
     for (int idx = tid; idx < RSZ; idx += 256) {
         const int row = idx / RW, col = idx - row * RW;
         if (row < Cout && col < wa.ncols)
             slab[(size_t)row * wa.ncols + col] = (s_red[idx] + s_red[RSZ + idx]) + (s_red[2 * RSZ + idx] + s_red[3 * RSZ + idx]);
     }
     WTRACE(7, 3);
-    side_run_hosted(side, smem);                           // queued slab reductions of EARLIER launches (sidejob.h)
+    side_run_hosted(side, smem, vb, vgrid);                // queued slab reductions of EARLIER launches (sidejob.h)
     WTRACE(7, 4);
+}
+template <int KS, int IN, int GM2>
+__global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(const WArgs wa, const int n_grows, const SidePack side) {
+    wgrad_lean_body<KS, IN, GM2>(wa, n_grows, side, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---- paired launch: the data gradient of a 12-channel 3x3 conv (conv4_body.h) and a weight gradient that does not depend on it, in
+// ONE grid -- blocks [0, n_conv) run the conv, the rest the weight gradient.  Inside a TAT block's backward the pairs are
+// (dW1 | dconv1), (dW0 | dconv0), (dW_block | dconv_block): each pair reads the same incoming gradient, and neither half fills the
+// chip through its prologue and tail (at 180x320 each is one tile per block: two latency-bound launches become one).
+template <int EP, int WIN>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_pair_kernel(const bnerv_conv::KArgs ka, const WArgs wa, const int n_grows, const int n_conv, const SidePack side) {
+    if ((int)blockIdx.x < n_conv) {                        // block-uniform
+        SidePack none;
+        none.n_jobs = 0; none.n_slices = 0;
+        bnerv_q4::conv_q4_body<BNERV_IN_PLAIN, EP>(ka, none, (int)blockIdx.x, n_conv);
+    } else {
+        wgrad_lean_body<3, WIN, 0>(wa, n_grows, side, (int)blockIdx.x - n_conv, (int)gridDim.x - n_conv);
+    }
 }
 
 constexpr size_t WLEAN_MAX_BYTES = 0x7ff00000;
@@ -733,17 +754,22 @@ static int wlean_blocks(const bnerv_wgrad_desc& d) {
     return want < target ? want : target;
 }
 
-template <int KS, int IN, int GM2>
-int launch_wlean(hipStream_t st, const WArgs& wa) {
+template <int KS>
+static size_t wlean_lds_bytes(int n_grows) {
     using G = Geo<KS>;
     constexpr int NTW = (KS == 3) ? 7 : 1;
     constexpr int NPLL = (KS == 3) ? 12 : 15;
     constexpr int NXSLOT = NPLL * G::ROWS * G::SEGS;
     constexpr int NXS = (NXSLOT + 255) / 256;
-    const int n_grows = wa.d.Cout <= 12 ? 12 : 16;
     const size_t lds_main = (size_t)(NPLL + 2) * G::PLANE + (size_t)(NXS * 256 - NXSLOT) * 4 + (size_t)n_grows * CSG + 64 + 32;
     const size_t lds_red = (size_t)4 * 16 * NTW * 16;
-    const size_t lds = (lds_main > lds_red ? lds_main : lds_red) * sizeof(float);
+    return (lds_main > lds_red ? lds_main : lds_red) * sizeof(float);
+}
+
+template <int KS, int IN, int GM2>
+int launch_wlean(hipStream_t st, const WArgs& wa) {
+    const int n_grows = wa.d.Cout <= 12 ? 12 : 16;
+    const size_t lds = wlean_lds_bytes<KS>(n_grows);
     SidePack side;
     bnerv_side_take(wa.d.ctx, &side, 2 * wlean_blocks(wa.d));
     hipLaunchKernelGGL((wgrad_lean_kernel<KS, IN, GM2>), dim3(wlean_blocks(wa.d)), dim3(256), lds, st, wa, n_grows, side);
@@ -1722,5 +1748,82 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
     }
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3(cdiv(count, 32)), dim3(1024), 0, st, wa.slab, n_slabs, d.Cout, wa.ncols, d.dw, d.db);
     BNERV_LAUNCH_CHECK("wgrad_finish");
+    return BNERV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ paired launch
+namespace {
+template <int EP, int WIN>
+int launch_pair(hipStream_t st, bnerv_conv::KArgs& ka, const WArgs& wa) {
+    bnerv_q4::q4_prepare(ka);
+    const int n_grows = wa.d.Cout <= 12 ? 12 : 16;
+    size_t lds = bnerv_q4::q4_lds_bytes();
+    const size_t lw = wlean_lds_bytes<3>(n_grows);
+    if (lw > lds) lds = lw;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pair_kernel<EP, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    int n_conv = ka.total_items < 768 ? ka.total_items : 768;          // 3 conv blocks per CU when the layer is large
+    n_conv = (n_conv + 7) & ~7;                                        // multiple of 8: block b runs on XCD b % 8 for BOTH halves' slices
+    const int n_w = wlean_blocks(wa.d);
+    SidePack side;
+    bnerv_side_take(wa.d.ctx, &side, 2 * n_w);
+    hipLaunchKernelGGL((conv_wgrad_pair_kernel<EP, WIN>), dim3(n_conv + n_w), dim3(256), lds, st, ka, wa, n_grows, n_conv, side);
+    BNERV_LAUNCH_CHECK("conv_wgrad_pair");
+    return BNERV_OK;
+}
+}  // namespace
+
+// Returns BNERV_OK when both were launched together, 1 when the pair is not one this launch takes (the caller then issues
+// bnerv_conv_wgrad and bnerv_conv_igemm separately, in that order), a negative BNERV_E_* on error.
+extern "C" int bnerv_conv_wgrad_pair(void* stream, const bnerv_conv_desc* cdp, const bnerv_wgrad_desc* wdp) {
+    BNERV_REQUIRE(cdp != nullptr && wdp != nullptr, "conv_wgrad_pair: null descriptor");
+    static const bool off = [] { const char* e = getenv("BNERV_PAIR"); return e && e[0] == '0'; }();
+    if (off) return 1;
+    bnerv_conv::KArgs ka;
+    ka.d = *cdp;
+    const bnerv_conv_desc& c = ka.d;
+    WArgs wa;
+    wa.d = *wdp;
+    const bnerv_wgrad_desc& w = wa.d;
+    // the conv half: a plain-input 12-channel data gradient of conv4.hip's family
+    if (!(c.k == 3 && c.in_mode == BNERV_IN_PLAIN && c.in_s == 1 && c.out_s == 1 && c.x && c.w && c.out && c.B > 0)) return 1;
+    if (!(c.ep_mode == BNERV_EP_DGELU_SAVED || c.ep_mode == BNERV_EP_DSIN || c.ep_mode == BNERV_EP_PLAIN)) return 1;
+    if (c.ep_mode != BNERV_EP_PLAIN && !(c.aux0 && c.aux1 && c.scale && c.partial)) return 1;
+    if (c.transposed ? !(c.Cout == c.wCi && c.Cin == c.wCo) : !(c.Cout == c.wCo && c.Cin == c.wCi)) return 1;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    ka.tiles_x = cdiv(c.W, bnerv_conv::TW);
+    ka.tiles_y = cdiv(c.H, bnerv_conv::TH);
+    ka.vec = ((c.W % 4 == 0) && al(c.x) && al(c.out) && al(c.aux0) && al(c.aux1) && al(c.aux2)) ? 1 : 0;
+    ka.ksplit = 1;
+    ka.chunks_per_split = 0;
+    ka.magic_tiles = ka.magic_tiles_x = 0;
+    if (!bnerv_q4::q4_shape_ok(ka)) return 1;
+    { static const bool q4off = [] { const char* e = getenv("BNERV_Q4"); return e && e[0] == '0'; }(); if (q4off) return 1; }
+    // the weight-gradient half: the lean kernel's plain / affine 3x3 form on the same image size
+    if (!(w.k == 3 && w.x && w.g && w.dw && w.ws && w.B == c.B && w.H == c.H && w.W == c.W && w.g_s == 1 && w.defer_finish && w.ctx && w.ctx == c.ctx)) return 1;
+    if (!(w.in_mode == BNERV_IN_PLAIN || w.in_mode == BNERV_IN_AFFINE) || !(w.g_mode == BNERV_IN_PLAIN || w.g_mode == BNERV_IN_UNSHUFFLE)) return 1;
+    if (w.in_mode == BNERV_IN_AFFINE && !(w.scale && w.shift)) return 1;
+    if (w.ws_bytes < bnerv_conv_wgrad_ws_bytes(w.B, w.Cin, w.Cout, w.H, w.W, w.k)) return bnerv_set_error(BNERV_E_WS, "conv_wgrad_pair: weight-gradient workspace too small");
+    const Plan p = make_plan(w.B, w.Cin, w.Cout, w.H, w.W, w.k);
+    wa.slab = reinterpret_cast<float*>(w.ws);
+    wa.tiles_x = cdiv(w.W, TW);
+    wa.tiles_y = cdiv(w.H, TH);
+    wa.n_mgroups = p.n_mgroups;
+    wa.n_ngroups = p.n_ngroups;
+    wa.ncols = w.Cin * 9 + 1;
+    wa.vec = ((w.W % 4 == 0) && al(w.x) && al(w.g)) ? 1 : 0;
+    if (!wlean_ok(wa)) return 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = 1;
+#define BNERV_PAIR_CASE(E, I) if (c.ep_mode == E && w.in_mode == I) rc = launch_pair<E, I>(st, ka, wa);
+    BNERV_PAIR_CASE(BNERV_EP_DGELU_SAVED, BNERV_IN_AFFINE)
+    BNERV_PAIR_CASE(BNERV_EP_DSIN, BNERV_IN_AFFINE)
+    BNERV_PAIR_CASE(BNERV_EP_PLAIN, BNERV_IN_PLAIN)
+#undef BNERV_PAIR_CASE
+    if (rc != BNERV_OK) return rc;
+    bnerv_side_push(w.ctx, st, wa.slab, wlean_blocks(w), w.Cout * wa.ncols, wa.ncols, w.dw, w.db);     // the slab reduction rides on a later launch
     return BNERV_OK;
 }

@@ -62,6 +62,46 @@ def _wgrad(x, g, dw, db, *, B, Cin, Cout, H, W, k, in_mode, g_mode, g_s=1, gaux=
         L.ctx().keep.append(ws)
 
 
+def _wgrad_conv_pair(wg, cv):
+    """One weight gradient and one data gradient that read the same incoming gradient and do not depend on each other, as ONE launch
+    when the library takes the pair (include/bnerv.h bnerv_conv_wgrad_pair: 12-channel 3x3 layers), as the two usual launches
+    otherwise.  wg: keyword arguments of _wgrad (x, g, dw, db first), always deferred; cv: keyword arguments of _conv (x, w, bias, out
+    first) for an EP_DGELU_SAVED / EP_DSIN / EP_PLAIN epilogue.  Returns what _conv returns (the [B, 2, C] channel sums, or None)."""
+    lib = L.load()
+    x, g, dw, db = wg.pop("x"), wg.pop("g"), wg.pop("dw"), wg.pop("db")
+    nbytes = lib.bnerv_conv_wgrad_ws_bytes(wg["B"], wg["Cin"], wg["Cout"], wg["H"], wg["W"], wg["k"])
+    ws = _ws(nbytes, x.device)
+    wd = L.WgradDesc(L.ptr(x), L.ptr(g), L.ptr(wg.get("gaux")), L.ptr(wg.get("scale")), L.ptr(wg.get("shift")), L.ptr(dw), L.ptr(db), L.ptr(ws), nbytes,
+                     wg["B"], wg["Cin"], wg["Cout"], wg["H"], wg["W"], wg["k"], wg["in_mode"], wg["g_mode"], wg.get("g_s", 1), 1, L.ctx().handle)
+    cx, cw, cb, cout = cv.pop("x"), cv.pop("w"), cv.pop("bias"), cv.pop("out")
+    cd = L.ConvDesc(L.ptr(cx), L.ptr(cw), L.ptr(cb), L.ptr(cout), L.ptr(cv.get("out2")), L.ptr(cv.get("aux0")), L.ptr(cv.get("aux1")), L.ptr(cv.get("aux2")),
+                    L.ptr(cv.get("scale")), L.ptr(cv.get("shift")), None, cv["B"], cv["Cin"], cv["Cout"], cv["H"], cv["W"], cv["k"], cv["in_mode"], cv["ep_mode"],
+                    cv.get("in_s", 1), cv.get("out_s", 1), cv.get("transposed", 0), cw.shape[0], cw.shape[1], L.ctx().handle)
+    red = cv["ep_mode"] in (L.EP_DGELU, L.EP_DSIN, L.EP_DGELU_SAVED)
+    part = None
+    if red:
+        rows = lib.bnerv_conv_partial_rows(C.byref(cd))
+        part = torch.empty(rows, cv["B"], 2, cv["Cout"], dtype=torch.float32, device=cx.device)
+        cd.partial = part.data_ptr()
+    rc = lib.bnerv_conv_wgrad_pair(L.stream(), C.byref(cd), C.byref(wd))
+    if rc == 1:                                            # not a pair the launch takes: the two usual calls, weight gradient first
+        L.check(lib.bnerv_conv_wgrad(L.stream(), C.byref(wd)), "bnerv_conv_wgrad")
+        if not red and cv["ep_mode"] == L.EP_PLAIN:
+            nb = lib.bnerv_conv_splitk_ws_bytes(C.byref(cd))
+            if nb:
+                skw = _ws(nb, cx.device)
+                cd.partial = skw.data_ptr()
+        L.check(lib.bnerv_conv_igemm(L.stream(), C.byref(cd)), "bnerv_conv_igemm")
+    else:
+        L.check(rc, "bnerv_conv_wgrad_pair")
+    L.ctx().keep.append(ws)
+    if red:
+        st = torch.empty(cv["B"], 2, cv["Cout"], dtype=torch.float32, device=cx.device)
+        _reduce_slabs(part, rows, cv["B"] * 2 * cv["Cout"], st, defer=True)
+        return st
+    return None
+
+
 # Deferred slab reductions (include/bnerv.h, bnerv_reduce_slabs_deferred): inside one backward the reductions are queued in the
 # CONTEXT of the current stream (L.ctx()) and ride on the next lean conv / weight-gradient launch of that stream;
 # _flush_deferred() at the end of the backward launches the leftovers, so every tensor a backward returns is complete on the
@@ -354,17 +394,16 @@ def _tat_backward(dout, y0, c0, h, gp, s0, t0, s1, t1, w0, w1):
     dev = y0.device
     dw1 = torch.empty_like(w1); db1 = torch.empty(Cc, dtype=torch.float32, device=dev)
     # every slab reduction below is deferred: it rides on the next launch of this chain; the CALLER flushes the leftovers
-    _wgrad(h, dout, dw1, db1, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s1, shift=t1,
-           defer=True)
+    # (dW1 | d conv1) and (dW0 | d conv0): each pair reads one incoming gradient and is ONE launch where the library pairs them
     dv = torch.empty_like(y0)
-    st1 = _conv(dout, w1, None, dv, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU_SAVED, transposed=1,
-                aux0=gp, aux1=h, scale=s1, defer=True)
+    st1 = _wgrad_conv_pair(dict(x=h, g=dout, dw=dw1, db=db1, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s1, shift=t1),
+                           dict(x=dout, w=w1, bias=None, out=dv, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU_SAVED,
+                                transposed=1, aux0=gp, aux1=h, scale=s1))
     dw0 = torch.empty_like(w0); db0 = torch.empty(Cc, dtype=torch.float32, device=dev)
-    _wgrad(y0, dv, dw0, db0, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s0, shift=t0,
-           defer=True)
     du = torch.empty_like(y0)
-    st0 = _conv(dv, w0, None, du, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN, transposed=1,
-                aux0=y0, aux1=dout, aux2=c0, scale=s0, defer=True)
+    st0 = _wgrad_conv_pair(dict(x=y0, g=dv, dw=dw0, db=db0, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=s0, shift=t0),
+                           dict(x=dv, w=w0, bias=None, out=du, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN,
+                                transposed=1, aux0=y0, aux1=dout, aux2=c0, scale=s0))
     return du, st0[:, 0], st0[:, 1], st1[:, 0], st1[:, 1], dw0, db0, dw1, db1
 
 
@@ -426,11 +465,16 @@ class _SNeRVBlock(torch.autograd.Function):
         Ct, k = wu.shape[0], wu.shape[-1]
         dwu = torch.empty_like(wu)
         dbu = torch.empty(Ct, dtype=torch.float32, device=x.device) if ctx.has_bu else None
-        _wgrad(x, du, dwu, dbu, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s, defer=True)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and s == 1 and k == 3:      # (dW_block | d block conv): one launch where the library pairs them
             dx = torch.empty_like(x)
-            _conv(du, wu, None, dx, B=B, Cin=Ct, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1)
+            _wgrad_conv_pair(dict(x=x, g=du, dw=dwu, db=dbu, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=1),
+                             dict(x=du, w=wu, bias=None, out=dx, B=B, Cin=Ct, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_PLAIN, ep_mode=L.EP_PLAIN, transposed=1))
+        else:
+            _wgrad(x, du, dwu, dbu, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s, defer=True)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _conv(du, wu, None, dx, B=B, Cin=Ct, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1)
         _flush_deferred(block_end=True)
         m = ctx.mshape
         return dx, dwu, dbu, ds0.reshape(m), dt0.reshape(m), ds1.reshape(m), dt1.reshape(m), dw0, db0, dw1, db1, None

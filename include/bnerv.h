@@ -349,6 +349,16 @@ int bnerv_msssim(void* stream, const float* x, const float* y, float* out, void*
 size_t bnerv_psnr_ws_bytes(int B, int C, int H, int W);
 int bnerv_psnr(void* stream, const float* out, const float* gt, float* psnr, void* ws, size_t ws_bytes, int B, int C, int H, int W);
 
+/* Paired launch (ABI 5): the data gradient of a 3x3 convolution with at most 12 channels on both sides (plain input; epilogues
+ * EP_DGELU_SAVED / EP_DSIN / EP_PLAIN) and a weight gradient of the same image size that does not depend on it, in ONE grid.  Inside
+ * the backward of ResBlock_SFT / NeRVBlock (model_blocks.py:83-89, :34-39) autograd computes, for each of the three convolutions, the
+ * weight gradient and the input gradient from the SAME incoming gradient: (dW1 | d conv1), (dW0 | d conv0), (dW_block | d block conv);
+ * issued as two launches each half leaves most of the chip idle through its prologue and tail (one tile per block at 180x320).
+ * Both descriptors are exactly those bnerv_conv_wgrad / bnerv_conv_igemm would take (same workspaces; the weight gradient must be
+ * deferred -- defer_finish with a context -- and both must name the same context).  Returns BNERV_OK when the pair was launched, 1 when
+ * this pair is not one the launch takes (issue the two calls separately, weight gradient first), negative BNERV_E_* on error. */
+int bnerv_conv_wgrad_pair(void* stream, const bnerv_conv_desc* conv, const bnerv_wgrad_desc* wgrad);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused multi-tensor Adan step.  Replaces Adan.step -> _multi_tensor_adan (optimizer.py:125-235, :296-362), i.e. the
  * slot the reference reserves for the external `fused_adan` extension (optimizer.py:365-395).
