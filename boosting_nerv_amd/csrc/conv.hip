@@ -25,6 +25,9 @@
 int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec, int ksplit, int chunks_per_split);   // convbf.hip
 namespace bnerv_conv { struct KArgs; }
 int bnerv_conv4_try(hipStream_t st, bnerv_conv::KArgs& ka);   // conv4.hip: 1 = not that family's layer
+int bnerv_convs_try(hipStream_t st, const bnerv_conv_desc& d, int vec, int ksplit);   // convs.hip (low-resolution stages): 1 = not that family's layer
+bool bnerv_convs_shape_ok(const bnerv_conv_desc& d, int vec);
+int bnerv_convs_tiles(int H, int W);
 
 namespace {
 using namespace bnerv_conv;
@@ -1618,7 +1621,8 @@ extern "C" int bnerv_conv_partial_rows(const bnerv_conv_desc* dp) {
     if (!dp || dp->H <= 0 || dp->W <= 0) return 0;
     bnerv_conv_desc d = *dp;
     if (d.in_mode == BNERV_IN_UNSHUFFLE && d.in_s == 1) d.in_mode = BNERV_IN_PLAIN;
-    return cdiv(d.H, TH) * cdiv(d.W, TW);     // every kernel of this build uses 8x32 tiles; callers must still ask (it may change)
+    if (bnerv_convs_shape_ok(d, conv_vec_ok(d))) return bnerv_convs_tiles(d.H, d.W);      // the low-resolution family (convs.hip): 4x16 tiles
+    return cdiv(d.H, TH) * cdiv(d.W, TW);     // every other kernel of this build uses 8x32 tiles; callers must still ask
 }
 
 // Data gradient of a 1x1 head (reference: head_layer 1x1 C->3 + OutImg tanh, model_nerv.py:41,56-57): 3 -> C channels with the
@@ -1709,7 +1713,11 @@ extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
         BNERV_LAUNCH_CHECK("head1x1_dgrad");
         return BNERV_OK;
     }
-    // split-bf16 kernels (convbf.hip) first: the wide layers (with the same split-K plan: its slabs are reduced below), opt-in 12-channel ones
+    {   // the low-resolution stages (convs.hip) first: small images, <= 32 input channels
+        const int rs = bnerv_convs_try(st, d, ka.vec, ka.ksplit);
+        if (rs != 1) return rs;
+    }
+    // split-bf16 kernels (convbf.hip) next: the wide layers (with the same split-K plan: its slabs are reduced below), opt-in 12-channel ones
     int rc = bnerv_convbf_try(st, d, ka.vec, ka.ksplit, ka.chunks_per_split);
     if (rc == 1) {                                         // +1: not the split kernels' layer (negative values are real errors)
         ka.magic_tiles = ka.magic_tiles_x = 0;

@@ -1,0 +1,251 @@
+// convs.hip -- 3x3 stride-1 convolutions of the LOW-RESOLUTION stages (reference call sites: lib/quant_ops.py:39-41 through
+// model_blocks.py:74-89, :196-220: the 9x16 -> 45x80 -> 90x160 blocks of NeRV-boost, 15 / 30 channels).
+//
+// At 45x80 a layer is 58 MFLOP: ~1 us of matrix work.  The 8x32-pixel tiles of the persistent kernels (conv.hip, convbf.hip) cut such an
+// image into 18 tiles -- 36 blocks on 256 CUs, each a serial chain of [weight staging, tile staging, 270-deep K loop over 256 pixels,
+// epilogue] -- and the launch takes 13..19 us whatever the arithmetic.  Here the same implicit GEMM (v_mfma_f32_16x16x4_f32, exact f32)
+// runs on 4x16-pixel tiles x 16 output channels, ONE tile per block and no persistence:
+//   * 4 x more blocks per image and a K loop 4 x shorter per wave (each wave owns ONE 16-pixel row = one M tile);
+//   * the weights of the block's 16 output channels are one contiguous slice of the OIHW tensor (forward) or 16-row segments of it
+//     (data gradient): loaded coalesced into LDS as they are, the B fragment of (tap, channel quad) is one ds_read_b32 at a
+//     per-lane base + immediate -- no gather, no fragment re-layout;
+//   * the haloed input tile (6 x 24 floats per channel, all channels at once: Cin <= 32) enters through raw buffer loads with the
+//     affine prologue applied on the way; zero padding through out-of-range offsets;
+//   * epilogues straight from the accumulators (a D fragment = 4 consecutive pixels of one output channel per lane): bias, sin / cos
+//     (stride-1 or PixelShuffle(2 / 3 / 5) scatter), gelu pair, residual, plain, dGELU(saved) and dSIN with their per-channel sums.
+// Scope: k = 3, Cin <= 32, any Cout (16 per block), H * W <= 16384, float4-aligned rows.
+#include "common.h"
+#include "sidejob.h"
+#include "conv_common.h"
+
+namespace {
+using namespace bnerv_conv;
+
+constexpr int STH = 4, STW = 16;           // tile: 4 rows x 16 px; wave w owns row w
+constexpr int SROWS = STH + 2;             // haloed rows
+constexpr int SXOFF = 4;                   // left margin (aligned float4 segments)
+constexpr int SRS = STW + 2 * SXOFF;       // 24 floats per LDS row
+constexpr int SSEGS = SRS / 4;             // 6 float4 per row
+constexpr int SPLANE = SROWS * SRS + 4;    // 148: == 20 (mod 32) -> the four k-lanes of an A fragment read spread over the banks
+constexpr int SCOL0 = SXOFF - 1;
+constexpr int SMAXC = 32;                  // input channels staged at once
+
+struct SArgs {
+    bnerv_conv_desc d;
+    int tiles_x, tiles_y;
+};
+
+template <int EP>
+__device__ __forceinline__ float s_ep(float v, float bias, float* o2) {
+    if constexpr (EP == BNERV_EP_BIAS) return v + bias;
+    if constexpr (EP == BNERV_EP_BIAS_SIN) { float sv, cv; sincos_f(v + bias, &sv, &cv); *o2 = cv; return sv; }
+    if constexpr (EP == BNERV_EP_BIAS_GELU) { float h; gelu_pair_f(v + bias, &h, o2); return h; }
+    return v;
+}
+
+// NQ = ceil(Cin / 4) rounded to 4 or 8 (16 or 32 staged channels)
+template <int IN, int EP, int NQ>
+__global__ __launch_bounds__(256, 4) void conv_small_kernel(const SArgs sa) {
+    constexpr int NCH = NQ * 4;
+    constexpr int NSLOT = NCH * SROWS * SSEGS;                 // float4 slots of the input tile
+    constexpr int NPRE = (NSLOT + 255) / 256;
+    constexpr bool AFF = (IN == BNERV_IN_AFFINE);
+    constexpr bool RED = (EP == BNERV_EP_DSIN || EP == BNERV_EP_DGELU_SAVED);
+    const bnerv_conv_desc& d = sa.d;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;                                        // [NCH][SPLANE]
+    float* s_w = smem + NCH * SPLANE;                          // raw weight slice: forward [16 co][Cin * 9], transposed [Cin][16 co][9]
+    float* s_red = s_w + 16 * SMAXC * 9;                       // [4 waves][2][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
+    const int tile = blockIdx.x, b = blockIdx.z, co_base = blockIdx.y * 16;
+    const int ty0 = (tile / sa.tiles_x) * STH, tx0 = (tile % sa.tiles_x) * STW;
+
+    // ---- input tile: raw buffer loads, all in flight, affine applied on the way into LDS (zero padding AFTER the affine)
+    const unsigned shift = (unsigned)((W + SXOFF) * 4);
+    const unsigned in_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, in_bytes);
+    const unsigned sb = (unsigned)((((b * Cin) * H + ty0) * W + tx0) * 4);
+    f32x4 ra[NPRE];
+    float sc[NPRE], sh[NPRE];
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        const int sidx = tid + k * 256;
+        const int c = sidx / (SROWS * SSEGS), rem = sidx - c * (SROWS * SSEGS), r = rem / SSEGS, sg = rem - r * SSEGS;
+        const int gy = ty0 + r - 1, gx = tx0 + 4 * sg - SXOFF;
+        const bool ok = sidx < NSLOT && c < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        ra[k] = bload(rx, ok ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB, sb);
+        sc[k] = 1.f; sh[k] = 0.f;
+        if constexpr (AFF) { if (ok) { sc[k] = 1.0f + d.scale[b * Cin + c]; sh[k] = d.shift[b * Cin + c]; } else sc[k] = 0.f; }
+    }
+    // ---- weight slice of this block's 16 output channels, as it lies in memory (coalesced), zero beyond Cout / Cin
+    {
+        const int ncopy = 16 * Cin * 9;
+        if (!d.transposed) {
+            // W(co, ci, t) = w[co][ci][t]: rows co_base .. co_base + 15 are contiguous
+            const float* src = d.w + (size_t)co_base * Cin * 9;
+            const int nvalid = min(16, Cout - co_base) * Cin * 9;
+            for (int i = tid; i < ncopy; i += 256) s_w[i] = i < nvalid ? src[i] : 0.f;
+        } else {
+            // W(co, ci, t) = w[ci][co][8 - t] (w is [wCo = Cin][wCi = Cout][9]): per ci a segment of 16 x 9 floats; kept as [ci][16][9]
+            for (int i = tid; i < ncopy; i += 256) {
+                const int ci = i / 144, rem = i - ci * 144, col = rem / 9;
+                s_w[i] = (co_base + col < Cout) ? d.w[((size_t)ci * d.wCi + co_base) * 9 + rem] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        const int sidx = tid + k * 256;
+        if (sidx < NSLOT) {
+            const int c = sidx / (SROWS * SSEGS), rem = sidx - c * (SROWS * SSEGS), r = rem / SSEGS, sg = rem - r * SSEGS;
+            f32x4 v = ra[k];
+            if constexpr (AFF) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[k] + sh[k];
+            }
+            *reinterpret_cast<f32x4*>(s_in + c * SPLANE + r * SRS + 4 * sg) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- K loop: A = pixel li of the wave's row, channel 4q + kq ; B = W(co_base + li, 4q + kq, tap) from the raw slice
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* a_base = s_in + kq * SPLANE + wave * SRS + li + SCOL0;
+    const float* b_base = d.transposed ? s_w + (kq * 16 + li) * 9 : s_w + li * Cin * 9 + kq * 9;
+    const int b_qstep = d.transposed ? 4 * 144 : 36;           // + 4 input channels
+    const bool ci_tail = (Cin & 3) != 0;                       // the last quad reads beyond Cin: those weights must count as zero
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (4 * q < Cin) {                                     // block-uniform
+            const bool bvalid = !ci_tail || (4 * q + kq < Cin);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float av = a_base[q * 4 * SPLANE + (t / 3) * SRS + (t % 3)];
+                float bv = b_base[q * b_qstep + (d.transposed ? 8 - t : t)];
+                bv = bvalid ? bv : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue from the accumulator: lane (li, kq) = output channel co_base + li, pixels (row wave, columns 4 kq .. 4 kq + 3)
+    const int co = co_base + li, gy = ty0 + wave, gx = tx0 + 4 * kq;
+    const bool ok = co < Cout && gy < H && gx < W;
+    const float bias = (EP != BNERV_EP_PLAIN && !RED && d.bias && co < Cout) ? d.bias[co] : 0.f;
+    const size_t o = (((size_t)b * Cout + co) * H + gy) * (size_t)W + gx;
+    if constexpr (RED) {
+        float ps = 0.f, pt = 0.f;
+        if (ok) {
+            const float scl = 1.0f + d.scale[b * Cout + co];
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(d.aux0 + o), a1 = *reinterpret_cast<const f32x4*>(d.aux1 + o);
+            f32x4 a2 = {1.f, 1.f, 1.f, 1.f}, r;
+            if constexpr (EP == BNERV_EP_DSIN) { if (d.aux2) a2 = *reinterpret_cast<const f32x4*>(d.aux2 + o); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[e];
+                if constexpr (EP == BNERV_EP_DGELU_SAVED) { r[e] = v * scl * a0[e]; ps = fmaf(v, a1[e], ps); }
+                else { r[e] = (a1[e] + v * scl) * a2[e]; ps = fmaf(v, a0[e], ps); }
+                pt += v;
+            }
+            *reinterpret_cast<f32x4*>(d.out + o) = r;
+        }
+        ps += __shfl_xor(ps, 16, 64); pt += __shfl_xor(pt, 16, 64);
+        ps += __shfl_xor(ps, 32, 64); pt += __shfl_xor(pt, 32, 64);
+        if (lane < 16) { s_red[(wave * 2 + 0) * 16 + lane] = ps; s_red[(wave * 2 + 1) * 16 + lane] = pt; }
+        __syncthreads();
+        if (tid < 32) {
+            const int qq = tid >> 4, c = tid & 15;
+            const float s = ((s_red[(0 * 2 + qq) * 16 + c] + s_red[(1 * 2 + qq) * 16 + c]) + s_red[(2 * 2 + qq) * 16 + c]) + s_red[(3 * 2 + qq) * 16 + c];
+            if (co_base + c < Cout) d.partial[(((size_t)tile * d.B + b) * 2 + qq) * Cout + co_base + c] = s;
+        }
+    } else if (d.out_s == 1) {
+        if (ok) {
+            f32x4 r, r2;
+            if constexpr (EP == BNERV_EP_BIAS_RES) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(d.aux0 + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = acc[e] + bias + a0[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float c2 = 0.f; r[e] = s_ep<EP>(acc[e], bias, &c2); r2[e] = c2; }
+            }
+            *reinterpret_cast<f32x4*>(d.out + o) = r;
+            if constexpr (EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) { if (d.out2) *reinterpret_cast<f32x4*>(d.out2 + o) = r2; }
+        }
+    } else {
+        // PixelShuffle(s): conv-space channel co -> (c, i, j); pixel (gy, gx + e) -> (gy * s + i, (gx + e) * s + j)
+        if (ok) {
+            const int s = d.out_s, s2 = s * s, c = co / s2, rem = co - c * s2, i = rem / s, j = rem - i * s;
+            const int Cf = Cout / s2, HF = H * s, WF = W * s;
+            const size_t rowo = (((size_t)b * Cf + c) * HF + (size_t)(gy * s + i)) * (size_t)WF;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (gx + e < W) {
+                    float c2 = 0.f;
+                    const float r = s_ep<EP>(acc[e], bias, &c2);
+                    const size_t oo = rowo + (size_t)((gx + e) * s + j);
+                    d.out[oo] = r;
+                    if constexpr (EP == BNERV_EP_BIAS_SIN) { if (d.out2) d.out2[oo] = c2; }
+                }
+            }
+        }
+    }
+}
+
+template <int IN, int EP, int NQ>
+int launch_small(hipStream_t st, const SArgs& sa) {
+    const bnerv_conv_desc& d = sa.d;
+    const size_t lds = ((size_t)NQ * 4 * SPLANE + (size_t)16 * SMAXC * 9 + 128) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_kernel<IN, EP, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv_small_kernel<IN, EP, NQ>), dim3(sa.tiles_x * sa.tiles_y, cdiv(d.Cout, 16), d.B), dim3(256), lds, st, sa);
+    BNERV_LAUNCH_CHECK("conv_small");
+    return BNERV_OK;
+}
+
+template <int IN, int EP>
+int launch_small_nq(hipStream_t st, const SArgs& sa) {
+    return sa.d.Cin <= 16 ? launch_small<IN, EP, 4>(st, sa) : launch_small<IN, EP, 8>(st, sa);
+}
+
+}  // namespace
+
+// shapes of this family: small images whose 8x32 tiling leaves the chip idle (the threshold keeps 180x320 and above on the persistent kernels)
+bool bnerv_convs_shape_ok(const bnerv_conv_desc& d, int vec) {
+    { const char* e = getenv("BNERV_SMALL"); if (e && e[0] == '0') return false; }      // A/B switch, read per call (tests reach the other families with it)
+    if (!(vec && d.k == 3 && d.Cin <= SMAXC && d.in_s == 1 && (size_t)d.H * d.W <= 16384 && d.B <= 65535 && cdiv(d.Cout, 16) <= 65535)) return false;
+    if (d.Cin <= 12 && d.Cout <= 12) return false;                 // the 12-channel layers have their own family (conv4.hip)
+    if (!(d.in_mode == BNERV_IN_PLAIN || d.in_mode == BNERV_IN_AFFINE)) return false;
+    const int e = d.ep_mode;
+    if (d.out_s != 1) return d.in_mode == BNERV_IN_PLAIN && (e == BNERV_EP_BIAS || e == BNERV_EP_BIAS_SIN) && (d.out_s == 2 || d.out_s == 3 || d.out_s == 5);
+    if (d.in_mode == BNERV_IN_AFFINE) return e == BNERV_EP_BIAS || e == BNERV_EP_BIAS_GELU || e == BNERV_EP_BIAS_RES;
+    return e == BNERV_EP_BIAS || e == BNERV_EP_BIAS_SIN || e == BNERV_EP_PLAIN || e == BNERV_EP_DGELU_SAVED || e == BNERV_EP_DSIN;
+}
+int bnerv_convs_tiles(int H, int W) { return cdiv(H, STH) * cdiv(W, STW); }
+
+// 1: not this family's layer; BNERV_OK / negative BNERV_E_*: handled
+int bnerv_convs_try(hipStream_t st, const bnerv_conv_desc& d, int vec, int ksplit) {
+    if (ksplit > 1 || !bnerv_convs_shape_ok(d, vec)) return 1;
+    SArgs sa;
+    sa.d = d;
+    sa.tiles_x = cdiv(d.W, STW);
+    sa.tiles_y = cdiv(d.H, STH);
+    const int in = d.in_mode, ep = d.ep_mode;
+#define BNERV_CASE(I, E) if (in == I && ep == E) return launch_small_nq<I, E>(st, sa);
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_BIAS_SIN)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_PLAIN)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DGELU_SAVED)
+    BNERV_CASE(BNERV_IN_PLAIN, BNERV_EP_DSIN)
+    BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS)
+    BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_GELU)
+    BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_RES)
+#undef BNERV_CASE
+    return 1;
+}

@@ -129,6 +129,7 @@ def test_decode_graph_refresh_after_weight_change(monkeypatch):
     refresh() re-prepares them and the replayed forward equals the eager one again, bit for bit."""
     from boosting_nerv_amd.engine import DecodeGraph
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    monkeypatch.setenv("BNERV_SMALL", "0")                 # (keep the tiny model's layers on the split kernels: the test is about their weight-fragment plan)
     torch.manual_seed(3)
     model = _build("tiny_nerv", configs.tiny_nerv()).to(DEV).eval()
     norm = torch.tensor([3 / 7], dtype=torch.float64, device=DEV)
@@ -396,6 +397,7 @@ def test_weight_fragment_plan_changes_no_bit(monkeypatch):
     from boosting_nerv_amd.optimizer import Adan
     from boosting_nerv_amd.synth import SyntheticVideo
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    monkeypatch.setenv("BNERV_SMALL", "0")                 # (keep the tiny model's layers on the split kernels: the test is about their weight-fragment plan)
     vid = SyntheticVideo(4, 180, 320)
     fd = torch.stack([vid.frame(i) for i in range(4)]).to(DEV)
     nd = torch.tensor([(i + 1) / 4 for i in range(4)], dtype=torch.float64).to(DEV)

@@ -571,6 +571,7 @@ def test_wide_split_conv_kernel_tat_block(ops, shape, min_items, monkeypatch):
     bf16x6 products with f32 accumulation) on the TAT block -- its four launches cover the affine -> gelu-pair, affine -> residual,
     dGELU-saved and dSIN modes -- against the oracle, with the tile-count threshold lowered so that small shapes reach it."""
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    monkeypatch.setenv("BNERV_SMALL", "0")                 # (small images would go to the low-resolution family, convs.hip: these tests are about the split kernels)
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_ITEMS", min_items)
     x0, mods, w0, b0, w1, b1, g = _tat_inputs(*shape, seed=7)
     ref = _tat_ref(x0, mods, w0, b0, w1, b1)
@@ -590,6 +591,7 @@ def test_wide_split_conv_kernel_plain(ops, case, min_items, monkeypatch):
     """Same kernel through conv2d_ps (plain -> bias forward, plain data gradient) and the sin block conv, incl. Cout <= 16 with several
     K chunks and Cin <= 16 with several cout tiles."""
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    monkeypatch.setenv("BNERV_SMALL", "0")                 # (small images would go to the low-resolution family, convs.hip: these tests are about the split kernels)
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_ITEMS", min_items)
     B, Cin, Ct, H, W = case
     g = torch.Generator().manual_seed(sum(case))
@@ -612,6 +614,7 @@ def test_wide_split_conv_kernel_upconv_ps2(ops, case, min_items, monkeypatch):
     """Up-conv + PixelShuffle(2) through the wide split kernel: forward with the pair-up epilogue (plain and sin/cos), data gradient
     through the unshuffle(2) prologue; whole SNeRV block as well (its up-conv, TAT convs and every gradient)."""
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    monkeypatch.setenv("BNERV_SMALL", "0")                 # (small images would go to the low-resolution family, convs.hip: these tests are about the split kernels)
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_ITEMS", min_items)
     B, Cin, Ct, H, W = case
     g = torch.Generator().manual_seed(sum(case))
@@ -646,6 +649,7 @@ def test_wide_split_conv_kernel_upconv_ps35(ops, case, min_items, monkeypatch):
     """Up-conv + PixelShuffle(3 / 5) forward through the wide split kernel's scatter-store epilogue (plain and sin / cos), gradients
     through the kernels that own them."""
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+    monkeypatch.setenv("BNERV_SMALL", "0")                 # (small images would go to the low-resolution family, convs.hip: these tests are about the split kernels)
     monkeypatch.setenv("BNERV_SPLIT_WIDE_MIN_ITEMS", min_items)
     B, Cin, Ct, H, W, s = case
     g = torch.Generator().manual_seed(sum(case))

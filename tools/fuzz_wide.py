@@ -4,6 +4,7 @@ dGELU / dSIN epilogues with their per-channel sums).  usage: python tools/fuzz_w
 (checker tool: torch fp64 is the reference here, not part of the product)"""
 import math, os, random, sys, torch
 os.environ.setdefault("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+os.environ.setdefault("BNERV_SMALL", "0")          # keep small test images on the split kernels (not the low-resolution family)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch.nn.functional as F
 from boosting_nerv_amd import ops

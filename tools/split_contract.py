@@ -8,6 +8,7 @@ tests/test_gpu_ops.py runs it both ways, so a silent downgrade of the arithmetic
 usage: python tools/split_contract.py        (BNERV_SPLIT_WIDE selects the mode under test; checker tool, torch fp64 is the reference)"""
 import math, os, sys, torch
 os.environ.setdefault("BNERV_SPLIT_WIDE_MIN_TILES", "1")
+os.environ.setdefault("BNERV_SMALL", "0")          # keep small test images on the split kernels (not the low-resolution family)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch.nn.functional as F
 from boosting_nerv_amd import ops, _lib as L
