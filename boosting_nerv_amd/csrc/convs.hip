@@ -80,21 +80,30 @@ __global__ __launch_bounds__(256, 4) void conv_small_kernel(const SArgs sa) {
         sc[k] = 1.f; sh[k] = 0.f;
         if constexpr (AFF) { if (ok) { sc[k] = 1.0f + d.scale[b * Cin + c]; sh[k] = d.shift[b * Cin + c]; } else sc[k] = 0.f; }
     }
-    // ---- weight slice of this block's 16 output channels, as it lies in memory (coalesced), zero beyond Cout / Cin
+    // ---- weight slice of this block's 16 output channels, as it lies in memory (coalesced), zero beyond Cout / Cin.  Every load is
+    //      issued before the first store (a loop of load -> store pairs is one L2 round trip per iteration: 17 of them were most of
+    //      the launch).
     {
+        constexpr int NWL = (16 * NCH * 9 + 255) / 256;        // dwords per thread (18 at 32 channels)
         const int ncopy = 16 * Cin * 9;
+        float wv[NWL];
         if (!d.transposed) {
             // W(co, ci, t) = w[co][ci][t]: rows co_base .. co_base + 15 are contiguous
             const float* src = d.w + (size_t)co_base * Cin * 9;
             const int nvalid = min(16, Cout - co_base) * Cin * 9;
-            for (int i = tid; i < ncopy; i += 256) s_w[i] = i < nvalid ? src[i] : 0.f;
+#pragma unroll
+            for (int u = 0; u < NWL; ++u) { const int i = tid + u * 256; wv[u] = i < nvalid ? src[i] : 0.f; }
         } else {
             // W(co, ci, t) = w[ci][co][8 - t] (w is [wCo = Cin][wCi = Cout][9]): per ci a segment of 16 x 9 floats; kept as [ci][16][9]
-            for (int i = tid; i < ncopy; i += 256) {
+#pragma unroll
+            for (int u = 0; u < NWL; ++u) {
+                const int i = tid + u * 256;
                 const int ci = i / 144, rem = i - ci * 144, col = rem / 9;
-                s_w[i] = (co_base + col < Cout) ? d.w[((size_t)ci * d.wCi + co_base) * 9 + rem] : 0.f;
+                wv[u] = (i < ncopy && co_base + col < Cout) ? d.w[((size_t)ci * d.wCi + co_base) * 9 + rem] : 0.f;
             }
         }
+#pragma unroll
+        for (int u = 0; u < NWL; ++u) { const int i = tid + u * 256; if (i < ncopy) s_w[i] = wv[u]; }
     }
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
@@ -175,6 +184,28 @@ __global__ __launch_bounds__(256, 4) void conv_small_kernel(const SArgs sa) {
             *reinterpret_cast<f32x4*>(d.out + o) = r;
             if constexpr (EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) { if (d.out2) *reinterpret_cast<f32x4*>(d.out2 + o) = r2; }
         }
+    } else if (d.out_s == 2 && (Cout & 3) == 0) {
+        // PixelShuffle(2): lanes li = 4 c + 2 i + j.  Lanes j = 0 / 1 (neighbours) hold the even / odd output columns of the same row:
+        // they swap halves so that each stores 4 CONSECUTIVE output pixels -- lane j = 0 the columns 2 gx .. 2 gx + 3, lane j = 1 the next four.
+        float c2v[4], rv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { c2v[e] = 0.f; rv[e] = s_ep<EP>(acc[e], bias, &c2v[e]); }
+        const int j = li & 1;
+        f32x4 o1, o2;
+        {
+            float pr[4], pc[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pr[e] = __shfl_xor(rv[e], 1, 64); pc[e] = __shfl_xor(c2v[e], 1, 64); }
+            o1 = j ? f32x4{pr[2], rv[2], pr[3], rv[3]} : f32x4{rv[0], pr[0], rv[1], pr[1]};
+            o2 = j ? f32x4{pc[2], c2v[2], pc[3], c2v[3]} : f32x4{c2v[0], pc[0], c2v[1], pc[1]};
+        }
+        if (ok) {
+            const int c = co >> 2, i = (co >> 1) & 1;
+            const int Cf = Cout >> 2, HF = 2 * H, WF = 2 * W;
+            const size_t oo = (((size_t)b * Cf + c) * HF + (size_t)(2 * gy + i)) * (size_t)WF + (size_t)(2 * gx + 4 * j);
+            *reinterpret_cast<f32x4*>(d.out + oo) = o1;
+            if constexpr (EP == BNERV_EP_BIAS_SIN) { if (d.out2) *reinterpret_cast<f32x4*>(d.out2 + oo) = o2; }
+        }
     } else {
         // PixelShuffle(s): conv-space channel co -> (c, i, j); pixel (gy, gx + e) -> (gy * s + i, (gx + e) * s + j)
         if (ok) {
@@ -219,7 +250,9 @@ int launch_small_nq(hipStream_t st, const SArgs& sa) {
 // shapes of this family: small images whose 8x32 tiling leaves the chip idle (the threshold keeps 180x320 and above on the persistent kernels)
 bool bnerv_convs_shape_ok(const bnerv_conv_desc& d, int vec) {
     { const char* e = getenv("BNERV_SMALL"); if (e && e[0] == '0') return false; }      // A/B switch, read per call (tests reach the other families with it)
-    if (!(vec && d.k == 3 && d.Cin <= SMAXC && d.in_s == 1 && (size_t)d.H * d.W <= 16384 && d.B <= 65535 && cdiv(d.Cout, 16) <= 65535)) return false;
+    // small images; an up-conv (several cout groups per tile) pays up to 180x320, where the persistent split kernel still runs one tile per block
+    const size_t max_px = (d.out_s == 2 && d.Cout >= 32) ? 65536 : 16384;
+    if (!(vec && d.k == 3 && d.Cin <= SMAXC && d.in_s == 1 && (size_t)d.H * d.W <= max_px && d.B <= 65535 && cdiv(d.Cout, 16) <= 65535)) return false;
     if (d.Cin <= 12 && d.Cout <= 12) return false;                 // the 12-channel layers have their own family (conv4.hip)
     if (!(d.in_mode == BNERV_IN_PLAIN || d.in_mode == BNERV_IN_AFFINE)) return false;
     const int e = d.ep_mode;
