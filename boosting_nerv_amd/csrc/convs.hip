@@ -13,7 +13,8 @@
 //     affine prologue applied on the way; zero padding through out-of-range offsets;
 //   * epilogues straight from the accumulators (a D fragment = 4 consecutive pixels of one output channel per lane): bias, sin / cos
 //     (stride-1 or PixelShuffle(2 / 3 / 5) scatter), gelu pair, residual, plain, dGELU(saved) and dSIN with their per-channel sums.
-// Scope: k = 3, Cin <= 32, any Cout (16 per block), H * W <= 16384, float4-aligned rows.
+// Scope: k = 3, Cin <= 32 (64 for the unshuffle(2) prologue: the data gradient of a PixelShuffle(2) up-conv), any Cout (16 per block),
+// H * W <= 16384 (65536 for the up-convs and their data gradients), float4-aligned rows.
 #include "common.h"
 #include "sidejob.h"
 #include "conv_common.h"
@@ -28,7 +29,7 @@ constexpr int SRS = STW + 2 * SXOFF;       // 24 floats per LDS row
 constexpr int SSEGS = SRS / 4;             // 6 float4 per row
 constexpr int SPLANE = SROWS * SRS + 4;    // 148: == 20 (mod 32) -> the four k-lanes of an A fragment read spread over the banks
 constexpr int SCOL0 = SXOFF - 1;
-constexpr int SMAXC = 32;                  // input channels staged at once
+constexpr int SMAXC = 64;                  // input channels staged at once (32 for the plain / affine modes, 64 for the unshuffled gradient of an up-conv)
 
 struct SArgs {
     bnerv_conv_desc d;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256, 4) void conv_small_kernel(const SArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;                                        // [NCH][SPLANE]
     float* s_w = smem + NCH * SPLANE;                          // raw weight slice: forward [16 co][Cin * 9], transposed [Cin][16 co][9]
-    float* s_red = s_w + 16 * SMAXC * 9;                       // [4 waves][2][16]
+    float* s_red = s_w + 16 * NCH * 9;                         // [4 waves][2][16]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
@@ -68,17 +69,36 @@ __global__ __launch_bounds__(256, 4) void conv_small_kernel(const SArgs sa) {
     const unsigned in_bytes = (unsigned)((size_t)d.B * Cin * H * W * 4) + shift;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, shift, in_bytes);
     const unsigned sb = (unsigned)((((b * Cin) * H + ty0) * W + tx0) * 4);
-    f32x4 ra[NPRE];
-    float sc[NPRE], sh[NPRE];
+    constexpr bool UNS = (IN == BNERV_IN_UNSHUFFLE);           // x is stored pixel-shuffled (x2): [B][Cin / 4][2H][2W]
+    constexpr int NSLOT_U = (NCH / 2) * SROWS * SSEGS;         // unshuffle: a slot = channel PAIR (cf, i, j = 0 / 1) x row x segment, two float4 of the source row
+    constexpr int NPRE_U = (NSLOT_U + 255) / 256;
+    f32x4 ra[UNS ? NPRE_U : NPRE], rb[UNS ? NPRE_U : 1];
+    float sc[UNS ? 1 : NPRE], sh[UNS ? 1 : NPRE];
+    if constexpr (UNS) {
+        const unsigned ub = (unsigned)((size_t)d.B * Cin * H * W * 4);
+        const __amdgpu_buffer_rsrc_t ru = make_rsrc(d.x, 0, ub);
+        const unsigned sbu = (unsigned)((size_t)b * Cin * H * W * 4);
 #pragma unroll
-    for (int k = 0; k < NPRE; ++k) {
-        const int sidx = tid + k * 256;
-        const int c = sidx / (SROWS * SSEGS), rem = sidx - c * (SROWS * SSEGS), r = rem / SSEGS, sg = rem - r * SSEGS;
-        const int gy = ty0 + r - 1, gx = tx0 + 4 * sg - SXOFF;
-        const bool ok = sidx < NSLOT && c < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        ra[k] = bload(rx, ok ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB, sb);
-        sc[k] = 1.f; sh[k] = 0.f;
-        if constexpr (AFF) { if (ok) { sc[k] = 1.0f + d.scale[b * Cin + c]; sh[k] = d.shift[b * Cin + c]; } else sc[k] = 0.f; }
+        for (int k = 0; k < NPRE_U; ++k) {
+            const int sidx = tid + k * 256;
+            const int p = sidx / (SROWS * SSEGS), rem = sidx - p * (SROWS * SSEGS), r = rem / SSEGS, sg = rem - r * SSEGS;
+            const int gy = ty0 + r - 1, gx = tx0 + 4 * sg - SXOFF;
+            const bool ok = sidx < NSLOT_U && 2 * p < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const unsigned off = ok ? (unsigned)((((p >> 1) * 2 * H + 2 * gy + (p & 1)) * (2 * W) + 2 * gx) * 4) : OOB;
+            ra[k] = bload(ru, off, sbu);
+            rb[k] = bload(ru, ok ? off + 16u : OOB, sbu);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int sidx = tid + k * 256;
+            const int c = sidx / (SROWS * SSEGS), rem = sidx - c * (SROWS * SSEGS), r = rem / SSEGS, sg = rem - r * SSEGS;
+            const int gy = ty0 + r - 1, gx = tx0 + 4 * sg - SXOFF;
+            const bool ok = sidx < NSLOT && c < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            ra[k] = bload(rx, ok ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB, sb);
+            sc[k] = 1.f; sh[k] = 0.f;
+            if constexpr (AFF) { if (ok) { sc[k] = 1.0f + d.scale[b * Cin + c]; sh[k] = d.shift[b * Cin + c]; } else sc[k] = 0.f; }
+        }
     }
     // ---- weight slice of this block's 16 output channels, as it lies in memory (coalesced), zero beyond Cout / Cin.  Every load is
     //      issued before the first store (a loop of load -> store pairs is one L2 round trip per iteration: 17 of them were most of
@@ -105,17 +125,31 @@ __global__ __launch_bounds__(256, 4) void conv_small_kernel(const SArgs sa) {
 #pragma unroll
         for (int u = 0; u < NWL; ++u) { const int i = tid + u * 256; if (i < ncopy) s_w[i] = wv[u]; }
     }
+    if constexpr (UNS) {
 #pragma unroll
-    for (int k = 0; k < NPRE; ++k) {
-        const int sidx = tid + k * 256;
-        if (sidx < NSLOT) {
-            const int c = sidx / (SROWS * SSEGS), rem = sidx - c * (SROWS * SSEGS), r = rem / SSEGS, sg = rem - r * SSEGS;
-            f32x4 v = ra[k];
-            if constexpr (AFF) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[k] + sh[k];
+        for (int k = 0; k < NPRE_U; ++k) {
+            const int sidx = tid + k * 256;
+            if (sidx < NSLOT_U) {
+                const int p = sidx / (SROWS * SSEGS), rem = sidx - p * (SROWS * SSEGS), r = rem / SSEGS, sg = rem - r * SSEGS;
+                const f32x4 va = ra[k], vb = rb[k];
+                float* dst = s_in + (2 * p) * SPLANE + r * SRS + 4 * sg;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{va[0], va[2], vb[0], vb[2]};              // j = 0: even source columns
+                *reinterpret_cast<f32x4*>(dst + SPLANE) = f32x4{va[1], va[3], vb[1], vb[3]};     // j = 1: odd source columns
             }
-            *reinterpret_cast<f32x4*>(s_in + c * SPLANE + r * SRS + 4 * sg) = v;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int sidx = tid + k * 256;
+            if (sidx < NSLOT) {
+                const int c = sidx / (SROWS * SSEGS), rem = sidx - c * (SROWS * SSEGS), r = rem / SSEGS, sg = rem - r * SSEGS;
+                f32x4 v = ra[k];
+                if constexpr (AFF) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[k] + sh[k];
+                }
+                *reinterpret_cast<f32x4*>(s_in + c * SPLANE + r * SRS + 4 * sg) = v;
+            }
         }
     }
     __syncthreads();
@@ -229,7 +263,7 @@ __global__ __launch_bounds__(256, 4) void conv_small_kernel(const SArgs sa) {
 template <int IN, int EP, int NQ>
 int launch_small(hipStream_t st, const SArgs& sa) {
     const bnerv_conv_desc& d = sa.d;
-    const size_t lds = ((size_t)NQ * 4 * SPLANE + (size_t)16 * SMAXC * 9 + 128) * sizeof(float);
+    const size_t lds = ((size_t)NQ * 4 * SPLANE + (size_t)16 * NQ * 4 * 9 + 128) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_kernel<IN, EP, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -242,7 +276,8 @@ int launch_small(hipStream_t st, const SArgs& sa) {
 
 template <int IN, int EP>
 int launch_small_nq(hipStream_t st, const SArgs& sa) {
-    return sa.d.Cin <= 16 ? launch_small<IN, EP, 4>(st, sa) : launch_small<IN, EP, 8>(st, sa);
+    if constexpr (IN == BNERV_IN_UNSHUFFLE) return sa.d.Cin <= 32 ? launch_small<IN, EP, 8>(st, sa) : launch_small<IN, EP, 16>(st, sa);
+    else return sa.d.Cin <= 16 ? launch_small<IN, EP, 4>(st, sa) : launch_small<IN, EP, 8>(st, sa);
 }
 
 }  // namespace
@@ -251,8 +286,11 @@ int launch_small_nq(hipStream_t st, const SArgs& sa) {
 bool bnerv_convs_shape_ok(const bnerv_conv_desc& d, int vec) {
     { const char* e = getenv("BNERV_SMALL"); if (e && e[0] == '0') return false; }      // A/B switch, read per call (tests reach the other families with it)
     // small images; an up-conv (several cout groups per tile) pays up to 180x320, where the persistent split kernel still runs one tile per block
-    const size_t max_px = (d.out_s == 2 && d.Cout >= 32) ? 65536 : 16384;
-    if (!(vec && d.k == 3 && d.Cin <= SMAXC && d.in_s == 1 && (size_t)d.H * d.W <= max_px && d.B <= 65535 && cdiv(d.Cout, 16) <= 65535)) return false;
+    const bool uns = d.in_mode == BNERV_IN_UNSHUFFLE;          // the data gradient of a PixelShuffle(2) up-conv: its input is the shuffled gradient
+    const size_t max_px = ((d.out_s == 2 && d.Cout >= 32) || uns) ? 65536 : 16384;
+    if (!(vec && d.k == 3 && d.Cin <= (uns ? 64 : 32) && (size_t)d.H * d.W <= max_px && d.B <= 65535 && cdiv(d.Cout, 16) <= 65535)) return false;
+    if (uns) return d.in_s == 2 && (d.Cin & 3) == 0 && d.ep_mode == BNERV_EP_PLAIN && d.out_s == 1 && (size_t)d.B * d.Cin * d.H * d.W * 4 < LEAN_MAX_BYTES;
+    if (d.in_s != 1) return false;
     if (d.Cin <= 12 && d.Cout <= 12) return false;                 // the 12-channel layers have their own family (conv4.hip)
     if (!(d.in_mode == BNERV_IN_PLAIN || d.in_mode == BNERV_IN_AFFINE)) return false;
     const int e = d.ep_mode;
@@ -279,6 +317,7 @@ int bnerv_convs_try(hipStream_t st, const bnerv_conv_desc& d, int vec, int kspli
     BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS)
     BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_GELU)
     BNERV_CASE(BNERV_IN_AFFINE, BNERV_EP_BIAS_RES)
+    BNERV_CASE(BNERV_IN_UNSHUFFLE, BNERV_EP_PLAIN)
 #undef BNERV_CASE
     return 1;
 }

@@ -737,3 +737,12 @@ def test_wide_split_kernels_random_shapes():
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_wide.py")
     r = subprocess.run([sys.executable, tool, "60", "7"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_low_resolution_family_random_shapes():
+    """The same sweep over the shapes convs.hip takes (Cin <= 32, PixelShuffle(2 / 3 / 5) epilogues, the unshuffle(2) prologue of the
+    up-conv data gradients up to 64 channels, TAT blocks with their slab reductions)."""
+    import subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_wide.py")
+    r = subprocess.run([sys.executable, tool, "80", "11", "small"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,10 +1,12 @@
 """Randomised shape sweep of the wide split kernels (conv_bfw / wgrad_bfw) against float64 torch references on the GPU: plain and
 PixelShuffle(2 / 3 / 5) convolutions with their data / weight / bias gradients, and the TAT block (affine prologues, gelu pair, residual,
-dGELU / dSIN epilogues with their per-channel sums).  usage: python tools/fuzz_wide.py [cases=120] [seed=0]
+dGELU / dSIN epilogues with their per-channel sums).  usage: python tools/fuzz_wide.py [cases=120] [seed=0] [small]
+"small": the same sweep over the shapes of the low-resolution family (convs.hip: Cin <= 32, up-conv data gradients up to 64 channels).
 (checker tool: torch fp64 is the reference here, not part of the product)"""
 import math, os, random, sys, torch
 os.environ.setdefault("BNERV_SPLIT_WIDE_MIN_TILES", "1")
-os.environ.setdefault("BNERV_SMALL", "0")          # keep small test images on the split kernels (not the low-resolution family)
+SMALL = "small" in sys.argv[3:]
+os.environ["BNERV_SMALL"] = "1" if SMALL else "0"   # wide sweep: keep small test images on the split kernels (not the low-resolution family)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch.nn.functional as F
 from boosting_nerv_amd import ops
@@ -52,7 +54,7 @@ for it in range(N):
     g = torch.Generator(device="cpu").manual_seed(rng.randint(0, 1 << 30))
     rn = lambda *s: torch.randn(*s, generator=g).to(dev)
     if kind == "tat":
-        Cc = rng.randint(17, 130)
+        Cc = rng.randint(13, 32) if SMALL else rng.randint(17, 130)
         case = (kind, B, Cc, H, W, os.environ["BNERV_SPLIT_WIDE_MIN_ITEMS"])
         x0 = rn(B, Cc, H, W).requires_grad_(True)
         mods = [(rn(B, Cc, 1, 1) * 0.3).requires_grad_(True) for _ in range(4)]
@@ -70,8 +72,8 @@ for it in range(N):
             bad += check("tat " + n_, a, r, case)
     else:
         s = {"conv": 1, "ps2": 2, "ps3": 3, "ps5": 5}[kind]
-        Cin = rng.randint(9, 110)
-        Ct = s * s * rng.randint(5 if s == 2 else 2, 40 if s == 2 else (20 if s == 3 else 8)) if s > 1 else rng.randint(17, 110)
+        Cin = rng.randint(9, 32) if SMALL else rng.randint(9, 110)
+        Ct = s * s * rng.randint(5 if s == 2 else 2, (16 if SMALL and rng.random() < 0.7 else 40) if s == 2 else (20 if s == 3 else 8)) if s > 1 else rng.randint(17, 110)
         if s > 2:
             H, W = min(H, 20), min(W, 64)
         if Cin <= 16 and Ct <= 16:
