@@ -32,14 +32,13 @@ namespace {
 // =====================================================================================================================
 constexpr int NSB = 512;  // partial blocks per sample
 
-__global__ __launch_bounds__(256) void diff_stats_kernel(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ part, int n_per_sample) {
-    const int b = blockIdx.y;
+__device__ __forceinline__ void diff_stats_body(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ part, int n_per_sample, const int bx, const int b) {
     const float* pp = p + (size_t)b * n_per_sample;
     const float* tt = t + (size_t)b * n_per_sample;
     float s1 = 0.f, s2 = 0.f;
     // eight loads in flight per thread; the sums take the elements in the same order as one by one
     constexpr int STR = NSB * 256;
-    int i = blockIdx.x * 256 + threadIdx.x;
+    int i = bx * 256 + threadIdx.x;
     for (; i + 3 * STR < n_per_sample; i += 4 * STR) {
         float d[4];
 #pragma unroll
@@ -58,8 +57,11 @@ __global__ __launch_bounds__(256) void diff_stats_kernel(const float* __restrict
     if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
     __syncthreads();
     if (threadIdx.x < 2) {
-        part[((size_t)b * NSB + blockIdx.x) * 2 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        part[((size_t)b * NSB + bx) * 2 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
     }
+}
+__global__ __launch_bounds__(256) void diff_stats_kernel(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ part, int n_per_sample) {
+    diff_stats_body(p, t, part, n_per_sample, blockIdx.x, blockIdx.y);
 }
 
 // one wave per sample: lane-strided partial sums, then a wave reduction in fp64
@@ -148,13 +150,13 @@ __global__ void avgpool2_kernel(const float* __restrict__ x0, const float* __res
 // 640, 320, 160): a block owns a 32x32 patch of level 0 = 16x16 of level 1 = ... = 2x2 of level 4, the intermediate levels pass
 // through LDS.  Same arithmetic as avgpool2_kernel level by level (0.25 * (((a + b) + c) + d)), so the pyramid is bit-identical.
 struct PyrArgs { const float* src[2]; float* dst[2][LV]; int H[LV], W[LV]; int planes; };
-__global__ __launch_bounds__(256) void pyramid_kernel(const PyrArgs a) {
+__device__ __forceinline__ void pyramid_body(const PyrArgs& a, const int bx, const int by, const int bz) {
     __shared__ float s1[16][17], s2[8][9], s3[4][5];
-    const int img = blockIdx.z & 1, pl = blockIdx.z >> 1;
+    const int img = bz & 1, pl = bz >> 1;
     const float* x = a.src[img] + (size_t)pl * a.H[0] * a.W[0];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     {
-        const int oy = blockIdx.y * 16 + ty, ox = blockIdx.x * 16 + tx;
+        const int oy = by * 16 + ty, ox = bx * 16 + tx;
         float v = 0.f;
         if (oy < a.H[1] && ox < a.W[1]) {
             const float2 r0 = *reinterpret_cast<const float2*>(x + (size_t)(2 * oy) * a.W[0] + 2 * ox);
@@ -166,25 +168,26 @@ __global__ __launch_bounds__(256) void pyramid_kernel(const PyrArgs a) {
     }
     __syncthreads();
     if (tid < 64) {
-        const int y = tid >> 3, xx = tid & 7, oy = blockIdx.y * 8 + y, ox = blockIdx.x * 8 + xx;
+        const int y = tid >> 3, xx = tid & 7, oy = by * 8 + y, ox = bx * 8 + xx;
         const float v = 0.25f * (((s1[2 * y][2 * xx] + s1[2 * y][2 * xx + 1]) + s1[2 * y + 1][2 * xx]) + s1[2 * y + 1][2 * xx + 1]);
         if (oy < a.H[2] && ox < a.W[2]) a.dst[img][2][((size_t)pl * a.H[2] + oy) * a.W[2] + ox] = v;
         s2[y][xx] = v;
     }
     __syncthreads();
     if (tid < 16) {
-        const int y = tid >> 2, xx = tid & 3, oy = blockIdx.y * 4 + y, ox = blockIdx.x * 4 + xx;
+        const int y = tid >> 2, xx = tid & 3, oy = by * 4 + y, ox = bx * 4 + xx;
         const float v = 0.25f * (((s2[2 * y][2 * xx] + s2[2 * y][2 * xx + 1]) + s2[2 * y + 1][2 * xx]) + s2[2 * y + 1][2 * xx + 1]);
         if (oy < a.H[3] && ox < a.W[3]) a.dst[img][3][((size_t)pl * a.H[3] + oy) * a.W[3] + ox] = v;
         s3[y][xx] = v;
     }
     __syncthreads();
     if (tid < 4) {
-        const int y = tid >> 1, xx = tid & 1, oy = blockIdx.y * 2 + y, ox = blockIdx.x * 2 + xx;
+        const int y = tid >> 1, xx = tid & 1, oy = by * 2 + y, ox = bx * 2 + xx;
         const float v = 0.25f * (((s3[2 * y][2 * xx] + s3[2 * y][2 * xx + 1]) + s3[2 * y + 1][2 * xx]) + s3[2 * y + 1][2 * xx + 1]);
         if (oy < a.H[4] && ox < a.W[4]) a.dst[img][4][((size_t)pl * a.H[4] + oy) * a.W[4] + ox] = v;
     }
 }
+__global__ __launch_bounds__(256) void pyramid_kernel(const PyrArgs a) { pyramid_body(a, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 struct SsimArgs {
     const float* X; const float* Y;
@@ -294,23 +297,27 @@ struct CoefArgs {
     int BC;
     float chain;                // -c_ms / (B*C)
 };
-__global__ __launch_bounds__(320) void ms_coef_kernel(const CoefArgs a) {
-    const int bc = blockIdx.x, lane = threadIdx.x & 63, l = threadIdx.x >> 6;
+// one wave per level (a block of 5 waves) or, inside a 256-thread launch, waves 0..3 with wave 0 taking level 4 as well: the per-level
+// sums never mix, so both forms add the same numbers in the same order
+__device__ __forceinline__ void ms_coef_body(const CoefArgs& a, const int bc) {
+    const int lane = threadIdx.x & 63, nw = (int)blockDim.x >> 6;
     __shared__ float stat[LV];
-    double s = 0.0;
-    // 8 loads in flight per lane (a level-0 row of 1800 partials was 29 serialised L2 round trips: 12 us for 3 blocks), added in
-    // the same order as one by one
-    const float* part = a.partial[l] + (size_t)bc * a.tiles[l];
-    const int nt = a.tiles[l];
-    for (int i0 = lane; i0 < nt; i0 += 8 * 64) {
-        float v[8];
+    for (int l = threadIdx.x >> 6; l < LV; l += nw) {
+        double s = 0.0;
+        // 8 loads in flight per lane (a level-0 row of 1800 partials was 29 serialised L2 round trips: 12 us for 3 blocks), added in
+        // the same order as one by one
+        const float* part = a.partial[l] + (size_t)bc * a.tiles[l];
+        const int nt = a.tiles[l];
+        for (int i0 = lane; i0 < nt; i0 += 8 * 64) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64; v[u] = i < nt ? part[i] : 0.f; }
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64; v[u] = i < nt ? part[i] : 0.f; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (i0 + u * 64 < nt) s += (double)v[u];
+            for (int u = 0; u < 8; ++u) if (i0 + u * 64 < nt) s += (double)v[u];
+        }
+        s = wave_sum_d(s);
+        if (lane == 0) stat[l] = (float)(s * (double)a.inv_nvalid[l]);
     }
-    s = wave_sum_d(s);
-    if (lane == 0) stat[l] = (float)(s * (double)a.inv_nvalid[l]);
     __syncthreads();
     if (threadIdx.x == 0) {
         float P = 1.f;
@@ -320,6 +327,7 @@ __global__ __launch_bounds__(320) void ms_coef_kernel(const CoefArgs a) {
             a.coef[(size_t)k * a.BC + bc] = stat[k] > 0.f ? a.chain * a.weights[k] * (P / stat[k]) * a.inv_nvalid[k] : 0.f;
     }
 }
+__global__ __launch_bounds__(320) void ms_coef_kernel(const CoefArgs a) { ms_coef_body(a, blockIdx.x); }
 
 // ---- backward from the stored statistic gradients: adjoint of the separable "valid" filter over the 3 maps, then
 //      dX = coef * (A0 + 2 x A1 + y A2) [+ 0.25 * d(coarser level)] [+ L1/L2 terms at level 0].  ~6x less arithmetic than
@@ -613,11 +621,11 @@ struct FftArgs {
     FftPlan prow, pcol;
 };
 
-__global__ __launch_bounds__(256) void fft_rows_fwd_kernel(const FftArgs a) {
+__device__ __forceinline__ void fft_rows_fwd_body(const FftArgs& a, const int bx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float2* buf = reinterpret_cast<float2*>(sm);
     const int W = a.W;
-    const size_t row0 = (size_t)blockIdx.x * ROWS_PER_BLOCK;            // global row index over BC*H
+    const size_t row0 = (size_t)bx * ROWS_PER_BLOCK;                    // global row index over BC*H
     const size_t nrows = (size_t)a.BC * a.H;
     const int nl = (int)min((size_t)ROWS_PER_BLOCK, nrows - row0);
     float2* tw = buf + ROWS_PER_BLOCK * W;
@@ -645,13 +653,14 @@ __global__ __launch_bounds__(256) void fft_rows_fwd_kernel(const FftArgs a) {
         a.T[(row0 + line) * Wh + f] = buf[line * W + a.prow.pos[f]];
     }
 }
+__global__ __launch_bounds__(256) void fft_rows_fwd_kernel(const FftArgs a) { fft_rows_fwd_body(a, blockIdx.x); }
 
-__global__ __launch_bounds__(256) void fft_cols_kernel(const FftArgs a) {
+__device__ __forceinline__ void fft_cols_body(const FftArgs& a, const int bx, const int bc, const int ncolblk) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float2* buf = reinterpret_cast<float2*>(sm);                          // [COLS_PER_BLOCK][H]
     __shared__ float red[4];
-    const int H = a.H, W = a.Wh, bc = blockIdx.y;                          // W: kept columns (half spectrum)
-    const int v0 = blockIdx.x * COLS_PER_BLOCK;
+    const int H = a.H, W = a.Wh;                                           // W: kept columns (half spectrum)
+    const int v0 = bx * COLS_PER_BLOCK;
     const int nc = min(COLS_PER_BLOCK, W - v0);
     float2* T = a.T + (size_t)bc * H * W;
     float2* tw = buf + COLS_PER_BLOCK * H;
@@ -684,7 +693,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const FftArgs a) {
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) a.partial[(size_t)bc * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) a.partial[(size_t)bc * ncolblk + bx] = red[0] + red[1] + red[2] + red[3];
     if (a.grad == nullptr) return;
     fft_adjoint(buf, nc, H, a.pcol, tw);
     for (int i = threadIdx.x; i < H * nc; i += blockDim.x) {
@@ -692,6 +701,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const FftArgs a) {
         T[(size_t)y * W + v0 + c] = buf[c * H + y];
     }
 }
+__global__ __launch_bounds__(256) void fft_cols_kernel(const FftArgs a) { fft_cols_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 __global__ __launch_bounds__(256) void fft_rows_adj_kernel(const FftArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -749,7 +759,7 @@ struct FinalArgs {
     float c_l1, c_l2, c_ms, c_fft;
 };
 // one wave: lane-strided sums over the partial arrays (independent loads in flight), wave reductions in fp64
-__global__ __launch_bounds__(64) void loss_final_kernel(const FinalArgs a) {
+__device__ __forceinline__ void loss_final_body(const FinalArgs& a) {      // ONE wave: threadIdx.x < 64
     const int lane = threadIdx.x;
     double total = 0.0;
     for (int b = 0; b < a.B; ++b) {
@@ -780,6 +790,35 @@ __global__ __launch_bounds__(64) void loss_final_kernel(const FinalArgs a) {
         total += l;
     }
     if (lane == 0) a.loss_out[0] = (float)(total / a.B);
+}
+__global__ __launch_bounds__(64) void loss_final_kernel(const FinalArgs a) { loss_final_body(a); }
+
+// ---- merged launches of the Fusion losses on an even pyramid (MS-SSIM + spectral term + gradient): the 10 launches of the branch
+// sequence become 6.  What is merged are launches that do not depend on each other, as block ranges of one grid (the bodies are
+// unchanged, every number is computed by the same instructions in the same order):
+//   head:  row FFTs of pred - target  |  the 4-level pyramid of both images  |  the L1 / L2 partial sums
+//   mid:   column FFTs (+ spectral partials, + adjoint columns)  |  the MS-SSIM coefficients (needs the SSIM launch before it)
+//   tail:  level-0 SSIM gradient with the 0.25-chain  |  loss_final (needs only the partials of head and mid)
+struct LossHeadArgs { FftArgs f; PyrArgs p; const float* pred; const float* target; float* stats_part; int nps, n_fft, n_pyr, pyr_gx, pyr_gy; };
+__global__ __launch_bounds__(256) void loss_head_kernel(const LossHeadArgs a) {
+    int b = blockIdx.x;
+    if (b < a.n_fft) { fft_rows_fwd_body(a.f, b); return; }               // the long blocks first
+    b -= a.n_fft;
+    if (b < a.n_pyr) { const int bx = b % a.pyr_gx, r = b / a.pyr_gx; pyramid_body(a.p, bx, r % a.pyr_gy, r / a.pyr_gy); return; }
+    b -= a.n_pyr;
+    diff_stats_body(a.pred, a.target, a.stats_part, a.nps, b % NSB, b / NSB);
+}
+struct LossMidArgs { FftArgs f; CoefArgs c; int ncolblk, n_cols; };
+__global__ __launch_bounds__(256) void loss_mid_kernel(const LossMidArgs a) {
+    const int b = blockIdx.x;
+    if (b < a.n_cols) fft_cols_body(a.f, b % a.ncolblk, b / a.ncolblk, a.ncolblk);
+    else ms_coef_body(a.c, b - a.n_cols);
+}
+struct LossTailArgs { SsimArgs s; CoarseChain cc; FinalArgs fin; int gx, gy, n0, BC; };
+__global__ __launch_bounds__(256) void loss_tail_kernel(const LossTailArgs a) {
+    const int b = blockIdx.x;
+    if (b < a.n0) { const int bx = b % a.gx, r = b / a.gx; ssim_bwd_body<true>(a.s, &a.cc, bx, r % a.gy, r / a.gy, a.BC); }
+    else if (threadIdx.x < 64) loss_final_body(a.fin);
 }
 __global__ void msssim_final_kernel(const float* __restrict__ msval, float* __restrict__ out, int B, int C) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -833,40 +872,68 @@ static bool even_pyramid(const WsLayout& L) {         // every pooled level has 
     return true;
 }
 
+static bool loss_merged() {                             // BNERV_LOSS_MERGED=0: every launch of the even-pyramid form on its own (A/B switch, read per call)
+    const char* e = getenv("BNERV_LOSS_MERGED");
+    return !(e && e[0] == '0');
+}
+
+// arguments of the even-pyramid forward launches (pyramid, every level's statistics, coefficients)
+static int fill_even_forward(const float* X, const float* Y, float* ws, const WsLayout& L, int BC, float chain, bool want_g, PyrArgs& pa, SsimAllArgs& sa, CoefArgs& ca) {
+    static const float wts[LV] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
+    const Win win = make_win();
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    pa.src[0] = X; pa.src[1] = Y; pa.planes = BC;
+    for (int l = 0; l < LV; ++l) {
+        pa.H[l] = L.pyr.H[l]; pa.W[l] = L.pyr.W[l];
+        if (L.pyr.H[l] <= HW_ || L.pyr.W[l] <= HW_) return bnerv_set_error(BNERV_E_ARG, "ms_ssim: level %d is %dx%d, needs > %d on both sides", l, L.pyr.H[l], L.pyr.W[l], HW_);
+        if (l > 0) { pa.dst[0][l] = ws + L.pyrX[l]; pa.dst[1][l] = ws + L.pyrY[l]; }
+    }
+    int nblk = 0;
+    for (int l = 0; l < LV; ++l) {
+        SsimArgs& a = sa.lv[l];
+        a.X = l ? ws + L.pyrX[l] : X; a.Y = l ? ws + L.pyrY[l] : Y; a.partial = ws + L.ssim_part[l]; a.H = L.pyr.H[l]; a.W = L.pyr.W[l];
+        a.G = want_g ? ws + L.Gl[l] : nullptr;
+        a.tiles_x = cdiv(a.W - HW_, STW); a.tiles_y = cdiv(a.H - HW_, STH); a.C1 = C1; a.C2 = C2; a.win = win;
+        sa.first[l] = nblk;
+        nblk += a.tiles_x * a.tiles_y;
+        ca.partial[l] = ws + L.ssim_part[l]; ca.tiles[l] = L.tiles[l];
+        ca.inv_nvalid[l] = 1.0f / ((float)(a.H - HW_) * (float)(a.W - HW_));
+        ca.weights[l] = wts[l];
+    }
+    sa.first[LV] = nblk;
+    ca.msval = ws + L.msval; ca.coef = ws + L.coef; ca.BC = BC; ca.chain = chain;
+    return BNERV_OK;
+}
+// ... and of the even-pyramid backward launches (the coarser levels' own terms; level 0 with the 0.25-chain over them)
+static void fill_even_backward(const float* X, const float* Y, float* grad, float* ws, const WsLayout& L, int BC, float k_l1, float k_l2, SsimAllArgs& sa, CoarseChain& cc) {
+    const Win win = make_win();
+    int nblk = 0;
+    for (int l = 0; l < LV; ++l) {
+        SsimArgs& a = sa.lv[l];
+        a.X = l ? ws + L.pyrX[l] : X; a.Y = l ? ws + L.pyrY[l] : Y; a.coef = ws + L.coef + (size_t)l * BC;
+        a.dX = l ? ws + L.dXl[l] : grad; a.H = L.pyr.H[l]; a.W = L.pyr.W[l]; a.C1 = 0.01f * 0.01f; a.C2 = 0.03f * 0.03f; a.win = win;
+        a.k_l1 = k_l1; a.k_l2 = k_l2; a.G = ws + L.Gl[l];
+        sa.first[l] = nblk;
+        if (l >= 1) nblk += cdiv(a.W, STW) * cdiv(a.H, STH);
+        cc.own[l] = l ? ws + L.dXl[l] : nullptr; cc.H[l] = a.H; cc.W[l] = a.W;
+    }
+    sa.first[LV] = nblk;
+    cc.n = LV - 1;
+}
+
 static int run_ms_forward(hipStream_t st, const float* X, const float* Y, float* ws, const WsLayout& L, int B, int C, float chain, bool want_g) {
     const int BC = B * C;
     const Win win = make_win();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     if (even_pyramid(L)) {
         // 3 launches instead of 10: the pyramid, every level's statistics, the coefficients
-        static const float wts[LV] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
-        PyrArgs pa{};
-        pa.src[0] = X; pa.src[1] = Y; pa.planes = BC;
-        for (int l = 0; l < LV; ++l) {
-            pa.H[l] = L.pyr.H[l]; pa.W[l] = L.pyr.W[l];
-            if (L.pyr.H[l] <= HW_ || L.pyr.W[l] <= HW_) return bnerv_set_error(BNERV_E_ARG, "ms_ssim: level %d is %dx%d, needs > %d on both sides", l, L.pyr.H[l], L.pyr.W[l], HW_);
-            if (l > 0) { pa.dst[0][l] = ws + L.pyrX[l]; pa.dst[1][l] = ws + L.pyrY[l]; }
-        }
+        PyrArgs pa{}; SsimAllArgs sa{}; CoefArgs ca{};
+        int rc = fill_even_forward(X, Y, ws, L, BC, chain, want_g, pa, sa, ca);
+        if (rc) return rc;
         hipLaunchKernelGGL(pyramid_kernel, dim3(cdiv(L.pyr.W[1], 16), cdiv(L.pyr.H[1], 16), 2 * BC), dim3(256), 0, st, pa);
         BNERV_LAUNCH_CHECK("pyramid");
-        SsimAllArgs sa{};
-        CoefArgs ca{};
-        int nblk = 0;
-        for (int l = 0; l < LV; ++l) {
-            SsimArgs& a = sa.lv[l];
-            a.X = l ? ws + L.pyrX[l] : X; a.Y = l ? ws + L.pyrY[l] : Y; a.partial = ws + L.ssim_part[l]; a.H = L.pyr.H[l]; a.W = L.pyr.W[l];
-            a.G = want_g ? ws + L.Gl[l] : nullptr;
-            a.tiles_x = cdiv(a.W - HW_, STW); a.tiles_y = cdiv(a.H - HW_, STH); a.C1 = C1; a.C2 = C2; a.win = win;
-            sa.first[l] = nblk;
-            nblk += a.tiles_x * a.tiles_y;
-            ca.partial[l] = ws + L.ssim_part[l]; ca.tiles[l] = L.tiles[l];
-            ca.inv_nvalid[l] = 1.0f / ((float)(a.H - HW_) * (float)(a.W - HW_));
-            ca.weights[l] = wts[l];
-        }
-        sa.first[LV] = nblk;
-        hipLaunchKernelGGL(ssim_fwd_all_kernel, dim3(nblk, BC), dim3(256), 0, st, sa);
+        hipLaunchKernelGGL(ssim_fwd_all_kernel, dim3(sa.first[LV], BC), dim3(256), 0, st, sa);
         BNERV_LAUNCH_CHECK("ssim_fwd_all");
-        ca.msval = ws + L.msval; ca.coef = ws + L.coef; ca.BC = BC; ca.chain = chain;
         hipLaunchKernelGGL(ms_coef_kernel, dim3(BC), dim3(320), 0, st, ca);
         BNERV_LAUNCH_CHECK("ms_coef");
         return BNERV_OK;
@@ -909,19 +976,8 @@ static int run_ms_backward(hipStream_t st, const float* X, const float* Y, float
         // 2 launches instead of 5: the coarser levels' own terms together, then level 0 with the 0.25-chain over them
         SsimAllArgs sa{};
         CoarseChain cc{};
-        int nblk = 0;
-        for (int l = 0; l < LV; ++l) {
-            SsimArgs& a = sa.lv[l];
-            a.X = l ? ws + L.pyrX[l] : X; a.Y = l ? ws + L.pyrY[l] : Y; a.coef = ws + L.coef + (size_t)l * BC;
-            a.dX = l ? ws + L.dXl[l] : grad; a.H = L.pyr.H[l]; a.W = L.pyr.W[l]; a.C1 = 0.01f * 0.01f; a.C2 = 0.03f * 0.03f; a.win = win;
-            a.k_l1 = k_l1; a.k_l2 = k_l2; a.G = ws + L.Gl[l];
-            sa.first[l] = nblk;
-            if (l >= 1) nblk += cdiv(a.W, STW) * cdiv(a.H, STH);
-            cc.own[l] = l ? ws + L.dXl[l] : nullptr; cc.H[l] = a.H; cc.W[l] = a.W;
-        }
-        sa.first[LV] = nblk;
-        cc.n = LV - 1;
-        hipLaunchKernelGGL(ssim_bwd_coarse_all_kernel, dim3(nblk, BC), dim3(256), 0, st, sa);
+        fill_even_backward(X, Y, grad, ws, L, BC, k_l1, k_l2, sa, cc);
+        hipLaunchKernelGGL(ssim_bwd_coarse_all_kernel, dim3(sa.first[LV], BC), dim3(256), 0, st, sa);
         BNERV_LAUNCH_CHECK("ssim_bwd_coarse_all");
         hipLaunchKernelGGL(ssim_bwd_level0_chain_kernel, dim3(cdiv(L.pyr.W[0], STW), cdiv(L.pyr.H[0], STH), BC), dim3(256), 0, st, sa.lv[0], cc);
         BNERV_LAUNCH_CHECK("ssim_bwd_level0");
@@ -958,6 +1014,10 @@ extern "C" size_t bnerv_loss_ws_bytes(int B, int C, int H, int W, int use_ms, in
     return make_layout(B, C, H, W, use_ms != 0, use_fft != 0).total * sizeof(float);
 }
 
+// (A second stream for the spectral branch was measured and dropped: forked with an event pair the loss section of the trace shrinks
+// from 207 to 194 us, but the column FFT doubles next to the SSIM maps, the fork / join edges idle the chip for 6 + 10 us and a
+// two-branch graph replays slower than a linear one: C1 1.789 ms forked against 1.759 ms.  Independent launches are merged as block
+// ranges of one grid instead -- loss_head / loss_mid / loss_tail above.)
 extern "C" int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* dp) {
     BNERV_REQUIRE(dp != nullptr, "loss: null descriptor");
     const bnerv_loss_desc d = *dp;
@@ -970,11 +1030,59 @@ extern "C" int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* dp) {
     hipStream_t st = (hipStream_t)stream;
     float* ws = reinterpret_cast<float*>(d.ws);
     const int nps = d.C * d.H * d.W, BC = d.B * d.C;
+    const float k_l1 = d.c_l1 / ((float)d.B * (float)nps), k_l2 = 2.0f * d.c_l2 / ((float)d.B * (float)nps);
+    if (use_ms && (d.H <= 160 || d.W <= 160)) return bnerv_set_error(BNERV_E_ARG, "loss: MS-SSIM needs min(H,W) > 160 (got %dx%d)", d.H, d.W);
+    FftArgs a{};
+    size_t lds_row = 0, lds_col = 0;
+    int nrowblk = 0;
+    if (use_fft) {
+        if (!make_plan(d.W, &a.prow) || !make_plan(d.H, &a.pcol))
+            return bnerv_set_error(BNERV_E_ARG, "loss: FFT size %dx%d has a prime factor > %d", d.H, d.W, BNERV_FFT_MAX_RADIX);
+        a.pred = d.pred; a.target = d.target; a.T = reinterpret_cast<float2*>(ws + L.T); a.Wh = d.W / 2 + 1; a.partial = ws + L.fft_part; a.grad = d.grad;
+        a.BC = BC; a.H = d.H; a.W = d.W; a.gscale = d.c_fft / ((float)d.B * (float)nps * 2.0f); a.accumulate = 1;
+        lds_row = (size_t)(ROWS_PER_BLOCK + 1) * d.W * sizeof(float2); lds_col = (size_t)(COLS_PER_BLOCK + 1) * d.H * sizeof(float2);   // + twiddle table
+        BNERV_REQUIRE(lds_row <= 160 * 1024 && lds_col <= 160 * 1024, "loss: frame %dx%d too large for the LDS FFT", d.H, d.W);
+        nrowblk = cdiv(BC * d.H, ROWS_PER_BLOCK);
+    }
+    FinalArgs f{};
+    f.stats_part = ws + L.stats_part; f.msval = use_ms ? ws + L.msval : nullptr; f.fft_part = use_fft ? ws + L.fft_part : nullptr;
+    f.loss_out = d.loss_out; f.stats_out = d.stats_out; f.B = d.B; f.C = d.C; f.n_per_sample = nps; f.ncolblk = L.ncolblk;
+    f.c_l1 = d.c_l1; f.c_l2 = d.c_l2; f.c_ms = d.c_ms; f.c_fft = d.c_fft;
+
+    if (use_ms && use_fft && d.grad && even_pyramid(L) && loss_merged()) {
+        // 6 launches: head (row FFTs | pyramid | L1 / L2 sums), SSIM statistics, mid (column FFTs | coefficients), coarse SSIM
+        // gradients, tail (level-0 gradient | loss_final), adjoint row FFTs (adds the spectral gradient)
+        LossHeadArgs ha{}; LossMidArgs ma{}; LossTailArgs ta{};
+        SsimAllArgs sf{};
+        int rc = fill_even_forward(d.pred, d.target, ws, L, BC, -d.c_ms / (float)BC, true, ha.p, sf, ma.c);
+        if (rc) return rc;
+        ha.f = a; ha.pred = d.pred; ha.target = d.target; ha.stats_part = ws + L.stats_part; ha.nps = nps;
+        ha.n_fft = nrowblk; ha.pyr_gx = cdiv(L.pyr.W[1], 16); ha.pyr_gy = cdiv(L.pyr.H[1], 16); ha.n_pyr = ha.pyr_gx * ha.pyr_gy * 2 * BC;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
+        hipLaunchKernelGGL(loss_head_kernel, dim3(ha.n_fft + ha.n_pyr + NSB * d.B), dim3(256), lds_row, st, ha);
+        BNERV_LAUNCH_CHECK("loss_head");
+        hipLaunchKernelGGL(ssim_fwd_all_kernel, dim3(sf.first[LV], BC), dim3(256), 0, st, sf);
+        BNERV_LAUNCH_CHECK("ssim_fwd_all");
+        ma.f = a; ma.ncolblk = L.ncolblk; ma.n_cols = L.ncolblk * BC;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_col);
+        hipLaunchKernelGGL(loss_mid_kernel, dim3(ma.n_cols + BC), dim3(256), lds_col, st, ma);
+        BNERV_LAUNCH_CHECK("loss_mid");
+        SsimAllArgs sb{};
+        fill_even_backward(d.pred, d.target, d.grad, ws, L, BC, k_l1, k_l2, sb, ta.cc);
+        hipLaunchKernelGGL(ssim_bwd_coarse_all_kernel, dim3(sb.first[LV], BC), dim3(256), 0, st, sb);
+        BNERV_LAUNCH_CHECK("ssim_bwd_coarse_all");
+        ta.s = sb.lv[0]; ta.fin = f; ta.gx = cdiv(L.pyr.W[0], STW); ta.gy = cdiv(L.pyr.H[0], STH); ta.BC = BC; ta.n0 = ta.gx * ta.gy * BC;
+        hipLaunchKernelGGL(loss_tail_kernel, dim3(ta.n0 + 1), dim3(256), 0, st, ta);
+        BNERV_LAUNCH_CHECK("loss_tail");
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_adj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
+        hipLaunchKernelGGL(fft_rows_adj_kernel, dim3(nrowblk), dim3(256), lds_row, st, a);
+        BNERV_LAUNCH_CHECK("fft_rows_adj");
+        return BNERV_OK;
+    }
+
     int rc = launch_stats(st, d.pred, d.target, ws + L.stats_part, d.B, nps);
     if (rc) return rc;
-    const float k_l1 = d.c_l1 / ((float)d.B * (float)nps), k_l2 = 2.0f * d.c_l2 / ((float)d.B * (float)nps);
     if (use_ms) {
-        if (d.H <= 160 || d.W <= 160) return bnerv_set_error(BNERV_E_ARG, "loss: MS-SSIM needs min(H,W) > 160 (got %dx%d)", d.H, d.W);
         rc = run_ms_forward(st, d.pred, d.target, ws, L, d.B, d.C, -d.c_ms / (float)BC, d.grad != nullptr);
         if (rc) return rc;
         if (d.grad) { rc = run_ms_backward(st, d.pred, d.target, d.grad, ws, L, d.B, d.C, k_l1, k_l2); if (rc) return rc; }
@@ -985,17 +1093,9 @@ extern "C" int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* dp) {
         BNERV_LAUNCH_CHECK("grad_l1l2");
     }
     if (use_fft) {
-        FftArgs a{};
-        if (!make_plan(d.W, &a.prow) || !make_plan(d.H, &a.pcol))
-            return bnerv_set_error(BNERV_E_ARG, "loss: FFT size %dx%d has a prime factor > %d", d.H, d.W, BNERV_FFT_MAX_RADIX);
-        a.pred = d.pred; a.target = d.target; a.T = reinterpret_cast<float2*>(ws + L.T); a.Wh = d.W / 2 + 1; a.partial = ws + L.fft_part; a.grad = d.grad;
-        a.BC = BC; a.H = d.H; a.W = d.W; a.gscale = d.c_fft / ((float)d.B * (float)nps * 2.0f); a.accumulate = 1;
-        const size_t lds_row = (size_t)(ROWS_PER_BLOCK + 1) * d.W * sizeof(float2), lds_col = (size_t)(COLS_PER_BLOCK + 1) * d.H * sizeof(float2);   // + twiddle table
-        BNERV_REQUIRE(lds_row <= 160 * 1024 && lds_col <= 160 * 1024, "loss: frame %dx%d too large for the LDS FFT", d.H, d.W);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_adj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_col);
-        const int nrowblk = cdiv(BC * d.H, ROWS_PER_BLOCK);
         hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(nrowblk), dim3(256), lds_row, st, a);
         BNERV_LAUNCH_CHECK("fft_rows_fwd");
         hipLaunchKernelGGL(fft_cols_kernel, dim3(L.ncolblk, BC), dim3(256), lds_col, st, a);
@@ -1005,10 +1105,6 @@ extern "C" int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* dp) {
             BNERV_LAUNCH_CHECK("fft_rows_adj");
         }
     }
-    FinalArgs f{};
-    f.stats_part = ws + L.stats_part; f.msval = use_ms ? ws + L.msval : nullptr; f.fft_part = use_fft ? ws + L.fft_part : nullptr;
-    f.loss_out = d.loss_out; f.stats_out = d.stats_out; f.B = d.B; f.C = d.C; f.n_per_sample = nps; f.ncolblk = L.ncolblk;
-    f.c_l1 = d.c_l1; f.c_l2 = d.c_l2; f.c_ms = d.c_ms; f.c_fft = d.c_fft;
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, f);
     BNERV_LAUNCH_CHECK("loss_final");
     return BNERV_OK;

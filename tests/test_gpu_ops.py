@@ -713,6 +713,23 @@ def test_fused_msssim_launches_equal_the_level_by_level_form(ops, shape, monkeyp
     assert (ga - gb).abs().max().item() <= 3e-5 * gb.abs().max().item()      # (a0 + 2 x a1 + y a2 cancels: a different contraction shows at 1e-5 of the largest entry)
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 720, 1280), (2, 3, 176, 208)])
+def test_merged_loss_launches_change_no_bit(ops, shape, monkeypatch):
+    """Fusion10_freq on an even pyramid: independent launches share one grid as block ranges (row FFTs | pyramid | L1 / L2 sums; column
+    FFTs | MS-SSIM coefficients; level-0 gradient | loss_final -- 6 launches instead of 10).  The bodies are the same code, so the loss,
+    the per-sample statistics and the gradient are BIT-equal to the one-launch-per-kernel form (BNERV_LOSS_MERGED=0)."""
+    g = torch.Generator().manual_seed(7 + sum(shape))
+    tgt = torch.rand(*shape, generator=g).to(DEV)
+    pred = (tgt + 0.1 * torch.randn(*shape, generator=g).to(DEV)).clamp(0, 1)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BNERV_LOSS_MERGED", mode)
+        loss, stats, grad = ops.loss_value_grad_stats(pred, tgt, "Fusion10_freq")
+        out[mode] = (loss.clone(), stats.clone(), grad.clone())
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.equal(a, b)
+
+
 def test_msssim_kernel_against_independent_form(ops):
     """bnerv_msssim (the kernels behind the 0.3 * (1 - ms_ssim) term of Fusion10_freq, hnerv_utils.py:369-370, and the MS-SSIM eval
     metric, :410-412) against the independent float64 form of tests/msssim_independent.py -- direct 2-D window, written from the
