@@ -720,11 +720,27 @@ __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(cons
 }
 
 // ---- paired launch: the data gradient of a 12-channel 3x3 conv (conv4_body.h) and a weight gradient that does not depend on it, in
-// ONE grid -- blocks [0, n_conv) run the conv, the rest the weight gradient.  Inside a TAT block's backward the pairs are
+// ONE grid -- blocks [0, n_conv) run the conv, the rest the weight gradient (small layers), or the two roles interleaved with equal
+// block counts and the same tile walk (large layers: n_conv < 0, see launch_pair).  Inside a TAT block's backward the pairs are
 // (dW1 | dconv1), (dW0 | dconv0), (dW_block | dconv_block): each pair reads the same incoming gradient, and neither half fills the
 // chip through its prologue and tail (at 180x320 each is one tile per block: two latency-bound launches become one).
 template <int EP, int WIN>
-__global__ __launch_bounds__(256, 3) void conv_wgrad_pair_kernel(const bnerv_conv::KArgs ka, const WArgs wa, const int n_grows, const int n_conv, const SidePack side) {
+__global__ __launch_bounds__(256, 3) void conv_wgrad_pair_kernel(const bnerv_conv::KArgs ka, const WArgs wa, const int n_grows, const int n_conv, const SidePack side, const int pat) {
+    if (n_conv < 0) {
+        // interleaved roles (n_conv = -(blocks per role)): XCD-local slots alternate conv / weight gradient, and block k of either role
+        // walks the same tile list on the same XCD -- what one reads of the shared gradient (and of the conv's aux = the weight
+        // gradient's input) the other finds in that XCD's L2
+        const int nr = -n_conv, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, vb = ((slot >> 1) << 3) + xcd;
+        const int role = pat == 0 ? (slot & 1) : ((slot + (slot >> pat)) & 1);
+        if (role == 0) {
+            SidePack none;
+            none.n_jobs = 0; none.n_slices = 0;
+            bnerv_q4::conv_q4_body<BNERV_IN_PLAIN, EP>(ka, none, vb, nr);
+        } else {
+            wgrad_lean_body<3, WIN, 0>(wa, n_grows, side, vb, nr);
+        }
+        return;
+    }
     if ((int)blockIdx.x < n_conv) {                        // block-uniform
         SidePack none;
         none.n_jobs = 0; none.n_slices = 0;
@@ -1754,7 +1770,7 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
 // ------------------------------------------------------------------------------------------------------------------ paired launch
 namespace {
 template <int EP, int WIN>
-int launch_pair(hipStream_t st, bnerv_conv::KArgs& ka, const WArgs& wa) {
+int launch_pair(hipStream_t st, bnerv_conv::KArgs& ka, const WArgs& wa, int* n_w_out) {
     bnerv_q4::q4_prepare(ka);
     const int n_grows = wa.d.Cout <= 12 ? 12 : 16;
     size_t lds = bnerv_q4::q4_lds_bytes();
@@ -1767,10 +1783,22 @@ int launch_pair(hipStream_t st, bnerv_conv::KArgs& ka, const WArgs& wa) {
     }
     int n_conv = ka.total_items < 768 ? ka.total_items : 768;          // 3 conv blocks per CU when the layer is large
     n_conv = (n_conv + 7) & ~7;                                        // multiple of 8: block b runs on XCD b % 8 for BOTH halves' slices
-    const int n_w = wlean_blocks(wa.d);
+    int n_w = wlean_blocks(wa.d);
+    int grid = n_conv + n_w;
+    if (n_w_out) *n_w_out = n_w;
+    // BNERV_PAIR_MIX: blocks per role of the interleaved form (0: conv blocks first, then the weight gradient's); BNERV_PAIR_PAT: the
+    // role of XCD-local slot s is (s + (s >> PAT)) & 1 (0: s & 1).  Measured on C1 (1.745 ms with the roles one after the other):
+    // 384 blocks per role 1.680 (PAT 0), 1.642 (PAT 5: the parity flips every 32 slots = the CUs of an XCD, so every CU holds both
+    // roles), 1.664 (6), 1.68 (3, 4, 7); 376 / 368 per role as 384, 512 per role (not all resident) 1.783.
+    static const int mix = [] { const char* e = getenv("BNERV_PAIR_MIX"); return e ? atoi(e) : 384; }();
+    static const int pat = [] { const char* e = getenv("BNERV_PAIR_PAT"); return e ? atoi(e) : 5; }();
+    if (mix > 0 && ka.total_items >= 2 * mix && n_w >= mix) {          // large layer: mix blocks per role, all resident, roles interleaved
+        n_w = mix; n_conv = -mix; grid = 2 * mix;
+        if (n_w_out) *n_w_out = n_w;
+    }
     SidePack side;
     bnerv_side_take(wa.d.ctx, &side, 2 * n_w);
-    hipLaunchKernelGGL((conv_wgrad_pair_kernel<EP, WIN>), dim3(n_conv + n_w), dim3(256), lds, st, ka, wa, n_grows, n_conv, side);
+    hipLaunchKernelGGL((conv_wgrad_pair_kernel<EP, WIN>), dim3(grid), dim3(256), lds, st, ka, wa, n_grows, n_conv, side, pat);
     BNERV_LAUNCH_CHECK("conv_wgrad_pair");
     return BNERV_OK;
 }
@@ -1817,13 +1845,13 @@ extern "C" int bnerv_conv_wgrad_pair(void* stream, const bnerv_conv_desc* cdp, c
     wa.vec = ((w.W % 4 == 0) && al(w.x) && al(w.g)) ? 1 : 0;
     if (!wlean_ok(wa)) return 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int rc = 1;
-#define BNERV_PAIR_CASE(E, I) if (c.ep_mode == E && w.in_mode == I) rc = launch_pair<E, I>(st, ka, wa);
+    int rc = 1, n_w_used = 0;
+#define BNERV_PAIR_CASE(E, I) if (c.ep_mode == E && w.in_mode == I) rc = launch_pair<E, I>(st, ka, wa, &n_w_used);
     BNERV_PAIR_CASE(BNERV_EP_DGELU_SAVED, BNERV_IN_AFFINE)
     BNERV_PAIR_CASE(BNERV_EP_DSIN, BNERV_IN_AFFINE)
     BNERV_PAIR_CASE(BNERV_EP_PLAIN, BNERV_IN_PLAIN)
 #undef BNERV_PAIR_CASE
     if (rc != BNERV_OK) return rc;
-    bnerv_side_push(w.ctx, st, wa.slab, wlean_blocks(w), w.Cout * wa.ncols, wa.ncols, w.dw, w.db);     // the slab reduction rides on a later launch
+    bnerv_side_push(w.ctx, st, wa.slab, n_w_used, w.Cout * wa.ncols, wa.ncols, w.dw, w.db);     // the slab reduction rides on a later launch
     return BNERV_OK;
 }

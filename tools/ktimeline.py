@@ -1,13 +1,13 @@
 """Per-launch timeline of ONE eager step from a rocprofv3 kernel trace (CSV): every launch of one complete step in issue
 order with its duration, the gap to its predecessor and its grid -- shows which SHAPES the time goes to (a --stats table merges
 all resolutions of one template).  usage: python tools/ktimeline.py <dir with *_kernel_trace.csv> [marker kernel substring]
-The marker is a kernel launched exactly once per step (default: loss_final_kernel)."""
+The marker is a kernel launched exactly once per step (default: adan_table_kernel, the optimizer: a step then reads forward, loss, backward, update)."""
 import csv
 import glob
 import sys
 
 d = sys.argv[1]
-marker = sys.argv[2] if len(sys.argv) > 2 else "loss_final_kernel"
+marker = sys.argv[2] if len(sys.argv) > 2 else "adan_table_kernel"
 f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
