@@ -19,6 +19,8 @@
 #include "sidejob.h"
 #include "split16.h"
 #include "conv4_body.h"     // the 4x4x1 conv body: paired conv + weight-gradient launches (bnerv_conv_wgrad_pair, bottom of this file)
+#include "convs_body.h"     // the low-resolution conv body, for the same
+bool bnerv_convs_shape_ok(const bnerv_conv_desc& d, int vec);     // convs.hip
 #include <stdlib.h>
 #include <type_traits>
 #include <string.h>
@@ -818,7 +820,8 @@ int launch_wlean_modes(hipStream_t st, const WArgs& wa) {
 // GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient (two float4 per cout PAIR), 2 = tanh-grad (g, gaux),
 //      3 = pixel-shuffled by g_s (3, 5): one dword per pixel, g_s apart
 template <int IN, int GM2, int MTW, int NTW>
-__global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kernel(const WArgs wa, const int slots, const SidePack side) {
+__device__ __forceinline__ void wgrad_wide_body(const WArgs& wa, const int slots, const SidePack& side, const int vb, const int vgrid) {
+    // (vb of vgrid: this launch's block index / size, or the weight-gradient part of a paired launch)
     using G = Geo<3>;
     constexpr int NPL = wgrad_npl<3, NTW>();
     constexpr int NXSLOT = NPL * G::ROWS * G::SEGS;
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
     const int Cin = d.Cin, Cout = d.Cout, H = d.H, W = d.W;
-    const int co_base = (int)(((blockIdx.x >> 3) % (unsigned)(wa.n_ngroups * wa.n_mgroups)) / (unsigned)wa.n_ngroups) * MTW * 16;
+    const int co_base = (int)(((vb >> 3) % (unsigned)(wa.n_ngroups * wa.n_mgroups)) / (unsigned)wa.n_ngroups) * MTW * 16;
     const int g_rows = min(MTW * 16, Cout - co_base);
     float* s_g = smem;                                                       // g_rows rows of CSG (rows beyond Cout: see conv_wgrad_kernel)
     float* s_in = smem + g_rows * CSG;                                       // (NPL + 2) planes
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
 
     // block -> (xcd, slot, column group); the XCD owns a contiguous slice of the tile list, its slots take it round-robin
     const int ngroups = wa.n_ngroups * wa.n_mgroups;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int xcd = vb & 7, q = vb >> 3;
     const int slot = q / ngroups, grp = q - slot * ngroups;
     const int total = d.B * tiles_x * tiles_y;
     const int per = total >> 3, extra = total & 7;
@@ -1112,7 +1115,7 @@ __global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kern
         const int col = n_base + colq;
         if (co_base + row < Cout && col < wa.ncols) slab[(size_t)(co_base + row) * wa.ncols + col] = s_red[idx];
     }
-    side_run_hosted(side, smem);
+    side_run_hosted(side, smem, vb, vgrid);
 }
 
 struct WidePlan { int mtw, ntw, ngroups, mgroups, slots; };
@@ -1135,6 +1138,10 @@ static WidePlan wide_plan(const bnerv_wgrad_desc& d) {
     if (s < 1) s = 1;
     p.slots = s;
     return p;
+}
+template <int IN, int GM2, int MTW, int NTW>
+__global__ __launch_bounds__(256, (MTW * NTW <= 8 ? 3 : 2)) void wgrad_wide_kernel(const WArgs wa, const int slots, const SidePack side) {
+    wgrad_wide_body<IN, GM2, MTW, NTW>(wa, slots, side, (int)blockIdx.x, (int)gridDim.x);
 }
 
 static bool wide_ok(const WArgs& wa) {
@@ -1220,7 +1227,7 @@ constexpr int BW_PIECE = 3 * BW_COPY + 2 * BW_CONST;                          //
 // GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient of an up-conv (conv channel 4c + 2i + j at (y, x) = du[c][2y + i][2x + j]),
 // 3 = shuffled by s = g_s in {3, 5} (conv channel c s^2 + i s + j at (y, x) = du[c][s y + i][s x + j]; strided 4-B loads)
 template <int IN, int SP, int MTW, int GM2>
-__global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const int slots, const int ngroups_n, const int ngroups_m, const SidePack side) {
+__device__ __forceinline__ void wgrad_bfw_body(const WArgs& wa, const int slots, const int ngroups_n, const int ngroups_m, const SidePack& side, const int vb, const int vgrid) {
     constexpr int NS = Split<SP>::NS;
     constexpr bool AFF = (IN == BNERV_IN_AFFINE);
     constexpr int PIECE = BW_PIECE;
@@ -1236,7 +1243,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
     const int tiles_x = (W + 31) >> 5, tiles_y = (H + BW_TH - 1) / BW_TH;
 
     const int ngroups = ngroups_n * ngroups_m;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int xcd = vb & 7, q = vb >> 3;
     const int slot = q / ngroups, grp = q - slot * ngroups;
     const int mg = grp / ngroups_n;
     const int co_base = mg * MTW * 16;
@@ -1544,7 +1551,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const
         const int col = n_base + colq;
         if (co_base + row < Cout && col < wa.ncols) slab[(size_t)(co_base + row) * wa.ncols + col] = s_red[idx];
     }
-    side_run_hosted(side, smem);
+    side_run_hosted(side, smem, vb, vgrid);
 }
 
 struct BwPlan { int mtw, ngroups_n, ngroups_m, slots; };
@@ -1558,6 +1565,11 @@ static int bw_mode() {                                     // BNERV_SPLIT_WIDE =
     }();
     return v;
 }
+template <int IN, int SP, int MTW, int GM2>
+__global__ __launch_bounds__(256, 2) void wgrad_bfw_kernel(const WArgs wa, const int slots, const int ngroups_n, const int ngroups_m, const SidePack side) {
+    wgrad_bfw_body<IN, SP, MTW, GM2>(wa, slots, ngroups_n, ngroups_m, side, (int)blockIdx.x, (int)gridDim.x);
+}
+
 static bool bw_ok(const WArgs& wa) {
     const bnerv_wgrad_desc& d = wa.d;
     if (bw_mode() < 0 || !wa.vec || d.k != 3 || (d.g_s > 3 && d.g_s != 5) || d.g_mode == BNERV_IN_TANHGRAD) return false;
@@ -1802,6 +1814,118 @@ int launch_pair(hipStream_t st, bnerv_conv::KArgs& ka, const WArgs& wa, int* n_w
     BNERV_LAUNCH_CHECK("conv_wgrad_pair");
     return BNERV_OK;
 }
+
+// ---- paired launch, low-resolution form: the data gradient of convs.hip's family (one 4x16 tile x 16 couts per block) next to a wide
+// weight gradient (wgrad_wide / wgrad_bfw bodies) that reads the same incoming gradient.  Below 180x320 each of the two is a launch of
+// 60..240 blocks that lasts 7..12 us whatever its arithmetic (staging latency, one K loop, one epilogue); together they are one such
+// launch.  Blocks [0, n_c8) are the conv's (n_c8 = its block count rounded up to 8, so that the weight gradient's logical XCD of block
+// vb is the physical one), the rest the weight gradient's.
+struct WideRoleArgs { int slots, ngn, ngm; };
+template <int IN, int GM2, int MTW, int NTW>
+struct WideRole {
+    static __device__ __forceinline__ void run(const WArgs& wa, const WideRoleArgs& r, const SidePack& side, int vb, int vgrid) { wgrad_wide_body<IN, GM2, MTW, NTW>(wa, r.slots, side, vb, vgrid); }
+    static size_t lds(const WArgs& wa) {
+        using G = Geo<3>;
+        constexpr int NPL = wgrad_npl<3, NTW>();
+        const int g_rows = wa.d.Cout < MTW * 16 ? wa.d.Cout : MTW * 16;
+        size_t lds_fl = (size_t)g_rows * CSG + (size_t)(NPL + 2) * G::PLANE + 64;
+        if (lds_fl < (size_t)MTW * 16 * CSG) lds_fl = (size_t)MTW * 16 * CSG;
+        if (lds_fl < (size_t)MTW * 16 * NTW * 16) lds_fl = (size_t)MTW * 16 * NTW * 16;
+        return lds_fl * sizeof(float);
+    }
+};
+template <int IN, int SP, int MTW, int GM2>
+struct BfwRole {
+    static __device__ __forceinline__ void run(const WArgs& wa, const WideRoleArgs& r, const SidePack& side, int vb, int vgrid) { wgrad_bfw_body<IN, SP, MTW, GM2>(wa, r.slots, r.ngn, r.ngm, side, vb, vgrid); }
+    static size_t lds(const WArgs&) {
+        constexpr int NS = Split<SP>::NS;
+        size_t lds = (size_t)NS * BW_PIECE + 2 * BW_NPL * sizeof(float);
+        const size_t red = (size_t)MTW * 16 * BW_NTW * 16 * sizeof(float);
+        return lds < red ? red : lds;
+    }
+};
+template <class WR, int CIN, int CEP, int CNQ>
+__global__ __launch_bounds__(256, 2) void small_pair_kernel(const bnerv_convs::SArgs sa, const WArgs wa, const WideRoleArgs r, const int n_c, const int n_c8,
+                                                            const int c_tiles, const int c_groups, const SidePack side) {
+    const int b = (int)blockIdx.x;
+    if (b < n_c8) {
+        if (b >= n_c) return;                              // (padding block)
+        const int q = b / c_tiles;
+        bnerv_convs::conv_small_body<CIN, CEP, CNQ>(sa, b - q * c_tiles, q % c_groups, q / c_groups);
+    } else {
+        WR::run(wa, r, side, b - n_c8, (int)gridDim.x - n_c8);
+    }
+}
+template <class WR, int CIN, int CEP, int CNQ>
+int launch_small_pair(hipStream_t st, const bnerv_convs::SArgs& sa, const WArgs& wa, const WideRoleArgs& r, int n_w) {
+    size_t lds = bnerv_convs::convs_lds_bytes<CNQ>();
+    const size_t lw = WR::lds(wa);
+    if (lw > lds) lds = lw;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_pair_kernel<WR, CIN, CEP, CNQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    const int c_tiles = sa.tiles_x * sa.tiles_y, c_groups = cdiv(sa.d.Cout, 16);
+    const int n_c = c_tiles * c_groups * sa.d.B, n_c8 = (n_c + 7) & ~7;
+    SidePack side;
+    bnerv_side_take(wa.d.ctx, &side, 2 * n_w);
+    hipLaunchKernelGGL((small_pair_kernel<WR, CIN, CEP, CNQ>), dim3(n_c8 + n_w), dim3(256), lds, st, sa, wa, r, n_c, n_c8, c_tiles, c_groups, side);
+    BNERV_LAUNCH_CHECK("small_pair");
+    return BNERV_OK;
+}
+
+// 1: not a pair of this form.  On BNERV_OK *n_slabs is the weight gradient's slab count (the caller queues its reduction).
+static int small_pair_try(hipStream_t st, const bnerv_conv_desc& c, WArgs& wa, int* n_slabs) {
+    const bnerv_wgrad_desc& w = wa.d;
+    { static const bool off = [] { const char* e = getenv("BNERV_PAIR_SMALL"); return e && e[0] == '0'; }(); if (off) return 1; }
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const int cvec = ((c.W % 4 == 0) && al(c.x) && al(c.out) && al(c.out2) && al(c.aux0) && al(c.aux1) && al(c.aux2)) ? 1 : 0;
+    if (!bnerv_convs_shape_ok(c, cvec)) return 1;
+    if (c.ep_mode == BNERV_EP_PLAIN && bnerv_conv_splitk_ws_bytes(&c) != 0) return 1;     // (a split-K layer: its own launches)
+    if (!(w.k == 3 && w.B == c.B && w.H == c.H && w.W == c.W && w.defer_finish && w.ctx && w.ctx == c.ctx)) return 1;
+    bnerv_convs::SArgs sa;
+    sa.d = c;
+    sa.tiles_x = cdiv(c.W, bnerv_convs::STW);
+    sa.tiles_y = cdiv(c.H, bnerv_convs::STH);
+    const int cnq = c.in_mode == BNERV_IN_UNSHUFFLE ? (c.Cin <= 32 ? 8 : 16) : (c.Cin <= 16 ? 4 : 8);
+    WideRoleArgs r{0, 0, 0};
+    int rc = 1;
+    if (wlean_ok(wa)) return 1;                            // (the lean weight gradient pairs with conv4.hip's family)
+#define BNERV_SP(WR, I, E, Q) if (c.in_mode == I && c.ep_mode == E && cnq == Q) rc = launch_small_pair<WR, I, E, Q>(st, sa, wa, r, n_w);
+    if (bw_ok(wa)) {
+        if (bw_mode() != (int)SP_BF16X6) return 1;
+        const BwPlan bp = bw_plan(w);
+        r.slots = bp.slots; r.ngn = bp.ngroups_n; r.ngm = bp.ngroups_m;
+        const int n_w = 8 * bp.slots * bp.ngroups_n * bp.ngroups_m;
+        *n_slabs = 8 * bp.slots;
+        if (w.g_s == 2 && w.in_mode == BNERV_IN_PLAIN && w.g_mode == BNERV_IN_UNSHUFFLE) {          // an up-conv's (dW | d input)
+            if (bp.mtw == 2) { using WR = BfwRole<BNERV_IN_PLAIN, SP_BF16X6, 2, 1>; BNERV_SP(WR, BNERV_IN_UNSHUFFLE, BNERV_EP_PLAIN, 8) BNERV_SP(WR, BNERV_IN_UNSHUFFLE, BNERV_EP_PLAIN, 16) }
+            if (bp.mtw == 3) { using WR = BfwRole<BNERV_IN_PLAIN, SP_BF16X6, 3, 1>; BNERV_SP(WR, BNERV_IN_UNSHUFFLE, BNERV_EP_PLAIN, 16) }
+        } else if (w.g_s == 1 && w.in_mode == BNERV_IN_AFFINE && w.g_mode != BNERV_IN_TANHGRAD) {  // a TAT conv's (dW | d input), 17..32 channels
+            if (bp.mtw == 2) { using WR = BfwRole<BNERV_IN_AFFINE, SP_BF16X6, 2, 0>; BNERV_SP(WR, BNERV_IN_PLAIN, BNERV_EP_DGELU_SAVED, 8) BNERV_SP(WR, BNERV_IN_PLAIN, BNERV_EP_DSIN, 8) }
+        }
+        return rc;
+    }
+    if (wide_ok(wa)) {
+        const WidePlan wp = wide_plan(w);
+        if (!(wp.mtw == 1 && wp.ntw == 8)) return 1;
+        const int ng0 = wa.n_ngroups, mg0 = wa.n_mgroups;
+        wa.n_ngroups = wp.ngroups;
+        wa.n_mgroups = wp.mgroups;
+        r.slots = wp.slots;
+        const int n_w = 8 * wp.slots * wp.ngroups * wp.mgroups;
+        *n_slabs = 8 * wp.slots;
+        if (w.g_s == 1 && w.in_mode == BNERV_IN_AFFINE && w.g_mode != BNERV_IN_TANHGRAD) {         // a TAT conv's (dW | d input), 13..16 channels
+            using WR = WideRole<BNERV_IN_AFFINE, 0, 1, 8>;
+            BNERV_SP(WR, BNERV_IN_PLAIN, BNERV_EP_DGELU_SAVED, 4) BNERV_SP(WR, BNERV_IN_PLAIN, BNERV_EP_DSIN, 4)
+        }
+        if (rc == 1) { wa.n_ngroups = ng0; wa.n_mgroups = mg0; }
+        return rc;
+    }
+#undef BNERV_SP
+    return 1;
+}
 }  // namespace
 
 // Returns BNERV_OK when both were launched together, 1 when the pair is not one this launch takes (the caller then issues
@@ -1812,29 +1936,25 @@ extern "C" int bnerv_conv_wgrad_pair(void* stream, const bnerv_conv_desc* cdp, c
     if (off) return 1;
     bnerv_conv::KArgs ka;
     ka.d = *cdp;
-    const bnerv_conv_desc& c = ka.d;
+    bnerv_conv_desc& c = ka.d;
     WArgs wa;
     wa.d = *wdp;
     const bnerv_wgrad_desc& w = wa.d;
-    // the conv half: a plain-input 12-channel data gradient of conv4.hip's family
-    if (!(c.k == 3 && c.in_mode == BNERV_IN_PLAIN && c.in_s == 1 && c.out_s == 1 && c.x && c.w && c.out && c.B > 0)) return 1;
+    // the conv half: a 3x3 stride-1 data gradient (plain input, or the unshuffle(2) prologue of an up-conv's), epilogue PLAIN / DGELU_SAVED / DSIN
+    if (c.in_mode == BNERV_IN_UNSHUFFLE && c.in_s == 1) c.in_mode = BNERV_IN_PLAIN;
+    if (!(c.k == 3 && c.out_s == 1 && c.x && c.w && c.out && c.B > 0)) return 1;
+    if (!((c.in_mode == BNERV_IN_PLAIN && c.in_s == 1) || (c.in_mode == BNERV_IN_UNSHUFFLE && c.in_s == 2))) return 1;
     if (!(c.ep_mode == BNERV_EP_DGELU_SAVED || c.ep_mode == BNERV_EP_DSIN || c.ep_mode == BNERV_EP_PLAIN)) return 1;
     if (c.ep_mode != BNERV_EP_PLAIN && !(c.aux0 && c.aux1 && c.scale && c.partial)) return 1;
+    if (c.ep_mode == BNERV_EP_DSIN && !c.aux2) return 1;
     if (c.transposed ? !(c.Cout == c.wCi && c.Cin == c.wCo) : !(c.Cout == c.wCo && c.Cin == c.wCi)) return 1;
-    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    ka.tiles_x = cdiv(c.W, bnerv_conv::TW);
-    ka.tiles_y = cdiv(c.H, bnerv_conv::TH);
-    ka.vec = ((c.W % 4 == 0) && al(c.x) && al(c.out) && al(c.aux0) && al(c.aux1) && al(c.aux2)) ? 1 : 0;
-    ka.ksplit = 1;
-    ka.chunks_per_split = 0;
-    ka.magic_tiles = ka.magic_tiles_x = 0;
-    if (!bnerv_q4::q4_shape_ok(ka)) return 1;
-    { static const bool q4off = [] { const char* e = getenv("BNERV_Q4"); return e && e[0] == '0'; }(); if (q4off) return 1; }
-    // the weight-gradient half: the lean kernel's plain / affine 3x3 form on the same image size
-    if (!(w.k == 3 && w.x && w.g && w.dw && w.ws && w.B == c.B && w.H == c.H && w.W == c.W && w.g_s == 1 && w.defer_finish && w.ctx && w.ctx == c.ctx)) return 1;
+    // the weight-gradient half: a deferred 3x3 weight gradient on the same image size and context
+    if (!(w.k == 3 && w.x && w.g && w.dw && w.ws && w.B == c.B && w.H == c.H && w.W == c.W && w.defer_finish && w.ctx && w.ctx == c.ctx)) return 1;
     if (!(w.in_mode == BNERV_IN_PLAIN || w.in_mode == BNERV_IN_AFFINE) || !(w.g_mode == BNERV_IN_PLAIN || w.g_mode == BNERV_IN_UNSHUFFLE)) return 1;
     if (w.in_mode == BNERV_IN_AFFINE && !(w.scale && w.shift)) return 1;
+    if (!(w.g_s == 1 || (w.g_s == 2 && w.g_mode == BNERV_IN_UNSHUFFLE && w.Cout % 4 == 0))) return 1;
     if (w.ws_bytes < bnerv_conv_wgrad_ws_bytes(w.B, w.Cin, w.Cout, w.H, w.W, w.k)) return bnerv_set_error(BNERV_E_WS, "conv_wgrad_pair: weight-gradient workspace too small");
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const Plan p = make_plan(w.B, w.Cin, w.Cout, w.H, w.W, w.k);
     wa.slab = reinterpret_cast<float*>(w.ws);
     wa.tiles_x = cdiv(w.W, TW);
@@ -1843,15 +1963,27 @@ extern "C" int bnerv_conv_wgrad_pair(void* stream, const bnerv_conv_desc* cdp, c
     wa.n_ngroups = p.n_ngroups;
     wa.ncols = w.Cin * 9 + 1;
     wa.vec = ((w.W % 4 == 0) && al(w.x) && al(w.g)) ? 1 : 0;
-    if (!wlean_ok(wa)) return 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int rc = 1, n_w_used = 0;
-#define BNERV_PAIR_CASE(E, I) if (c.ep_mode == E && w.in_mode == I) rc = launch_pair<E, I>(st, ka, wa, &n_w_used);
-    BNERV_PAIR_CASE(BNERV_EP_DGELU_SAVED, BNERV_IN_AFFINE)
-    BNERV_PAIR_CASE(BNERV_EP_DSIN, BNERV_IN_AFFINE)
-    BNERV_PAIR_CASE(BNERV_EP_PLAIN, BNERV_IN_PLAIN)
+    int rc = 1, n_slabs = 0;
+
+    // form 1: conv4.hip's 12-channel family next to the lean weight gradient (roles interleaved per XCD on large layers)
+    ka.tiles_x = cdiv(c.W, bnerv_conv::TW);
+    ka.tiles_y = cdiv(c.H, bnerv_conv::TH);
+    ka.vec = ((c.W % 4 == 0) && al(c.x) && al(c.out) && al(c.aux0) && al(c.aux1) && al(c.aux2)) ? 1 : 0;
+    ka.ksplit = 1;
+    ka.chunks_per_split = 0;
+    ka.magic_tiles = ka.magic_tiles_x = 0;
+    static const bool q4off = [] { const char* e = getenv("BNERV_Q4"); return e && e[0] == '0'; }();
+    if (!q4off && c.in_mode == BNERV_IN_PLAIN && w.g_s == 1 && bnerv_q4::q4_shape_ok(ka) && wlean_ok(wa)) {
+#define BNERV_PAIR_CASE(E, I) if (c.ep_mode == E && w.in_mode == I) rc = launch_pair<E, I>(st, ka, wa, &n_slabs);
+        BNERV_PAIR_CASE(BNERV_EP_DGELU_SAVED, BNERV_IN_AFFINE)
+        BNERV_PAIR_CASE(BNERV_EP_DSIN, BNERV_IN_AFFINE)
+        BNERV_PAIR_CASE(BNERV_EP_PLAIN, BNERV_IN_PLAIN)
 #undef BNERV_PAIR_CASE
+    }
+    // form 2: convs.hip's low-resolution family next to a wide weight gradient
+    if (rc == 1) rc = small_pair_try(st, c, wa, &n_slabs);
     if (rc != BNERV_OK) return rc;
-    bnerv_side_push(w.ctx, st, wa.slab, n_w_used, w.Cout * wa.ncols, wa.ncols, w.dw, w.db);     // the slab reduction rides on a later launch
+    bnerv_side_push(w.ctx, st, wa.slab, n_slabs, w.Cout * wa.ncols, wa.ncols, w.dw, w.db);     // the slab reduction rides on a later launch
     return BNERV_OK;
 }

@@ -358,11 +358,16 @@ class _Conv2dPS(torch.autograd.Function):
         Cout, k = w.shape[0], w.shape[-1]
         dw = torch.empty_like(w)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_b else None
-        _wgrad(x, g, dw, db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s, defer=True)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and k == 3:                 # (dW | dx): one launch where the library pairs them
             dx = torch.empty_like(x)
-            _conv(g, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1)
+            _wgrad_conv_pair(dict(x=x, g=g, dw=dw, db=db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s),
+                             dict(x=g, w=w, bias=None, out=dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1))
+        else:
+            _wgrad(x, g, dw, db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s, defer=True)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _conv(g, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1)
         _flush_deferred(block_end=True)
         return dx, dw, db, None
 
@@ -466,10 +471,10 @@ class _SNeRVBlock(torch.autograd.Function):
         dwu = torch.empty_like(wu)
         dbu = torch.empty(Ct, dtype=torch.float32, device=x.device) if ctx.has_bu else None
         dx = None
-        if ctx.needs_input_grad[0] and s == 1 and k == 3:      # (dW_block | d block conv): one launch where the library pairs them
+        if ctx.needs_input_grad[0] and k == 3:      # (dW_block | d block conv): one launch where the library pairs them
             dx = torch.empty_like(x)
-            _wgrad_conv_pair(dict(x=x, g=du, dw=dwu, db=dbu, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=1),
-                             dict(x=du, w=wu, bias=None, out=dx, B=B, Cin=Ct, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_PLAIN, ep_mode=L.EP_PLAIN, transposed=1))
+            _wgrad_conv_pair(dict(x=x, g=du, dw=dwu, db=dbu, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s),
+                             dict(x=du, w=wu, bias=None, out=dx, B=B, Cin=Ct, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1))
         else:
             _wgrad(x, du, dwu, dbu, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s, defer=True)
             if ctx.needs_input_grad[0]:
