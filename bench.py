@@ -129,12 +129,13 @@ def step_kernel_roofline(dev, Cc, H, W, reps=20):
         K2s  conv0 forward   [affine -> 3x3 -> bias -> gelu, gelu']      x2 per step
         K3s  conv1 forward   [affine -> 3x3 -> bias -> + residual]       x2
         K1   block conv      [3x3 -> bias -> sin, cos]                   x1
-        dK3s conv1 data grad [3x3^T -> * gelu' * (1+s) , channel sums]   x2
-        dK2s conv0 data grad [3x3^T -> (dout + . (1+s)) * cos, sums]     x2
-        wA   weight gradient with the affine prologue                    x4
-        wP   weight gradient, plain input                                x1
-    Algorithmic work per launch: flops = 2 * Cc*Cc*9 * H*W ; bytes = activations once in + once out (+ each auxiliary tensor
-    the mode reads or writes) + weights, 4 B each.  At Cc = 12 the plain modes sit just above the ridge (157.3 TF / 8 TB/s =
+        wA|dK3s  conv1 weight gradient (affine prologue) | conv1 data grad [3x3^T -> * gelu' * (1+s), channel sums]   x2
+        wA|dK2s  conv0 weight gradient (affine prologue) | conv0 data grad [3x3^T -> (dout + . (1+s)) * cos, sums]    x2
+        wP|dK1   block-conv weight gradient (plain)      | block-conv data grad [3x3^T]                               x1
+    (the backward launches are PAIRS since round 3: the two halves read the same gradient and run as interleaved roles of one grid,
+    ops._wgrad_conv_pair -- a pair is two convolutions' flops and every distinct tensor once).
+    Algorithmic work per launch: flops = 2 * Cc*Cc*9 * H*W per convolution; bytes = activations once in + once out (+ each auxiliary
+    tensor the mode reads or writes) + weights, 4 B each.  At Cc = 12 the plain modes sit just above the ridge (157.3 TF / 8 TB/s =
     19.7 flop/B) and the data gradients with 3-4 auxiliary planes below it, so every row also carries its own bound
     (max of flops / MFMA peak and bytes / HBM peak) and `frac_of_own_roof`.  `achieved` of the family = sum(flops) / sum(time)
     with the per-step launch counts as weights against the dense fp32 MFMA peak; the slowest member is reported next to it."""
@@ -155,17 +156,23 @@ def step_kernel_roofline(dev, Cc, H, W, reps=20):
         ("K2s conv0 fwd: affine->conv->bias->gelu,gelu'", 2, 3, lambda: ops._conv(x, w, b, out, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=sc, shift=sh, out2=out2, **kw)),
         ("K3s conv1 fwd: affine->conv->bias->+res", 2, 3, lambda: ops._conv(h, w, b, out, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_RES, scale=sc, shift=sh, aux0=y0, **kw)),
         ("K1 block conv fwd: conv->bias->sin,cos", 1, 3, lambda: ops._conv(x, w, b, out, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_SIN, out2=out2, **kw)),
-        ("dK3s conv1 dgrad: conv^T->dgelu(saved)+sums", 2, 4, lambda: ops._conv(dout, w, None, out, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU_SAVED, transposed=1, aux0=gp, aux1=h, scale=sc, defer=True, **kw)),
-        ("dK2s conv0 dgrad: conv^T->dsin+sums", 2, 5, lambda: ops._conv(dout, w, None, out, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN, transposed=1, aux0=y0, aux1=dout, aux2=c0, scale=sc, defer=True, **kw)),
-        ("wA weight grad, affine prologue", 4, 2, lambda: ops._wgrad(h, dout, dw, db, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=sc, shift=sh, defer=True, **kw)),
-        ("wP weight grad, plain", 1, 2, lambda: ops._wgrad(x, dout, dw, db, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, defer=True, **kw)),
+        ("wA|dK3s conv1 bwd pair: weight grad (affine) | conv^T->dgelu(saved)+sums", 2, 4, lambda: ops._wgrad_conv_pair(
+            dict(x=h, g=dout, dw=dw, db=db, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=sc, shift=sh, **kw),
+            dict(x=dout, w=w, bias=None, out=out, in_mode=L.IN_PLAIN, ep_mode=L.EP_DGELU_SAVED, transposed=1, aux0=gp, aux1=h, scale=sc, **kw))),
+        ("wA|dK2s conv0 bwd pair: weight grad (affine) | conv^T->dsin+sums", 2, 5, lambda: ops._wgrad_conv_pair(
+            dict(x=y0, g=dout, dw=dw, db=db, in_mode=L.IN_AFFINE, g_mode=L.IN_UNSHUFFLE, scale=sc, shift=sh, **kw),
+            dict(x=dout, w=w, bias=None, out=out, in_mode=L.IN_PLAIN, ep_mode=L.EP_DSIN, transposed=1, aux0=y0, aux1=gp, aux2=c0, scale=sc, **kw))),
+        ("wP|dK1 block conv bwd pair: weight grad (plain) | conv^T", 1, 3, lambda: ops._wgrad_conv_pair(
+            dict(x=x, g=dout, dw=dw, db=db, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=1, **kw),
+            dict(x=dout, w=w, bias=None, out=out, in_mode=L.IN_PLAIN, ep_mode=L.EP_PLAIN, transposed=1, **kw))),
     ]
-    flops = 2.0 * Cc * Cc * 9 * H * W
-    rows, tf, tt = [], 0.0, 0.0
+    flops1 = 2.0 * Cc * Cc * 9 * H * W
+    rows, tf, tt, nl = [], 0.0, 0.0, 0
     troof = 0.0
     for name, n, planes, fn in cases:
         t = _time_launches(fn, reps)       # (slab reductions are deferred exactly as in the step: they ride on the following launch)
         ops._flush_deferred()
+        flops = flops1 * (2 if "pair" in name else 1)      # a pair is two convolutions
         ach = flops / t / 1e12
         nbytes = planes * plane + wb
         t_m, t_h = flops / (PEAK_FP32_MFMA_TFLOPS * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
@@ -174,6 +181,7 @@ def step_kernel_roofline(dev, Cc, H, W, reps=20):
                      "frac_of_own_roof": round(max(t_m, t_h) / t, 4)})
         tf += n * flops
         tt += n * t
+        nl += n
         troof += n * max(t_m, t_h)
     ach = tf / tt / 1e12
     slow = min(rows, key=lambda r: r["achieved"])
@@ -202,10 +210,10 @@ def step_kernel_roofline(dev, Cc, H, W, reps=20):
         # f32-equivalent flops is the dense bf16 peak / 6; `peak` / `frac` stay priced against the fp32 MFMA peak of the arithmetic type
         pipe = {"instruction": "v_mfma_f32_16x16x32_bf16, 6 products per f32 product (bf16x6)", "peak": round(PEAK_BF16_MFMA_TFLOPS / 6, 1),
                 "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS / 6), 4), "unit": "TFLOP/s (f32-equivalent)"}
-    return {"kernel": f"final-stage conv family of the step ({Cc}->{Cc} 3x3 @{H}x{W}): flop-weighted over the 14 launches below", "bound": "mfma", "split_pipe": pipe,
+    return {"kernel": f"final-stage conv family of the step ({Cc}->{Cc} 3x3 @{H}x{W}): flop-weighted over the {nl} launches of a step listed below", "bound": "mfma", "split_pipe": pipe,
             "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
             "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-            "avg_launch_us": round(tt / 14 * 1e6, 2), "flops_per_launch": flops, "bytes_per_launch": k2s["bytes_per_launch"],
+            "avg_launch_us": round(tt / nl * 1e6, 2), "flops_per_launch": flops1, "bytes_per_launch": k2s["bytes_per_launch"],
             "slowest": {"kernel": slow["kernel"], "achieved": slow["achieved"], "frac": slow["frac"]},
             "frac_of_per_kernel_roof": round(troof / tt, 4), "kernels": rows}
 

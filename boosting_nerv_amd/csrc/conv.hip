@@ -27,6 +27,8 @@ namespace bnerv_conv { struct KArgs; }
 int bnerv_conv4_try(hipStream_t st, bnerv_conv::KArgs& ka);   // conv4.hip: 1 = not that family's layer
 int bnerv_convs_try(hipStream_t st, const bnerv_conv_desc& d, int vec, int ksplit);   // convs.hip (low-resolution stages): 1 = not that family's layer
 bool bnerv_convs_shape_ok(const bnerv_conv_desc& d, int vec);
+int bnerv_stem_dgrad_try(hipStream_t st, const bnerv_conv_desc& d);       // stem.hip (images of <= 256 pixels, long K): 1 = not that layer
+size_t bnerv_stem_dgrad_ws_bytes(const bnerv_conv_desc& d);
 int bnerv_convs_tiles(int H, int W);
 
 namespace {
@@ -1669,7 +1671,9 @@ __global__ __launch_bounds__(256) void head1x1_dgrad_kernel(const bnerv_conv_des
 extern "C" size_t bnerv_conv_splitk_ws_bytes(const bnerv_conv_desc* dp) {
     if (!dp || dp->B <= 0 || dp->Cin <= 0 || dp->Cout <= 0 || dp->H <= 0 || dp->W <= 0) return 0;
     const SplitPlan p = plan_split(*dp);
-    return p.ksplit > 1 ? (size_t)p.ksplit * dp->B * dp->Cout * dp->H * dp->W * sizeof(float) : 0;
+    const size_t a = p.ksplit > 1 ? (size_t)p.ksplit * dp->B * dp->Cout * dp->H * dp->W * sizeof(float) : 0;
+    const size_t b = bnerv_stem_dgrad_ws_bytes(*dp);       // the stem stage's data gradient (stem.hip) keeps one slab per 8 input channels
+    return a > b ? a : b;
 }
 
 extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
@@ -1712,6 +1716,10 @@ extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
         hipLaunchKernelGGL(head1x1_dgrad_kernel, dim3(cdiv(hw4, 256), d.B), dim3(256), 0, st, d, hw4);
         BNERV_LAUNCH_CHECK("head1x1_dgrad");
         return BNERV_OK;
+    }
+    if (d.ep_mode == BNERV_EP_PLAIN && d.partial != nullptr) {            // tiny image, long K (the stem up-conv's data gradient)
+        const int rs = bnerv_stem_dgrad_try(st, d);
+        if (rs != 1) return rs;
     }
     {   // the low-resolution stages (convs.hip) first: small images, <= 32 input channels
         const int rs = bnerv_convs_try(st, d, ka.vec, ka.ksplit);

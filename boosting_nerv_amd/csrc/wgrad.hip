@@ -21,6 +21,7 @@
 #include "conv4_body.h"     // the 4x4x1 conv body: paired conv + weight-gradient launches (bnerv_conv_wgrad_pair, bottom of this file)
 #include "convs_body.h"     // the low-resolution conv body, for the same
 bool bnerv_convs_shape_ok(const bnerv_conv_desc& d, int vec);     // convs.hip
+int bnerv_stem_wgrad_try(hipStream_t st, const bnerv_wgrad_desc& d);   // stem.hip (images of <= 256 pixels): 1 = not that layer
 #include <stdlib.h>
 #include <type_traits>
 #include <string.h>
@@ -1747,6 +1748,10 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     wa.vec = ((d.W % 4 == 0) && al(d.x) && al(d.g) && al(d.gaux)) ? 1 : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    {   // the stem stage (an image of <= 256 pixels, many output channels): written directly, no slabs
+        const int rs = bnerv_stem_wgrad_try(st, d);
+        if (rs != 1) return rs;
+    }
     int rc = -1, n_slabs = p.nsplit;
     if (wlean_ok(wa)) {
         rc = d.k == 1 ? launch_wlean_modes<1>(st, wa) : launch_wlean_modes<3>(st, wa);
