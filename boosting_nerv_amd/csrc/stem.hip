@@ -25,18 +25,37 @@ constexpr int WT_MAX_XFLOATS = 30000;                    // padded input image i
 constexpr int DT_CS = 8;                                 // data gradient: input channels per block (K = 72 = 18 steps)
 constexpr int DT_KSTEPS = DT_CS * 9 / 4;
 
-__device__ __forceinline__ int g_index(int b, int co, int y, int x, int Cout, int H, int W, int s) {
-    // conv-space channel co at (y, x) of a gradient stored pixel-shuffled by s: [B][Cout / s^2][H s][W s]
-    const int ss = s * s, cf = co / ss, r = co - cf * ss, i = r / s, j = r - i * s;
-    return (((b * (Cout / ss) + cf) * (H * s)) + y * s + i) * (W * s) + x * s + j;
-}
 __host__ __device__ inline int row_stride4(int n) {       // >= n, == 4 (mod 32): 16 rows x 4 k-lanes spread over the banks
     int v = (n + 3) & ~3;
     v += ((4 - v) % 32 + 32) % 32;
     return v;
 }
 
+// n independent (load, LDS store) pairs spread over the block, U loads in flight per thread before the first store (a plain loop waits for
+// each load before its store: 20+ serialised round trips per block)
+template <int U, class LD, class ST>
+__device__ __forceinline__ void staged(const int n, LD ld, ST st) {
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = i0 + u * 256; v[u] = i < n ? ld(i) : 0.f; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = i0 + u * 256; if (i < n) st(i, v[u]); }
+    }
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 struct WTArgs { const float* x; const float* g; float* dw; float* db; int B, Cin, Cout, H, W, s; };
+
+// base of conv-space channel co in a gradient stored pixel-shuffled by s ([B][C / s^2][H s][W s]); pixel (y, x) adds (y s)(W s) + x s
+__device__ __forceinline__ int g_base(int b, int co, int C, int H, int W, int s) {
+    const int ss = s * s, cf = co / ss, r = co - cf * ss, i = r / s, j = r - i * s;
+    return ((b * (C / ss) + cf) * (H * s) + i) * (W * s) + j;
+}
 
 __global__ __launch_bounds__(256) void wgrad_tiny_kernel(const WTArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -44,7 +63,8 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(const WTArgs a) {
     const int HWp = (HW + 3) & ~3, HWs = row_stride4(HW);
     float* s_x = smem;                                   // [Cin][PL] zero border
     float* s_g = s_x + ((a.Cin * PL + 3) & ~3);          // [16][HWs]
-    int* s_px = reinterpret_cast<int*>(s_g + 16 * HWs);  // [HWp]: pixel -> offset in a padded plane
+    int* s_px = reinterpret_cast<int*>(s_g + 16 * HWs);  // [HWp]: pixel -> offset in a padded plane (of its interior origin)
+    int* s_go = s_px + HWp;                              // [HWp]: pixel -> offset in the shuffled gradient plane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const int co_base = blockIdx.x * 16, nW = a.Cin * 9;
     int coloff[WT_NTW];
@@ -54,32 +74,63 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(const WTArgs a) {
         const int ci = col / 9, tap = col - ci * 9, dy = tap / 3, dx = tap - dy * 3;
         coloff[t] = col < nW ? ci * PL + dy * RS + dx : 0;                       // (columns beyond the matrix: any valid address, never stored)
     }
-    for (int i = tid; i < HWp; i += 256) s_px[i] = i < HW ? (i / W) * RS + (i % W) : 0;
+    for (int i = tid; i < HWp; i += 256) {
+        const int y = i / W, x = i - y * W;
+        s_px[i] = i < HW ? y * RS + x : 0;
+        s_go[i] = i < HW ? (y * a.s) * (W * a.s) + x * a.s : 0;
+    }
+    for (int i = tid; i < a.Cin * PL; i += 256) s_x[i] = 0.f;                    // the borders stay zero for every sample
+    for (int i = tid; i < 16 * HWs; i += 256) s_g[i] = 0.f;                      // ... and so do the padding pixels / rows beyond Cout
+    __syncthreads();
     f32x4 acc[WT_NTW];
 #pragma unroll
     for (int t = 0; t < WT_NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbs = 0.f;
+    const unsigned hw_magic = (unsigned)(((1ull << 32) + HW - 1) / HW);          // n / HW for n < 2^16 (HW <= 256)
+    const int gm = tid >> 4, gp0 = tid & 15, gco = co_base + gm;                 // gradient staging: thread -> (row, pixels gp0 + 16 j)
     for (int b = 0; b < a.B; ++b) {
         if (b) __syncthreads();
-        for (int i = tid; i < a.Cin * PL; i += 256) {
-            const int c = i / PL, r = i - c * PL, yy = r / RS - 1, xx = r % RS - 1;
-            s_x[i] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? a.x[((size_t)(b * a.Cin + c) * H + yy) * W + xx] : 0.f;
-        }
-        for (int i = tid; i < 16 * HWs; i += 256) {
-            const int m = i / HWs, p = i - m * HWs, co = co_base + m;
-            s_g[i] = (p < HW && co < a.Cout) ? a.g[g_index(b, co, p / W, p % W, a.Cout, H, W, a.s)] : 0.f;
-        }
-        __syncthreads();
-        for (int st = 0; st < HWp / 4; ++st) {
-            const float av = s_g[li * HWs + 4 * st + kq];
-            const int po = s_px[4 * st + kq];
+        const float* xb = a.x + (size_t)b * a.Cin * HW;
+        float gv[16];                                        // the block's 16 gradient rows: every load in flight before the input image's
+        const float* gr = a.g + (gco < a.Cout ? g_base(b, gco, a.Cout, H, W, a.s) : 0);
 #pragma unroll
-            for (int t = 0; t < WT_NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s_x[coloff[t] + po], acc[t], 0, 0, 0);
+        for (int u = 0; u < 16; ++u) { const int p = gp0 + 16 * u; gv[u] = (gco < a.Cout && p < HW) ? gr[s_go[p]] : 0.f; }
+        staged<20>(a.Cin * HW, [&](int i) { return xb[i]; },
+                   [&](int i, float v) { const int c = (int)__umulhi((unsigned)i, hw_magic), p = i - c * HW; s_x[c * PL + RS + 1 + s_px[p]] = v; });
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int p = gp0 + 16 * u; if (p < HW) s_g[gm * HWs + p] = gv[u]; }
+        __syncthreads();
+        {   // K loop: the operands of step st + 1 (and the pixel offset of st + 2) are loaded under the products of step st
+            const int nst = HWp / 4;
+            const float* ga = s_g + li * HWs + kq;
+            const int* pq = s_px + kq;
+            float av = ga[0], bv[WT_NTW];
+            int po = pq[0];
+#pragma unroll
+            for (int t = 0; t < WT_NTW; ++t) bv[t] = s_x[coloff[t] + po];
+            po = pq[nst > 1 ? 4 : 0];
+            for (int st = 0; st < nst; ++st) {
+                const int s1 = st + 1 < nst ? st + 1 : st, s2 = st + 2 < nst ? st + 2 : nst - 1;
+                const float av_n = ga[4 * s1];
+                float bn[WT_NTW];
+#pragma unroll
+                for (int t = 0; t < WT_NTW; ++t) bn[t] = s_x[coloff[t] + po];
+                const int po_n = pq[4 * s2];
+#pragma unroll
+                for (int t = 0; t < WT_NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
+                av = av_n; po = po_n;
+#pragma unroll
+                for (int t = 0; t < WT_NTW; ++t) bv[t] = bn[t];
+            }
         }
-        if (blockIdx.y == 0 && tid < 16) {                   // bias gradient: the row sums of g, pixels in order
-            float s = 0.f;
-            for (int p = 0; p < HW; ++p) s += s_g[tid * HWs + p];
-            dbs += s;
+        if (blockIdx.y == 0) {                               // bias gradient: the row sums of g (wave w: rows 4w .. 4w + 3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sm = 0.f;
+                for (int p = lane; p < HW; p += 64) sm += s_g[(wave * 4 + r) * HWs + p];
+                sm = wave_sum_f(sm);
+                if (lane == r) dbs += sm;
+            }
         }
     }
 #pragma unroll
@@ -92,7 +143,7 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(const WTArgs a) {
             if (co < a.Cout) a.dw[(size_t)co * nW + col] = acc[t][e];
         }
     }
-    if (blockIdx.y == 0 && tid < 16 && a.db && co_base + tid < a.Cout) a.db[co_base + tid] = dbs;
+    if (blockIdx.y == 0 && lane < 4 && a.db && co_base + wave * 4 + lane < a.Cout) a.db[co_base + wave * 4 + lane] = dbs;
 }
 
 struct DTArgs { const float* g; const float* w; float* slab; int B, Cin, Cout, H, W, s; };   // conv-space: Cin = channels of g, Cout = channels of dx
@@ -106,12 +157,19 @@ __global__ __launch_bounds__(256) void dgrad_tiny_kernel(const DTArgs a) {
     float* s_g = smem;                                   // [DT_CS][PL] zero border
     float* s_w = s_g + ((DT_CS * PL + 3) & ~3);          // [DT_CS][Cout][9] as stored (w[c][n][tap]); rows beyond Cin zero
     int* s_px = reinterpret_cast<int*>(s_w + ((DT_CS * NW + 3) & ~3));      // [MT * 16]
+    int* s_go = s_px + MT * 16;                          // [MT * 16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const int c0 = blockIdx.x * DT_CS;
-    for (int i = tid; i < MT * 16; i += 256) s_px[i] = i < HW ? (i / W) * RS + (i % W) : 0;
-    for (int i = tid; i < DT_CS * NW; i += 256) {
-        const int c = c0 + i / NW;
-        s_w[i] = c < a.Cin ? a.w[(size_t)c0 * NW + i] : 0.f;
+    for (int i = tid; i < MT * 16; i += 256) {
+        const int y = i / W, x = i - y * W;
+        s_px[i] = i < HW ? y * RS + x : 0;
+        s_go[i] = i < HW ? (y * a.s) * (W * a.s) + x * a.s : 0;
+    }
+    for (int i = tid; i < DT_CS * PL; i += 256) s_g[i] = 0.f;
+    {
+        const int nvalid = (min(a.Cin, c0 + DT_CS) - c0) * NW;          // rows beyond Cin stay zero
+        const float* wb = a.w + (size_t)c0 * NW;
+        staged<12>(DT_CS * NW, [&](int i) { return i < nvalid ? wb[i] : 0.f; }, [&](int i, float v) { s_w[i] = v; });
     }
     // per-lane K offsets: k = 4 st + kq = (c_local, tap); A reads g[c_local][p + tap], B reads w[c_local][n][8 - tap]
     int ka[DT_KSTEPS], kb[DT_KSTEPS];
@@ -124,11 +182,16 @@ __global__ __launch_bounds__(256) void dgrad_tiny_kernel(const DTArgs a) {
     int nb[NTN];
 #pragma unroll
     for (int n = 0; n < NTN; ++n) nb[n] = min(n * 16 + li, a.Cout - 1) * 9;        // (channels beyond Cout: a valid address, never stored)
+    const int gc = tid >> 5, gp0 = tid & 31;                                      // gradient staging: thread -> (local channel, pixels gp0 + 32 j)
     for (int b = 0; b < a.B; ++b) {
         __syncthreads();
-        for (int i = tid; i < DT_CS * PL; i += 256) {
-            const int cl = i / PL, r = i - cl * PL, yy = r / RS - 1, xx = r % RS - 1, c = c0 + cl;
-            s_g[i] = (c < a.Cin && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? a.g[g_index(b, c, yy, xx, a.Cin, H, W, a.s)] : 0.f;
+        if (c0 + gc < a.Cin) {
+            const float* gr = a.g + g_base(b, c0 + gc, a.Cin, H, W, a.s);
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int p = gp0 + 32 * u; v[u] = p < HW ? gr[s_go[p]] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int p = gp0 + 32 * u; if (p < HW) s_g[gc * PL + RS + 1 + s_px[p]] = v[u]; }
         }
         __syncthreads();
         float* out = a.slab + ((size_t)blockIdx.x * a.B + b) * a.Cout * HW;
@@ -173,7 +236,7 @@ int bnerv_stem_wgrad_try(hipStream_t st, const bnerv_wgrad_desc& d) {
     if ((size_t)d.Cin * PL > WT_MAX_XFLOATS || d.Cout < 64) return 1;          // (few output channels: the tiled kernels' split over pixels is as good)
     if ((size_t)d.B * (d.Cin > d.Cout ? d.Cin : d.Cout) * d.H * d.W >= (size_t)1 << 30) return 1;
     const int HW = d.H * d.W, HWp = (HW + 3) & ~3;
-    const size_t lds = ((size_t)((d.Cin * PL + 3) & ~3) + 16 * (size_t)row_stride4(HW) + HWp) * sizeof(float);
+    const size_t lds = ((size_t)((d.Cin * PL + 3) & ~3) + 16 * (size_t)row_stride4(HW) + 2 * HWp) * sizeof(float);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tiny_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -203,7 +266,7 @@ size_t bnerv_stem_dgrad_ws_bytes(const bnerv_conv_desc& d) {
 int bnerv_stem_dgrad_try(hipStream_t st, const bnerv_conv_desc& d) {
     if (!stem_switch() || !stem_dgrad_shape(d) || !d.partial) return 1;
     const int PL = (d.H + 2) * (d.W + 2), NW = d.Cout * 9, MT = cdiv(d.H * d.W, 16);
-    const size_t lds = ((size_t)((DT_CS * PL + 3) & ~3) + (size_t)((DT_CS * NW + 3) & ~3) + MT * 16) * sizeof(float);
+    const size_t lds = ((size_t)((DT_CS * PL + 3) & ~3) + (size_t)((DT_CS * NW + 3) & ~3) + 2 * MT * 16) * sizeof(float);
     DTArgs a{d.x, d.w, d.partial, d.B, d.Cin, d.Cout, d.H, d.W, d.in_mode == BNERV_IN_UNSHUFFLE ? d.in_s : 1};
     const int nblk = cdiv(d.Cin, DT_CS);
     if (d.Cout <= 32) hipLaunchKernelGGL(dgrad_tiny_kernel<2>, dim3(nblk), dim3(256), lds, st, a);
