@@ -413,6 +413,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group(backend="gloo" if share else "nccl", init_method="env://", world_size=world, rank=rank)
+    # Test hook (never set by the driver): BNERV_BENCH_FORCE_BUCKET=1 runs the N = 1 bench through the multi-GPU step (bucket gather ->
+    # RCCL all-reduce on a 1-rank group -> scatter, captured in the step graph) -- the single-GPU cost of that path, with one or two
+    # bucket segments (BNERV_DP_BUCKETS), is the only part of the N > 1 step a 1-GPU box can measure.
+    force_bucket = world == 1 and os.environ.get("BNERV_BENCH_FORCE_BUCKET", "0") == "1"
+    if force_bucket:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
 
     from boosting_nerv_amd.dp import shard_indices
     from boosting_nerv_amd.engine import TrainStep
@@ -434,7 +441,7 @@ def main():
     takes_image = "HNeRV" in args.model
     per_gpu_batch = 1
     step = TrainStep(model, opt, args.loss, takes_image, (per_gpu_batch, 3, r["h"], r["w"]), dev, use_graph=not a.no_graph,
-                     warmup_eager=3, world_size=world)
+                     warmup_eager=3, world_size=world, force_bucket=force_bucket)
     args.epochs = 300
     n_iter = len(keep)
 

@@ -17,7 +17,7 @@ from .dp import GradBucket
 
 class TrainStep:
     def __init__(self, model, optimizer, loss_type, takes_image, batch_shape, device, use_graph=True, warmup_eager=3,
-                 process_group=None, world_size=1, clip_max_norm=0.0, force_bucket=False):
+                 process_group=None, world_size=1, clip_max_norm=0.0, force_bucket=False, dp_buckets=None):
         self.model, self.opt, self.loss_type = model, optimizer, loss_type
         self.takes_image = takes_image                       # HNeRV_Boost consumes the frame; NeRV/ENeRV the frame index
         self.dev = device
@@ -35,7 +35,16 @@ class TrainStep:
         self.world = world_size
         # force_bucket: run the multi-GPU code path (bucket gather -> RCCL all-reduce -> scatter, two graphs) on a 1-rank
         # group, so the path the scaling runs take can be tested on a single-GPU box
-        self.bucket = GradBucket(model.parameters(), process_group, force=force_bucket) if (world_size > 1 or force_bucket) else None
+        # dp_buckets == 2 (or BNERV_DP_BUCKETS=2): the bucket in two segments -- the decoder layers' gradients start their all-reduce on a
+        # side stream from an autograd hook at the decoder / stem boundary, next to the rest of the backward (dp.GradBucket); needs a
+        # model that names its late parameters and calls the hook (model_nerv.NeRV_Boost).  Default 1: see DESIGN section 5.
+        import os as _os
+        nb = int(dp_buckets if dp_buckets is not None else _os.environ.get("BNERV_DP_BUCKETS", "1"))
+        late = model.dp_late_parameters() if (nb == 2 and hasattr(model, "dp_late_parameters")) else None
+        self.bucket = GradBucket(model.parameters(), process_group, force=force_bucket, late_params=late) if (world_size > 1 or force_bucket) else None
+        self._early_ok = True                                # False while a graph that cannot hold the collective is being captured
+        if self.bucket is not None and self.bucket.two:
+            model.dp_hook = self._dp_hook
         self.params = [p for p in model.parameters() if p.requires_grad]
         self._fetching = False                               # inside step_frame(): the step starts with the frame fetch
         self._wplan_entries = 0                              # entries of the capture stream context's weight-fragment plan
@@ -109,9 +118,11 @@ class TrainStep:
         lib = L.load()
         with torch.cuda.stream(self._cap_stream), L.use_ctx(self._cap_ctx) as c:
             L.check(lib.bnerv_ctx_wplan_record(c.handle), "bnerv_ctx_wplan_record")
+            early_ok, self._early_ok = self._early_ok, False     # (the recording pass exchanges nothing)
             try:
                 self._fwd_bwd()
             finally:
+                self._early_ok = early_ok
                 n = lib.bnerv_ctx_wplan_freeze(c.handle)
             if n < 0:
                 L.check(n, "bnerv_ctx_wplan_freeze")
@@ -119,10 +130,19 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
 
+    def _dp_hook(self, grad):
+        """Autograd hook on the stem output (two buckets): the decoder layers' gradients are complete once their deferred slab reductions
+        have run -- flush them, then start the early segment's all-reduce."""
+        if self._early_ok:
+            from . import ops
+            ops._flush_deferred(force=True)
+            self.bucket.exchange_early()
+        return None
+
     def _eager(self, prepared=False):
         self._fwd_bwd()
         if self.bucket is not None:
-            self.bucket.allreduce_mean()
+            self.bucket.finish()
         if self.clip_max_norm > 0:
             torch.nn.utils.clip_grad_norm_(self.params, self.clip_max_norm)
         if not prepared:
@@ -163,7 +183,9 @@ class TrainStep:
     def _capture_in_ctx(self, pool):
         import os
         import torch.distributed as dist
+        self._early_ok = False
         self._record_wplan()
+        self._early_ok = True
         cap = dict(pool=pool, stream=self._cap_stream)
         if self.bucket is None:
             with torch.cuda.graph(self.graph_a, **cap):
@@ -185,9 +207,9 @@ class TrainStep:
         if backend == "nccl" and os.environ.get("BNERV_DP_INGRAPH", "1") != "0":
             try:
                 with torch.cuda.graph(self.graph_a, **cap):
-                    head()
-                    dist.all_reduce(self.bucket.bucket, op=dist.ReduceOp.SUM, group=self.bucket.group)
-                    tail()
+                    self._planned_fwd_bwd()                   # (two buckets: the hook starts the early segment's all-reduce in here)
+                    self.bucket.finish()                      # gather -> all-reduce -> [join] -> scatter
+                    self.opt.launch_step()
                 self.collective_in_graph = True
                 return
             except Exception as e:                        # capture of the collective is not available on this stack: two graphs
@@ -196,6 +218,8 @@ class TrainStep:
                 torch.cuda.synchronize()
                 self.graph_a = torch.cuda.CUDAGraph()
         self.collective_in_graph = False
+        self._early_ok = False                              # graph A cannot hold a collective: one exchange between the two graphs
+        self.bucket._early_inflight = False
         with torch.cuda.graph(self.graph_a, **cap):
             head()
         self.graph_b = torch.cuda.CUDAGraph()

@@ -103,6 +103,17 @@ def decoder_layers_forward(layers, output, t_embed, out_list):
 
 class NeRV_Boost(_CEMHooks, nn.Module):
     lazy_flush_ok = True     # every reader of a deferred slab reduction in this model's backward is an operator of this package (engine.TrainStep)
+    dp_hook = None           # engine.TrainStep with two gradient buckets: called with d(loss)/d(stem output), i.e. after the decoder's backward
+
+    def dp_late_parameters(self):
+        """Parameters whose gradients the backward produces AFTER the decoder layers': the stem MLP (74 % of the bytes) and every MLP fed
+        by the time embedding (stem_t, the TAT modulation convs) -- their grouped dense backward runs last."""
+        from .model_blocks import SFTLayer
+        late = list(self.stem.parameters()) + list(self.stem_t.parameters())
+        for m in self.modules():
+            if isinstance(m, SFTLayer):
+                late += list(m.parameters())
+        return late
     def __init__(self, expansion=1, args=None):
         super().__init__()
         self.encoder = nn.Identity()
@@ -136,6 +147,8 @@ class NeRV_Boost(_CEMHooks, nn.Module):
         t_embed = self.pe_t(input[:, None], round_to_f32=True)         # pe_t(input[:, None].float()) without the conversion launch
         output, t_embed = mlp_pair_forward([self.stem, self.stem_t], [t_embed, t_embed])
         output = output.view(output.size(0), self.fc_dim, self.fc_h, self.fc_w)
+        if self.dp_hook is not None and output.requires_grad:
+            output.register_hook(self.dp_hook)             # fires when every decoder layer's backward has run (engine.TrainStep, two buckets)
         out_list = []
         output = decoder_layers_forward(self.layers, output, t_embed, out_list)
         img_out = head_out(self.head_layer, output, self.out_bias)

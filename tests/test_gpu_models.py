@@ -566,8 +566,9 @@ def test_smoke_entry():
 
 def test_dp_step_path_on_one_rank_group():
     """The multi-GPU step executed on a 1-rank NCCL(=RCCL) group, in both forms -- ONE graph with the all-reduce captured inside,
-    and graph A [fwd,loss,bwd,bucket gather] -> eager all-reduce -> graph B [scatter, Adan]: each must reproduce the single-GPU
-    trajectory exactly (mean over 1 rank is the identity)."""
+    and graph A [fwd,loss,bwd,bucket gather] -> eager all-reduce -> graph B [scatter, Adan] -- and with the bucket in one or two
+    segments (two: the decoder layers' all-reduce forked onto a side stream from the autograd hook at the stem boundary, joined before
+    the scatter; still one graph): each must reproduce the single-GPU trajectory exactly (mean over 1 rank is the identity)."""
     import os
     import torch.distributed as dist
     from boosting_nerv_amd.engine import TrainStep
@@ -585,12 +586,15 @@ def test_dp_step_path_on_one_rank_group():
         frames = torch.stack([vid.frame(i) for i in range(3)]).to(DEV)
         norm = torch.tensor([(i + 1) / 3 for i in range(3)], dtype=torch.float64, device=DEV)
         results = []
-        for force, ingraph in ((False, "1"), (True, "1"), (True, "0")):
+        for force, ingraph, nb in ((False, "1", 1), (True, "1", 1), (True, "0", 1), (True, "1", 2), (True, "0", 2)):
             os.environ["BNERV_DP_INGRAPH"] = ingraph
             torch.manual_seed(1)
             model = NeRV_Boost(1, args=configs.tiny_nerv()).to(DEV)
             opt = Adan(model.parameters(), lr=0.003)
-            step = TrainStep(model, opt, "Fusion10_freq", False, (1, 3, 180, 320), torch.device(DEV), use_graph=True, warmup_eager=2, force_bucket=force)
+            step = TrainStep(model, opt, "Fusion10_freq", False, (1, 3, 180, 320), torch.device(DEV), use_graph=True, warmup_eager=2, force_bucket=force,
+                             dp_buckets=nb)
+            if nb == 2:      # two segments: [decoder layers | stem + time-embedding MLPs]; the early all-reduce starts inside the backward
+                assert step.bucket.two and 0 < step.bucket.split < step.bucket.numel and model.dp_hook is not None
             losses = []
             for s in range(7):
                 loss, _ = step(frames[s % 3:s % 3 + 1], norm[s % 3:s % 3 + 1])

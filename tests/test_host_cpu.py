@@ -216,6 +216,73 @@ def test_dp_gradient_mean_two_ranks_gloo():
     assert allidx == list(range(10))
 
 
+def _gloo_two_bucket_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import torch.nn as nn
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from boosting_nerv_amd.dp import GradBucket
+    try:
+        torch.manual_seed(0)
+        stem = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 12))          # "late": its gradients come last in the backward
+        dec = nn.Sequential(nn.Linear(12, 9), nn.Tanh(), nn.Linear(9, 4))             # "early": the decoder layers
+        params = list(stem.parameters()) + list(dec.parameters())
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(10 + rank))     # every rank its own shard
+
+        def backward(bucket):
+            for p in params:
+                p.grad = None
+            fired = []
+            h = stem(x)
+            if bucket is not None and bucket.two:
+                def hook(g):
+                    fired.append(all(p.grad is not None for p in dec.parameters()) and all(p.grad is None for p in stem.parameters()))
+                    bucket.exchange_early()
+                h.register_hook(hook)
+            dec(h).square().sum().backward()
+            return fired
+
+        backward(None)
+        own = [p.grad.clone() for p in params]
+        one = GradBucket(params)
+        one.allreduce_mean()
+        mean1 = [p.grad.clone() for p in params]
+        two = GradBucket(params, late_params=list(stem.parameters()))
+        fired = backward(two)
+        inflight = two._early_inflight
+        two.finish()
+        mean2 = [p.grad.clone() for p in params]
+        # reference mean from an all-gather of the ranks' own gradients
+        ok_ref = True
+        for g, m in zip(own, mean1):
+            parts = [torch.empty_like(g) for _ in range(world)]
+            dist.all_gather(parts, g)
+            ok_ref &= torch.allclose(m, sum(parts) / world, rtol=1e-6, atol=1e-7)
+        q.put((rank, two.two, two.split == sum(p.numel() for p in dec.parameters()), fired == [True], inflight, ok_ref,
+               all(torch.equal(a, b) for a, b in zip(mean1, mean2)), not two._early_inflight))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_two_bucket_exchange_two_ranks_gloo():
+    """The two-segment bucket with world_size 2 on CPU: the hook at the decoder / stem boundary fires when exactly
+    the decoder layers' gradients exist, their all-reduce is in flight while the stem's backward runs, finish() exchanges the rest and
+    joins -- and every averaged gradient is BIT-equal to the one-bucket exchange (same sum of the same two numbers per element) and
+    equal to the mean of the ranks' own gradients."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_two_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert all(r[1:]), r
+
+
 def test_dp_mean_of_per_rank_grads_equals_batch_grad_oracle():
     """DP equivalence: grad of the batch-mean loss at b=2 == mean of the two single-frame grads."""
     from oracle import cpu_ref
