@@ -192,7 +192,7 @@ def step_kernel_roofline(dev, Cc, H, W, reps=20):
     # The PMC figure is only valid for the kernel sources it was measured on: tools/pmc_traffic.py stamps the profile with a SHA-256
     # of those sources, and a profile whose stamp differs from the tree (or that has none) is refused -- `traffic` stays null rather
     # than silently describing another kernel.
-    cand = [("r03_traffic.json", (12, 720, 1280)), ("r03_traffic_wide.json", None)]
+    cand = [("r03_traffic.json", (12, 720, 1280)), ("r03_traffic_wide.json", None), ("r03_traffic_c4.json", None)]
     for name, shape in cand:
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))

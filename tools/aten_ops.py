@@ -21,16 +21,29 @@ for _ in range(3):
     step(frames[:1], norm[:1])
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(frames[1:2], norm[1:2])
     torch.cuda.synchronize()
-ka = prof.key_averages(group_by_stack_n=6)
-rows = [e for e in ka if e.key.startswith("aten::") and getattr(e, "device_time_total", getattr(e, "cuda_time_total", 0)) > 0]
-rows.sort(key=lambda e: -e.count)
-tot = {}
-for e in rows:
-    tot[e.key] = tot.get(e.key, 0) + e.count
-print("ATen ops that launch kernels in one eager step:", sorted(tot.items(), key=lambda kv: -kv[1]))
-for e in rows[:28]:
-    st = [s for s in e.stack if "boosting_nerv_amd" in s or "torch/optim" in s][:3]
-    print(f"{e.count:4d} x {e.key:28s} dev_us {getattr(e, 'device_time_total', getattr(e, 'cuda_time_total', 0)):9.1f}  {' <- '.join(s.split('/')[-1] for s in st)}")
+rows = [e for e in prof.key_averages() if e.key.startswith("aten::") and getattr(e, "device_time_total", getattr(e, "cuda_time_total", 0)) > 0]
+rows.sort(key=lambda e: -getattr(e, "device_time_total", getattr(e, "cuda_time_total", 0)))
+for e in rows[:12]:
+    print(f"{e.count:4d} x {e.key:28s} device us {getattr(e, 'device_time_total', getattr(e, 'cuda_time_total', 0)):9.1f}")
+# call sites of the copying ops: count calls that really copy, keyed by the nearest frame inside this package
+import collections, traceback
+sites = collections.Counter()
+def wrap(name):
+    orig = getattr(torch.Tensor, name)
+    def f(self, *a, **k):
+        out = orig(self, *a, **k)
+        copied = name in ("clone", "copy_") or (isinstance(out, torch.Tensor) and out.is_cuda and out.data_ptr() != self.data_ptr())
+        if copied and self.is_cuda and self.numel() > 4096:
+            fr = [x for x in traceback.extract_stack()[:-1] if "boosting_nerv_amd" in x.filename]
+            sites[(name, fr[-1].filename.split("/")[-1] + ":" + str(fr[-1].lineno) if fr else "?", tuple(self.shape))] += 1
+        return out
+    setattr(torch.Tensor, name, f)
+for n in ("clone", "contiguous", "copy_", "reshape"):
+    wrap(n)
+step(frames[:1], norm[:1])
+torch.cuda.synchronize()
+for (name, site, shape), c in sites.most_common(40):
+    print(f"{c:3d} x {name:11s} {site:32s} {shape}")

@@ -1,12 +1,14 @@
 """Run ONE hot kernel a few times (for rocprofv3 --pmc runs).  usage: kone.py conv|conv_k2s|wgrad|conv38|wgrad38 [reps]
-conv / wgrad: the 12->12 3x3 layer at 720x1280 (C1); conv38 / wgrad38: the 38->38 3x3 layer at 1080x1920 (C3)."""
+conv / wgrad: the 12->12 3x3 layer at 720x1280 (C1; suffix _1080: at 1080x1920, C4); conv38 / wgrad38: the 38->38 3x3 layer at 1080x1920 (C3)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from boosting_nerv_amd import _lib as L, ops
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "conv"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-B, C, H, W = (1, 38, 1080, 1920) if "38" in which else (1, 12, 720, 1280)
+B, C, H, W = (1, 38, 1080, 1920) if "38" in which else ((1, 12, 1080, 1920) if which.endswith("_1080") else (1, 12, 720, 1280))
+if which.endswith("_1080"):        # C4's final stage: the 12-channel kernels at 1080x1920
+    which = which[:-5]
 x, g = torch.randn(B, C, H, W, device=dev), torch.randn(B, C, H, W, device=dev)
 w, b = torch.randn(C, C, 3, 3, device=dev) / 10, torch.randn(C, device=dev)
 sc, sh = torch.randn(B, C, device=dev) * 0.1, torch.randn(B, C, device=dev) * 0.1

@@ -1,6 +1,7 @@
 """HBM traffic of the step's dominant kernel from the PMC counters, stamped with the kernel sources it was measured on.
     python tools/pmc_traffic.py c1      (through gpurun, repo root)   -> gpurun_out/r03_traffic.json + r03_pmc.md
     python tools/pmc_traffic.py wide                                   -> gpurun_out/r03_traffic_wide.json
+    python tools/pmc_traffic.py c4                                     -> gpurun_out/r03_traffic_c4.json (C4's final stage, 12->12 @1080x1920)
 Method (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (with --kernel-trace only),
 chip-wide sums per dispatch averaged over the dispatches of tools/kone.py; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at
 64 B).  bench.py refuses the profile when the SHA-256 of the listed sources no longer matches the tree."""
@@ -9,6 +10,8 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 which = sys.argv[1] if len(sys.argv) > 1 else "c1"
 cfg = {"c1": dict(mode="conv_k2s", pat="conv_lean_kernel", shape=[12, 720, 1280], alg=132715584, sources=["conv.hip", "conv4.hip", "conv_common.h", "common.h"],
                   kernel="K2s: TAT conv0 forward (affine -> 3x3 -> bias -> gelu, gelu') 12->12 @720x1280", out="r03_traffic.json"),
+       "c4": dict(mode="conv_k2s_1080", pat="conv_lean_kernel", shape=[12, 1080, 1920], alg=298603584, sources=["conv.hip", "conv4.hip", "conv_common.h", "common.h"],
+                  kernel="K2s: TAT conv0 forward (affine -> 3x3 -> bias -> gelu, gelu') 12->12 @1080x1920", out="r03_traffic_c4.json"),
        "wide": dict(mode="conv38_k2s", pat="conv_bfw_kernel", shape=[38, 1080, 1920], alg=945561600, sources=["convbf.hip", "split16.h", "conv_common.h", "common.h"],
                     kernel="K2s 38->38 @1080x1920 on the wide split kernel", out="r03_traffic_wide.json")}[which]
 os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)

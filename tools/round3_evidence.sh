@@ -6,7 +6,8 @@ set -u
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 python tools/pmc_traffic.py c1 > /dev/null 2>&1
 python tools/pmc_traffic.py wide > /dev/null 2>&1
-cp $O/r03_traffic.json $O/r03_traffic_wide.json $R/profiles/ 2>/dev/null      # the bench lines below read (and verify) them
+python tools/pmc_traffic.py c4 > /dev/null 2>&1
+cp $O/r03_traffic.json $O/r03_traffic_wide.json $O/r03_traffic_c4.json $R/profiles/ 2>/dev/null      # the bench lines below read (and verify) them
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/r03_bench_c1.json 2> $O/r03_bench_c1.err
 for c in c3 c4 c5; do python $R/bench.py --config $c 2>/dev/null | tail -1 > $O/r03_bench_$c.json; done
