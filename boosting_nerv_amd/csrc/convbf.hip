@@ -8,6 +8,7 @@
 #include "common.h"
 #include "sidejob.h"
 #include "split16.h"
+#include "wgrad_bfw_body.h"   // the wide weight-gradient body: one role of the paired launch at the bottom of this file
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -676,7 +677,8 @@ struct WItem { int g, b, ty, tx, sp; };
 // paired 16-B stores; PS2 = 3: PixelShuffle(s), s = out_s in {3, 5}, with four 4-B stores s columns apart per accumulator quad.
 // IN_UNSHUFFLE: the input is read through the inverse map from the shuffled tensor (data gradient of an up-conv; in_s == 2).
 template <int IN, int EP, int SP, int NTB, int PS2>
-__global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const u32x4* __restrict__ wfrag, const int ngroups, const SidePack side) {
+__device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __restrict__ wfrag, const int ngroups, const SidePack& side, const int vb, const int vgrid) {
+    // (vb of vgrid: this launch's block index / size, or the conv role of a paired launch)
     constexpr int KS = 3;
     constexpr bool UNSH = (IN == BNERV_IN_UNSHUFFLE);
     static_assert(PS2 == 0 || EP == BNERV_EP_BIAS || EP == BNERV_EP_BIAS_SIN, "pixel-shuffle epilogues");
@@ -703,13 +705,13 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
     const int tiles_x = ka.tiles_x, tiles_y = ka.tiles_y;
     const int nck = (Cin + 15) >> 4;
 
-    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
-    const int nlb = (gridDim.x - xcd + 7) >> 3;
+    const int xcd = vb & 7, lb = vb >> 3;
+    const int nlb = (vgrid - xcd + 7) >> 3;
     const int per = ka.total_items >> 3, extra = ka.total_items & 7;
     const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
     int itx = r0 + lb;
     for (int i = tid; i < NS * BG::PIECE / 16; i += 256) reinterpret_cast<u32x4*>(s_a)[i] = u32x4{0u, 0u, 0u, 0u};   // no NaN patterns beside zero weights
-    if (itx >= r1) { side_run_hosted(side, smem); return; }
+    if (itx >= r1) { side_run_hosted(side, smem, vb, vgrid); return; }
     auto decode = [&](int i) __attribute__((always_inline)) {     // item order: tile fastest, then sample, then cout group
         WItem w;
         const int tiles = tiles_x * tiles_y;
@@ -1085,7 +1087,11 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
         lds_barrier();
         flush_partials(prev);
     }
-    side_run_hosted(side, smem);
+    side_run_hosted(side, smem, vb, vgrid);
+}
+template <int IN, int EP, int SP, int NTB, int PS2>
+__global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const u32x4* __restrict__ wfrag, const int ngroups, const SidePack side) {
+    conv_bfw_body<IN, EP, SP, NTB, PS2>(ka, wfrag, ngroups, side, (int)blockIdx.x, (int)gridDim.x);
 }
 
 constexpr size_t LEAN_MAX_BYTES = 0x7ff00000;            // every tensor view must stay below the OOB marker offset
@@ -1136,32 +1142,40 @@ static int wide_mode() {                                   // BNERV_SPLIT_WIDE =
     return v;
 }
 
+// the pre-split B fragments of this call: from the stream context's plan when one is live, else prepared here into the context's scratch
+// (NULL: no context, or the scratch would have to grow inside a graph capture -- the caller falls back to the f32 kernels)
+template <int NS>
+const void* weight_fragments(hipStream_t st, const bnerv_conv_desc& d, int nck, int ntb, int ngroups) {
+    using BG = BfGeo<3>;
+    const size_t slots = (size_t)ngroups * nck * ntb * BG::STEPS * NS * 64;
+    const int nfrag = ngroups * nck * ntb * BG::STEPS * 64;
+    const void* scratch = wplan_lookup(d.ctx, d, nck, ntb, NS);      // a live plan prepared this call's fragments at the start of the step
+    if (scratch) return scratch;
+    void* own = bnerv_ctx_scratch(d.ctx, slots * 16, st);
+    if (!own) {                                         // no context, or it would have to grow inside a graph capture: f32 kernels
+        static bool warned = false;                     // (different arithmetic and speed than the eager steps had: say so, once)
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "[bnerv] wide split conv: no scratch for the weight fragments (%zu bytes; context %s) -- this call runs on the f32 MFMA kernels; "
+                            "reserve the context's scratch before capturing (bnerv_ctx_reserve)\n", slots * 16, d.ctx ? "cannot grow here" : "missing");
+        }
+        return nullptr;
+    }
+    hipLaunchKernelGGL(bf_wprep_kernel<NS>, dim3(cdiv(nfrag, 256)), dim3(256), 0, st, d.w, reinterpret_cast<u32x4*>(own),
+                       d.wCo, d.wCi, d.transposed, d.Cin, d.Cout, nck, ntb, nfrag);
+    if (hipGetLastError() != hipSuccess) return nullptr;
+    wplan_note(d.ctx, d, nck, ntb, NS, nfrag);
+    return own;
+}
+
 template <int IN, int EP, int SP, int NTB, int PS2 = 0>
 int launch_bfw(hipStream_t st, KArgs& ka) {
     using BG = BfGeo<3>;
     constexpr int NS = Split<SP>::NS;
     const bnerv_conv_desc& d = ka.d;
     const int nck = cdiv(d.Cin, 16), ngroups = cdiv(cdiv(d.Cout, 16), NTB);
-    const size_t slots = (size_t)ngroups * nck * NTB * BG::STEPS * NS * 64;
-    const int nfrag = ngroups * nck * NTB * BG::STEPS * 64;
-    const void* scratch = wplan_lookup(d.ctx, d, nck, NTB, NS);      // a live plan prepared this call's fragments at the start of the step
-    if (!scratch) {
-        void* own = bnerv_ctx_scratch(d.ctx, slots * 16, st);
-        if (!own) {                                         // no context, or it would have to grow inside a graph capture: f32 kernels
-            static bool warned = false;                     // (different arithmetic and speed than the eager steps had: say so, once)
-            if (!warned) {
-                warned = true;
-                fprintf(stderr, "[bnerv] wide split conv: no scratch for the weight fragments (%zu bytes; context %s) -- this call runs on the f32 MFMA kernels; "
-                                "reserve the context's scratch before capturing (bnerv_ctx_reserve)\n", slots * 16, d.ctx ? "cannot grow here" : "missing");
-            }
-            return BF_NOT_HANDLED;
-        }
-        hipLaunchKernelGGL(bf_wprep_kernel<NS>, dim3(cdiv(nfrag, 256)), dim3(256), 0, st, d.w, reinterpret_cast<u32x4*>(own),
-                           d.wCo, d.wCi, d.transposed, d.Cin, d.Cout, nck, NTB, nfrag);
-        BNERV_LAUNCH_CHECK("bf_wprep");
-        wplan_note(d.ctx, d, nck, NTB, NS, nfrag);
-        scratch = own;
-    }
+    const void* scratch = weight_fragments<NS>(st, d, nck, NTB, ngroups);
+    if (!scratch) return BF_NOT_HANDLED;
     ka.total_items = ka.ksplit * ngroups * d.B * ka.tiles_x * ka.tiles_y;
     ka.magic_tiles = div_magic(ka.tiles_x * ka.tiles_y);
     ka.magic_tiles_x = div_magic(ka.tiles_x);
@@ -1206,6 +1220,52 @@ int launch_bfw_ntb(hipStream_t st, KArgs& ka) {
 template <int IN, int EP, int PS2 = 0>
 int launch_bfw_sp(hipStream_t st, KArgs& ka) {
     return wide_mode() == SP_BF16X3 ? launch_bfw_ntb<IN, EP, SP_BF16X3, PS2>(st, ka) : launch_bfw_ntb<IN, EP, SP_BF16X6, PS2>(st, ka);
+}
+
+// ---- paired launch, wide form: the data gradient of a wide 3x3 layer (conv_bfw body) and the weight gradient that reads the same incoming
+// gradient (wgrad_bfw body, wgrad_bfw_body.h) as interleaved roles of ONE grid -- equal block counts, the role of XCD-local slot s is
+// (s + s / 32) & 1 (every CU holds both roles), both roles walk their XCD's slice of the image top to bottom at the same rate, so what
+// one role reads of the shared gradient the other finds in that XCD's L2 (wgrad.hip::launch_pair has the 12-channel form and the
+// measurements).  Only for layers that fill the chip in both roles; everything else keeps its own launches (or the low-resolution pair).
+template <int CIN, int CEP, int NTB, int WIN, int MTW, int GM2>
+__global__ __launch_bounds__(256, 2) void bfw_pair_kernel(const KArgs ka, const u32x4* __restrict__ wfrag, const int ngroups, const bnerv_wb::WArgs wa,
+                                                          const int slots, const int ngn, const int ngm, const int nr, const SidePack side) {
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, vb = ((slot >> 1) << 3) + xcd;
+    if (((slot + (slot >> 5)) & 1) == 0) {
+        SidePack none;
+        none.n_jobs = 0; none.n_slices = 0;
+        conv_bfw_body<CIN, CEP, SP_BF16X6, NTB, 0>(ka, wfrag, ngroups, none, vb, nr);
+    } else {
+        bnerv_wb::wgrad_bfw_body<WIN, SP_BF16X6, MTW, GM2>(wa, slots, ngn, ngm, side, vb, nr);
+    }
+}
+
+template <int CIN, int CEP, int NTB, int WIN, int MTW, int GM2>
+int launch_bfw_pair(hipStream_t st, KArgs& ka, const bnerv_wb::WArgs& wa, int slots, int ngn, int ngm, int nr) {
+    using BG = BfGeo<3>;
+    constexpr int NS = Split<SP_BF16X6>::NS;
+    const bnerv_conv_desc& d = ka.d;
+    const int nck = cdiv(d.Cin, 16), ngroups = cdiv(cdiv(d.Cout, 16), NTB);
+    const void* scratch = weight_fragments<NS>(st, d, nck, NTB, ngroups);
+    if (!scratch) return BF_NOT_HANDLED;
+    ka.total_items = ngroups * d.B * ka.tiles_x * ka.tiles_y;
+    ka.magic_tiles = div_magic(ka.tiles_x * ka.tiles_y);
+    ka.magic_tiles_x = div_magic(ka.tiles_x);
+    size_t lds = (size_t)NS * BG::PIECE + (size_t)NTB * BG::STEPS * NS * 1024 + (size_t)(4 * 2 * NTB * 16) * sizeof(float);
+    size_t lw = (size_t)NS * bnerv_wb::BW_PIECE + 2 * bnerv_wb::BW_NPL * sizeof(float);
+    const size_t red = (size_t)MTW * 16 * bnerv_wb::BW_NTW * 16 * sizeof(float);
+    if (lw < red) lw = red;
+    if (lds < lw) lds = lw;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bfw_pair_kernel<CIN, CEP, NTB, WIN, MTW, GM2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    SidePack side;
+    bnerv_side_take(d.ctx, &side, 2 * nr);
+    hipLaunchKernelGGL((bfw_pair_kernel<CIN, CEP, NTB, WIN, MTW, GM2>), dim3(2 * nr), dim3(256), lds, st, ka, reinterpret_cast<const u32x4*>(scratch), ngroups, wa, slots, ngn, ngm, nr, side);
+    BNERV_LAUNCH_CHECK("bfw_pair");
+    return BNERV_OK;
 }
 
 int launch_wide_mode(hipStream_t st, KArgs& ka) {
@@ -1344,4 +1404,43 @@ int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec, int kspl
     if (const char* e = getenv("BNERV_SPLIT_WIDE_MIN_TILES")) min_tiles = atoi(e);     // tests lower it to reach the kernel with small shapes
     if (d.B * ka.tiles_x * ka.tiles_y < min_tiles) return BF_NOT_HANDLED;
     return launch_wide_mode(st, ka);
+}
+
+// 1: not a pair of this form (the caller goes on).  On BNERV_OK *n_slabs is the weight gradient's slab count.
+// w_mtw / ngn / ngm / nat_slots: the weight gradient's plan for its own launch (wgrad.hip::bw_plan).
+int bnerv_convbf_pair_try(hipStream_t st, const bnerv_conv_desc& d, int vec, const bnerv_wb::WArgs& wa, int w_mtw, int ngn, int ngm, int nat_slots, int* n_slabs) {
+    { static const bool off = [] { const char* e = getenv("BNERV_PAIR_BFW"); return e && e[0] == '0'; }(); if (off) return 1; }
+    if (wide_mode() != (int)SP_BF16X6 || !vec || d.k != 3 || !d.ctx || d.out_s != 1) return 1;
+    const bool uns = d.in_mode == BNERV_IN_UNSHUFFLE;
+    if (!(d.in_mode == BNERV_IN_PLAIN || (uns && d.in_s == 2 && d.Cin % 4 == 0))) return 1;
+    if (d.Cout <= 16 && d.Cin <= 16 && !uns) return 1;                                     // (the one-tile kernels' layer)
+    const size_t cmax = (size_t)(d.Cin > d.Cout ? d.Cin : d.Cout);
+    if ((size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 >= LEAN_MAX_BYTES) return 1;
+    const bnerv_wgrad_desc& w = wa.d;
+    KArgs ka;
+    ka.d = d;
+    ka.tiles_x = cdiv(d.W, TW);
+    ka.tiles_y = cdiv(d.H, TH);
+    ka.ksplit = 1;
+    ka.cps = cdiv(d.Cin, 16);
+    const int nt = cdiv(d.Cout, 16), ntb = nt <= 3 ? nt : (nt == 4 ? 2 : 3), ngroups = cdiv(nt, ntb);
+    const int wg = ngn * ngm;
+    const int slots = wg <= 32 ? 32 / wg : 0;              // 8 x wg x slots = the blocks per role (<= 256: two blocks per CU in all)
+    if (slots < 1) return 1;
+    const int nr = 8 * wg * slots;
+    // both roles must fill the chip on their own: the conv has at least two items per block, the weight gradient's own plan at least twice the slots
+    if (ngroups * d.B * ka.tiles_x * ka.tiles_y < 2 * nr || nat_slots < 2 * slots) return 1;
+    int rc = 1;
+#define BNERV_BP(CI, CE, NT, WI, MT, G2) if (d.in_mode == CI && d.ep_mode == CE && ntb == NT && w.in_mode == WI && w_mtw == MT && gm2 == G2) \
+        rc = launch_bfw_pair<CI, CE, NT, WI, MT, G2>(st, ka, wa, slots, ngn, ngm, nr);
+    const int gm2 = w.g_s == 2 ? 1 : 0;
+    if (w.g_s > 2 || w.g_mode == BNERV_IN_TANHGRAD) return 1;
+    // an up-conv's (dW | d input) where the data gradient has ONE output tile (<= 16 channels: the 12 -> 48 up-convs of the 12-channel
+    // stages): unshuffle(2) prologue | plain input, shuffled gradient.  Measured and NOT instantiated: the 38-channel TAT / block convs
+    // of C3 (both roles three tiles wide, matrix-bound) ran 18.54 ms per step paired against 18.21 ms with their own launches.
+    BNERV_BP(BNERV_IN_UNSHUFFLE, BNERV_EP_PLAIN, 1, BNERV_IN_PLAIN, 3, 1)
+    BNERV_BP(BNERV_IN_UNSHUFFLE, BNERV_EP_PLAIN, 1, BNERV_IN_PLAIN, 2, 1)
+#undef BNERV_BP
+    if (rc == BNERV_OK) *n_slabs = 8 * slots;
+    return rc == BF_NOT_HANDLED ? 1 : rc;
 }
