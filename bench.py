@@ -488,6 +488,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     loss, psnr = step.loss_out.item(), step.psnr_out.mean().item()
+    replicas_in_sync = None
+    if world > 1:
+        # every rank started from the same seeded parameters and applied the same averaged gradients: the replicas must hold the SAME
+        # bits after the timed steps -- a collective that was captured but did not exchange, or exchanged out of order, shows up here
+        ck = torch.stack([p.detach().double().sum() for p in model.parameters()] + [p.detach().double().abs().sum() for p in model.parameters()])
+        lo, hi = ck.clone(), ck.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_in_sync = bool(torch.equal(lo, hi))
     if rank == 0 and a.steps_only:
         print(json.dumps({"metric": "train frames/sec", "value": round(a.steps * per_gpu_batch * world / dt, 2), "ms_per_step": round(dt / a.steps * 1e3, 4), "steps_only": True}), flush=True)
     elif rank == 0:
@@ -513,7 +522,7 @@ def main():
                           "baseline_config": {"c1": "configs[1]", "c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]"}[a.config], "global_batch": per_gpu_batch * world,
                           "per_gpu_batch": per_gpu_batch, "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
                           "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else 0),
-                          "collective_in_graph": bool(getattr(step, "collective_in_graph", False)),
+                          "collective_in_graph": bool(getattr(step, "collective_in_graph", False)), "replicas_in_sync": replicas_in_sync,
                           "last_loss": round(loss, 6), "last_train_psnr_db": round(psnr, 4)}}
         c_last = last_stage_channels(model)
         out["roofline"] = step_kernel_roofline(dev, c_last, r["h"], r["w"], reps=20 if r["h"] <= 720 else 8)

@@ -475,12 +475,46 @@ def gen_full_c5(R):
     np.savez_compressed(os.path.join(OUT, "full_c5.npz"), **out)
 
 
+def gen_inpaint(R):
+    """Inpainting masks (row a12): TransformInput (hnerv_utils.py:59-84) in its 'center' and 'fixed' modes and the masked train step
+    of train_nerv_all.py:334-346 -- input = (img * mask).clamp(0, 1), loss_fn(img_out * mask, gt * mask), PSNR against the unmasked gt --
+    on the tiny NeRV_Boost (index input) and HNeRV_Boost (the masked frame IS the network input), state_dicts of tiny_*.npz."""
+    import copy
+    out = {}
+    for mname, args0 in (("nerv", configs.tiny_nerv()), ("hnerv", configs.tiny_hnerv())):
+        for mode in ("inpanting_center", "inpanting_fixed_50"):
+            args = copy.copy(args0)
+            args.inpanting = mode
+            torch.manual_seed(1)
+            m = _model(R, args)
+            tf = R.hnerv_utils.TransformInput(args)
+            g = torch.Generator().manual_seed(5)
+            frame = torch.rand(2, 3, 180, 320, generator=g) * 1.2 - 0.1          # (values outside [0, 1]: the clamp of the masked input acts)
+            norm_idx = torch.tensor([3 / 7, 6 / 7], dtype=torch.float64)
+            inp, gt, mask = tf(frame, torch.tensor([2, 5]))
+            img, _, _ = m(inp if args.model == "HNeRV_Boost" else norm_idx, norm_idx=norm_idx)
+            loss = R.hnerv_utils.loss_fn(img * mask, gt * mask, "L1_freq")
+            loss.backward()
+            k = f"{mname}/{mode}"
+            out[f"{k}/mask"] = np.packbits(npf(mask).astype(np.uint8))
+            out[f"{k}/mask_shape"] = np.array(mask.shape, dtype=np.int64)
+            out[f"{k}/mask_zeros"] = np.int64((mask == 0).sum().item())
+            summary(inp, f"{k}/inp", out, 512)
+            summary(img, f"{k}/img", out, 512)
+            out[f"{k}/gt_equals_frame"] = np.bool_(torch.equal(gt, frame))
+            out[f"{k}/loss_L1_freq"] = np.float64(loss.item())
+            out[f"{k}/psnr"] = npf(R.hnerv_utils.psnr_fn_single(img.detach(), gt))
+            for pn, p in m.named_parameters():
+                out[f"{k}/gnorm/{pn}"] = np.float64(p.grad.double().norm().item()) if p.grad is not None else np.float64(-1)
+    np.savez_compressed(os.path.join(OUT, "inpaint.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = ref_harness.load_reference()
-    which = sys.argv[1:] or ["pe", "blocks", "cnx", "tiny", "full", "full1080", "loss", "optim", "host", "cem", "cem_model", "full_c5"]
-    fns = dict(pe=gen_pe, blocks=gen_blocks, cnx=gen_convnext_blocks, tiny=gen_tiny_models, full=gen_full_models, full1080=gen_full_1080, loss=gen_loss, optim=gen_optim, host=gen_host, cem=gen_cem, cem_model=gen_cem_model, full_c5=gen_full_c5)
+    which = sys.argv[1:] or ["pe", "blocks", "cnx", "tiny", "full", "full1080", "loss", "optim", "host", "cem", "cem_model", "full_c5", "inpaint"]
+    fns = dict(pe=gen_pe, blocks=gen_blocks, cnx=gen_convnext_blocks, tiny=gen_tiny_models, full=gen_full_models, full1080=gen_full_1080, loss=gen_loss, optim=gen_optim, host=gen_host, cem=gen_cem, cem_model=gen_cem_model, full_c5=gen_full_c5, inpaint=gen_inpaint)
     for w in which:
         print("generating", w, flush=True)
         fns[w](R)

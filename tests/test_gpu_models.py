@@ -806,6 +806,7 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
     assert out["scaling"] == "weak" and out["value"] > 0 and out["cpu_baseline"] is None and out["roofline"]["frac"] > 0
     assert "eval_psnr_db" in out and "step_roofline" in out
+    assert out["config"]["replicas_in_sync"] is True           # both ranks hold the same parameter bits after the timed steps
 
 
 def test_bench_two_ranks_over_rccl(tmp_path):
@@ -834,4 +835,60 @@ def test_bench_two_ranks_over_rccl(tmp_path):
     a, b = run(True, 29681), run(False, 29683)
     assert a["n_gpus"] == 2 and a["config"]["rccl_ranks"] == 2 and a["config"]["collective_in_graph"] is True
     assert b["config"]["rccl_ranks"] == 2 and b["config"]["collective_in_graph"] is False
+    assert a["config"]["replicas_in_sync"] is True and b["config"]["replicas_in_sync"] is True
     assert a["config"]["last_loss"] == b["config"]["last_loss"] and a["config"]["last_train_psnr_db"] == b["config"]["last_train_psnr_db"]
+
+
+@pytest.mark.parametrize("mode", ["inpanting_center", "inpanting_fixed_50"])
+@pytest.mark.parametrize("mname,cfg", [("nerv", configs.tiny_nerv), ("hnerv", configs.tiny_hnerv)])
+def test_inpainting_masked_step_against_reference_golden(mname, cfg, mode):
+    """Row a12 on the GPU: an inpainting mask through the generic (eager, op-by-op) step of train_nerv_all._generic_step --
+    TransformInput on device tensors, the masked frame as HNeRV_Boost's input, loss_fn(out * mask, gt * mask) with the mask
+    multiplies in the autograd graph of the HIP operators -- against the reference's own masked step (train_nerv_all.py:334-346):
+    image, loss, PSNR against the unmasked frame, every gradient norm."""
+    import copy
+    from boosting_nerv_amd import hnerv_utils as hu
+    npz = load_golden("inpaint.npz")
+    args = copy.copy(cfg())
+    args.inpanting = mode
+    torch.manual_seed(1)
+    model = _build(mname, args)
+    model.load_state_dict({k: v for k, v in group(load_golden(f"tiny_{mname}.npz"), "sd/").items()})
+    model = model.to(DEV)
+    tf = hu.TransformInput(args)
+    frame = (torch.rand(2, 3, 180, 320, generator=torch.Generator().manual_seed(5)) * 1.2 - 0.1).to(DEV)
+    norm_idx = torch.tensor([3 / 7, 6 / 7], dtype=torch.float64, device=DEV)
+    inp, gt, mask = tf(frame, torch.tensor([2, 5], device=DEV))
+    k = f"{mname}/{mode}"
+    want = np.unpackbits(npz[f"{k}/mask"])[:180 * 320].reshape(180, 320)
+    assert mask.is_cuda and np.array_equal(mask.cpu().numpy().astype(np.uint8), want)
+    check_summary(inp, npz, f"{k}/inp", 0, 0)
+    img, _, _ = model(inp if args.model == "HNeRV_Boost" else norm_idx, norm_idx=norm_idx)
+    check_summary(img, npz, f"{k}/img", 1e-3, 1e-5)
+    loss = hu.loss_fn(img * mask, gt * mask, "L1_freq")
+    gold = float(npz[f"{k}/loss_L1_freq"])
+    assert abs(loss.item() - gold) < 3e-4 * abs(gold), (loss.item(), gold)
+    torch.testing.assert_close(hu.psnr_fn_single(img.detach(), gt).cpu(), torch.from_numpy(npz[f"{k}/psnr"]), rtol=1e-4, atol=2e-3)
+    loss.backward()
+    for pn, p in model.named_parameters():
+        gn = float(npz[f"{k}/gnorm/{pn}"])
+        if gn < 0:
+            continue
+        got = p.grad.double().norm().item()
+        assert abs(got - gn) <= 5e-3 * gn + 1e-6, (pn, got, gn)
+
+
+def test_inpainting_cli_end_to_end(tmp_path, monkeypatch):
+    """The train script with --inpanting inpanting_center (the reference's flag spelling): every step takes the generic path
+    (train_nerv_all._generic_step), the masked loss runs on the HIP operators for three epochs of a synthetic clip, and it learns."""
+    from boosting_nerv_amd import train_nerv_all as T
+    monkeypatch.chdir(tmp_path)
+    base = ("--outf ti --data_path synthetic:6x180x320 --vid tiny --model NeRV_Boost --sft_block res_sft --ch_t 32 --conv_type convnext pshuffel_3x3 "
+            "--act sin --norm none --crop_list 180_320 --resize_list -1 --loss Fusion10_freq --embed pe_1.25_80 --fc_hw 9_16 --dec_strds 5 2 2 "
+            "--ks 0_3_3 --reduce 2 --dec_blks 1 1 2 --modelsize 0.05 --lower_width 6 -b 1 --lr 0.003 --eval_freq 3 -p 2 --data_split 4_5_6")
+    T.main((base + " --optim_type Adan -e 3 --not_resume --inpanting inpanting_center").split())
+    out = tmp_path / "output" / "ti" / "tiny" / "Size0.05"
+    log = (out / "rank0.txt").read_text()
+    assert "Epoch[3/3]" in log and "Eval at epoch 3" in log
+    train_psnrs = [float(l.split("pred_PSNR: ")[1]) for l in log.splitlines() if "pred_PSNR" in l]
+    assert train_psnrs[-1] > train_psnrs[0]

@@ -400,3 +400,39 @@ def test_ans_coder_edge_cases():
     assert np.array_equal(em.ans_decode_categorical(words, vals.size, counts / counts.sum()), inv)
     h = -(counts * np.log2(counts / counts.sum())).sum()
     assert h <= words.size * 32 <= 1.01 * h + 64
+
+
+@pytest.mark.parametrize("mode", ["inpanting_center", "inpanting_fixed_50"])
+def test_inpainting_transform_and_masked_step_match_reference_golden(mode):
+    """Row a12 on the host: TransformInput (reference hnerv_utils.py:59-84) builds the reference's mask and masked, clamped input bit for
+    bit, returns the untouched frame as gt, and the oracle's masked step -- loss_fn(img * mask, gt * mask) of train_nerv_all.py:343 on
+    the tiny NeRV_Boost -- reproduces the reference's loss and PSNR (tests/golden/inpaint.npz, oracle/make_goldens.py inpaint)."""
+    import copy
+    from boosting_nerv_amd.hnerv_utils import TransformInput
+    from conftest import check_summary, group
+    from oracle import cpu_ref
+    npz = load_golden("inpaint.npz")
+    args = copy.copy(configs.tiny_nerv())
+    args.inpanting = mode
+    tf = TransformInput(args)
+    assert not tf.identity
+    frame = torch.rand(2, 3, 180, 320, generator=torch.Generator().manual_seed(5)) * 1.2 - 0.1
+    inp, gt, mask = tf(frame, torch.tensor([2, 5]))
+    k = f"nerv/{mode}"
+    want = np.unpackbits(npz[f"{k}/mask"])[:180 * 320].reshape(180, 320)
+    assert tuple(mask.shape) == tuple(npz[f"{k}/mask_shape"]) and np.array_equal(mask.numpy().astype(np.uint8), want)
+    assert int((mask == 0).sum()) == int(npz[f"{k}/mask_zeros"]) and not mask.requires_grad
+    assert torch.equal(gt, frame) and bool(npz[f"{k}/gt_equals_frame"])
+    check_summary(inp, npz, f"{k}/inp", 0, 0)
+    assert inp.min() >= 0 and inp.max() <= 1
+    none = copy.copy(args); none.inpanting = "none"
+    a, b, m0 = TransformInput(none)(frame, torch.tensor([2, 5]))
+    assert a is frame and b is frame and m0 is None                 # identity: the train loop skips the two multiplies by one
+    sd = {kk: v for kk, v in group(load_golden("tiny_nerv.npz"), "sd/").items()}
+    norm_idx = torch.tensor([3 / 7, 6 / 7], dtype=torch.float64)
+    img = cpu_ref.nerv_boost_forward(sd, norm_idx)
+    check_summary(img, npz, f"{k}/img", 1e-3, 1e-5)
+    loss = cpu_ref.loss_fn(img * mask, gt * mask, "L1_freq")
+    gold = float(npz[f"{k}/loss_L1_freq"])
+    assert abs(loss.item() - gold) < 1e-4 * abs(gold), (loss.item(), gold)
+    torch.testing.assert_close(cpu_ref.psnr_fn_single(img, gt), torch.from_numpy(npz[f"{k}/psnr"]), rtol=1e-5, atol=1e-4)
