@@ -57,6 +57,50 @@ class _CEMHooks:
                 m.bitrate_w_dict.update(d)
         return True
 
+    def cal_params_eval_fused(self, entropy_model):
+        """Evaluation-time bit accounting of every weight / bias tensor (reference train_nerv_compression.py:466-489: quantise, keep the
+        de-quantised tensor, estimate the rounded symbols' bits, code them) without the per-tensor loop: ONE fused quantise + rate pass
+        (ops.cem_scale_rate, rounded symbols), ONE device -> host copy of the flat weights, scales and statistics, and the host
+        rANS coder (csrc/ans.cpp) over the symbols rebuilt there -- np.rint(w / s) in float32 is the device's round(w / s) bit for
+        bit (IEEE division, ties to even).  Fills the modules' dequant_w / dequant_b and rate dictionaries exactly as the loop does;
+        returns False when the model is outside the fused kernel's scope (per-channel scales, other quantisers, CPU tensors)."""
+        import numpy as np
+        from . import ops
+        from .lib.entropy_model import ans_encode_gaussian
+        from .lib.transform_ops import Scale_T
+        mods = self._quant_modules()
+        if entropy_model is None or getattr(entropy_model, "distribution", None) != "gaussian" or not mods or not mods[0].weight.is_cuda:
+            return False
+        items = []
+        for m in mods:
+            items.append((m, False, m.weight, m.weight_quantizer))
+            if m.bias is not None:
+                items.append((m, True, m.bias, m.bias_quantizer))
+        if any(type(q) is not Scale_T or q.per_channel for _, _, _, q in items):
+            return False
+        with torch.no_grad():
+            tensors = [t.detach() for _, _, t, _ in items]
+            bits, stats, deqs = ops.cem_scale_rate(tensors, [q.scale.detach() for _, _, _, q in items], [None] * len(items), False)
+            host = torch.cat([t.reshape(-1) for t in tensors] + [q.scale.detach().reshape(-1) for _, _, _, q in items] + [stats.reshape(-1)]).cpu().numpy()
+        total = sum(t.numel() for t in tensors)
+        scales_h = host[total:total + len(items)]
+        stats_h = host[total + len(items):].reshape(len(items), 4)
+        off = 0
+        for i, (m, is_bias, t, _) in enumerate(items):
+            sym = np.rint(host[off:off + t.numel()] / scales_h[i]).astype(np.int32)
+            off += t.numel()
+            lo, hi = int(sym.min()), int(sym.max())
+            std = float(np.clip(stats_h[i, 2], 1e-5, 1e10))                     # (compress_matrix_flatten_gaussian_global's clamp)
+            real = int(ans_encode_gaussian(sym, lo, hi if hi > lo else lo + 1, float(stats_h[i, 1]), std).size) * 32
+            d = {"bitrate": bits[i], "mean": stats[i, 1], "std": stats[i, 2], "real_bitrate": real}
+            if is_bias:
+                m.dequant_b = deqs[i].reshape(t.shape)
+                m.bitrate_b_dict.update(d)
+            else:
+                m.dequant_w = deqs[i].reshape(t.shape)
+                m.bitrate_w_dict.update(d)
+        return True
+
     def cal_params(self, entropy_model=None):
         self._fused_bits_total = None
         if self.training and getattr(self, "cem_fused", True) and self._cal_params_fused(entropy_model):

@@ -243,18 +243,25 @@ def evaluate(model, full_dataloader, local_rank, args, dump_vis=False, coding=Fa
     model._fused_bits_total = None          # the rate dictionaries are refilled below: a cached training-step total must not be reported
     device = next(model.parameters()).device
     side_params, n_stats = 0, 0
+    # every tensor's rounded symbols, estimated bits and coded bits in one fused pass + one host copy (model_nerv._CEMHooks); the
+    # tensor-by-tensor loop of the reference (:466-489) below serves the settings the fused kernel does not (BNERV_CEM_EVAL_FUSED=0 forces it)
+    fused = (os.environ.get("BNERV_CEM_EVAL_FUSED", "1") != "0" and getattr(model, "cem_fused", True)
+             and hasattr(model, "cal_params_eval_fused") and model.cal_params_eval_fused(entropy_model))
     for m in _quant_modules(model):
         for kind in ('weight', 'bias'):
             tensor = getattr(m, kind)
             if tensor is None:
                 continue
             quantizer = getattr(m, f'{kind}_quantizer')
-            code, symbols, dequant = quantizer(tensor)
-            setattr(m, 'dequant_w' if kind == 'weight' else 'dequant_b', dequant)
             side_params += sum(p.numel() for p in quantizer.parameters())
             if entropy_model is not None:
-                getattr(m, 'bitrate_w_dict' if kind == 'weight' else 'bitrate_b_dict').update(entropy_model.cal_bitrate(code, symbols, False))
                 n_stats += 2                # (mean, std) of the tensor's Gaussian
+            if fused:
+                continue
+            code, symbols, dequant = quantizer(tensor)
+            setattr(m, 'dequant_w' if kind == 'weight' else 'dequant_b', dequant)
+            if entropy_model is not None:
+                getattr(m, 'bitrate_w_dict' if kind == 'weight' else 'bitrate_b_dict').update(entropy_model.cal_bitrate(code, symbols, False))
     is_hnerv = "HNeRV" in args.model
     takes_image = 'pe' not in args.embed or "HNeRV_Boost" in args.model
     if is_hnerv:

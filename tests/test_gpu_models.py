@@ -723,6 +723,54 @@ def test_cem_hooks_against_reference_golden():
         torch.testing.assert_close(p.grad.cpu(), torch.from_numpy(npz[f"grad/{k}"]), rtol=2e-3, atol=2e-3 * float(np.abs(npz[f"grad/{k}"]).max()) + 1e-6)
 
 
+def test_cem_eval_bits_fused_equals_tensor_loop():
+    """Evaluation-time bit accounting (reference train_nerv_compression.py:466-489): the fused form -- one quantise + rate pass over
+    every tensor, one host copy, the host rANS coder on symbols rebuilt as np.rint(w / s) -- against the reference's tensor-by-tensor
+    loop on the same model: de-quantised tensors bit-equal, the same coded bits (the symbols are the same integers; the Gaussian's
+    mean / std come from two summation orders, which may move a message by a word), estimated bits within 1e-4."""
+    from boosting_nerv_amd.lib.entropy_model import DiffEntropyModel
+    from boosting_nerv_amd.model_hnerv import HNeRV_Boost
+    torch.manual_seed(3)
+    model = HNeRV_Boost(configs.tiny_hnerv_quant()).to(DEV)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() > 1:
+                p.mul_(1.0 + 0.5 * torch.rand_like(p))
+    model.init_data()
+    model.eval()
+    em = DiffEntropyModel("gaussian")
+    mods = model._quant_modules()
+    loop = []
+    with torch.no_grad():
+        for m in mods:
+            for kind in ("weight", "bias"):
+                t = getattr(m, kind)
+                if t is None:
+                    continue
+                code, sym, deq = getattr(m, f"{kind}_quantizer")(t)
+                r = em.cal_bitrate(code, sym, False)
+                loop.append((deq.clone(), float(r["bitrate"]), int(r["real_bitrate"]), float(r["mean"]), float(r["std"])))
+    assert model.cal_params_eval_fused(em) is True
+    i = 0
+    tot_loop = tot_fused = 0
+    for m in mods:
+        for kind in ("weight", "bias"):
+            if getattr(m, kind) is None:
+                continue
+            deq, est, real, mean, std = loop[i]
+            i += 1
+            d = m.bitrate_w_dict if kind == "weight" else m.bitrate_b_dict
+            assert torch.equal(m.dequant_w if kind == "weight" else m.dequant_b, deq), (i, kind)
+            assert abs(float(d["bitrate"]) - est) <= 1e-4 * est + 1e-2, (i, float(d["bitrate"]), est)
+            assert abs(float(d["mean"]) - mean) <= 1e-5 + 1e-5 * abs(mean) and abs(float(d["std"]) - std) <= 1e-5 * std + 1e-6
+            assert abs(int(d["real_bitrate"]) - real) <= 32, (i, d["real_bitrate"], real)
+            tot_loop += real
+            tot_fused += int(d["real_bitrate"])
+    assert i == len(loop) and abs(tot_loop - tot_fused) <= 32 * 4
+    assert abs(float(model.get_bitrate_sum("bitrate")) - sum(x[1] for x in loop)) <= 1e-4 * sum(x[1] for x in loop)
+    assert int(model.get_bitrate_sum("real_bitrate")) == tot_fused
+
+
 def test_compression_cli_end_to_end(tmp_path, monkeypatch):
     """train_nerv_compression.py on a tiny synthetic clip (4 frames, 180x320, tiny HNeRV_Boost): 3 epochs of the rate-distortion
     step with the fused CEM kernel, then the evaluation report.  The rate must fall (lambda pushes it towards the target), the
