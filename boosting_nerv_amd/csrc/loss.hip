@@ -570,31 +570,99 @@ __device__ void butterfly_generic(float2* buf, int base, int M, int j, int tstri
     for (int q = 0; q < R; ++q) buf[base + q * M] = o[q];
 }
 
-template <bool ADJ>
-__device__ void fft_stage(float2* buf, int nlines, int lstride, int Ns, int R, const FftPlan& pl, const float2* tw) {
+// all butterflies of one stage, radix R known at compile time.  A thread's butterflies (2-3 per stage at 720 / 1280 points) are
+// independent: the loop is unrolled by UNR so that their LDS reads are in flight together instead of one round trip per butterfly.
+template <int R, bool ADJ>
+__device__ __forceinline__ void fft_stage_r(float2* buf, int nlines, int lstride, int Ns, const FftPlan& pl, const float2* tw) {
     const int N = pl.N, M = Ns / R, per_line = N / R, tstride = N / Ns;
     // index split by reciprocal multiplication (operands < 2^20, quotients < 2^11: the +0.5 margin dwarfs the rounding error) and
     // 24-bit multiplies: a runtime integer division costs ~40 instructions and a 32-bit multiply issues at quarter rate, and this
-    // loop is instruction-latency bound (a few butterflies per thread per stage, one block per CU)
+    // loop is instruction-latency bound (a few butterflies per thread per stage)
     const float inv_pl = 1.0f / (float)per_line, inv_M = 1.0f / (float)M;
-    for (int bf = threadIdx.x; bf < nlines * per_line; bf += blockDim.x) {
-        const int line = (int)(((float)bf + 0.5f) * inv_pl), rem = bf - __mul24(line, per_line);
-        const int blk = (int)(((float)rem + 0.5f) * inv_M), j = rem - __mul24(blk, M);
-        const int base = __mul24(line, lstride) + __mul24(blk, Ns) + j;
-        switch (R) {
-            case 2: butterfly<2, ADJ>(buf, base, M, j, tstride, pl, tw); break;
-            case 3: butterfly<3, ADJ>(buf, base, M, j, tstride, pl, tw); break;
-            case 4: butterfly<4, ADJ>(buf, base, M, j, tstride, pl, tw); break;
-            case 5: butterfly<5, ADJ>(buf, base, M, j, tstride, pl, tw); break;
-            default: butterfly_generic<ADJ>(buf, base, M, j, tstride, R, pl, tw); break;
+    const int total = nlines * per_line;
+    constexpr int UNR = ADJ ? 2 : 3;                       // (measured: the forward row pass 26 us at 3 / 35 at 2, the adjoint row pass 21 at 3 / 18 at 2; columns indifferent)
+    for (int bf0 = threadIdx.x; bf0 < total; bf0 += UNR * blockDim.x) {
+        float2 v[UNR][R], o[UNR][R];
+        int base[UNR], t1[UNR];
+        bool on[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int bf = bf0 + u * blockDim.x;
+            on[u] = bf < total;
+            const int bfc = on[u] ? bf : 0;
+            const int line = (int)(((float)bfc + 0.5f) * inv_pl), rem = bfc - __mul24(line, per_line);
+            const int blk = (int)(((float)rem + 0.5f) * inv_M), j = rem - __mul24(blk, M);
+            base[u] = __mul24(line, lstride) + __mul24(blk, Ns) + j;
+            t1[u] = __mul24(tstride, j);                   // j < Ns/R: t1 * q < N for q < R, no wrap
+#pragma unroll
+            for (int m = 0; m < R; ++m) v[u][m] = buf[base[u] + __mul24(m, M)];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (ADJ) {
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[u][q] = cmulc(v[u][q], tw[t1[u] * q]);
+                dft_core<R, +1>(v[u], o[u]);
+            } else {
+                dft_core<R, -1>(v[u], o[u]);
+#pragma unroll
+                for (int q = 1; q < R; ++q) o[u][q] = cmul(o[u][q], tw[t1[u] * q]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (on[u]) {
+#pragma unroll
+                for (int q = 0; q < R; ++q) buf[base[u] + __mul24(q, M)] = o[u][q];
+            }
         }
     }
     __syncthreads();
 }
 
-// `tw`: the plan's twiddle table copied to LDS by load_twiddles (every butterfly reads up to 2R-1 entries)
-__device__ void load_twiddles(float2* tw, const FftPlan& pl) {
-    for (int i = threadIdx.x; i < pl.N; i += blockDim.x) tw[i] = pl.tw[i];
+template <bool ADJ>
+__device__ void fft_stage(float2* buf, int nlines, int lstride, int Ns, int R, const FftPlan& pl, const float2* tw) {
+    switch (R) {
+        case 2: fft_stage_r<2, ADJ>(buf, nlines, lstride, Ns, pl, tw); return;
+        case 3: fft_stage_r<3, ADJ>(buf, nlines, lstride, Ns, pl, tw); return;
+        case 4: fft_stage_r<4, ADJ>(buf, nlines, lstride, Ns, pl, tw); return;
+        case 5: fft_stage_r<5, ADJ>(buf, nlines, lstride, Ns, pl, tw); return;
+        default: break;
+    }
+    const int N = pl.N, M = Ns / R, per_line = N / R, tstride = N / Ns;
+    const float inv_pl = 1.0f / (float)per_line, inv_M = 1.0f / (float)M;
+    for (int bf = threadIdx.x; bf < nlines * per_line; bf += blockDim.x) {
+        const int line = (int)(((float)bf + 0.5f) * inv_pl), rem = bf - __mul24(line, per_line);
+        const int blk = (int)(((float)rem + 0.5f) * inv_M), j = rem - __mul24(blk, M);
+        const int base = __mul24(line, lstride) + __mul24(blk, Ns) + j;
+        butterfly_generic<ADJ>(buf, base, M, j, tstride, R, pl, tw);
+    }
+    __syncthreads();
+}
+
+// `tw`: the plan's twiddle table (and, for the row kernels, the frequency -> buffer position table) copied to LDS.  The copy is split
+// into an issue half (global loads into registers, up to TAB_U per thread) and a commit half (LDS stores), so that a kernel can put its
+// own input loads between the two: ONE memory round trip for tables and data instead of one per loop iteration (these blocks are a
+// single latency chain each -- there is about one transform line per SIMD on the chip -- so every round trip shows in the launch).
+constexpr int TAB_U = 8;
+struct TabRegs { float2 t[TAB_U]; int p[TAB_U]; };
+template <bool POS>
+__device__ __forceinline__ void tables_issue(TabRegs& r, const FftPlan& pl) {
+#pragma unroll
+    for (int u = 0; u < TAB_U; ++u) {
+        const int i = threadIdx.x + u * blockDim.x;
+        r.t[u] = i < pl.N ? pl.tw[i] : float2{0.f, 0.f};
+        if (POS) r.p[u] = i < pl.N ? pl.pos[i] : 0;
+    }
+}
+template <bool POS>
+__device__ __forceinline__ void tables_commit(const TabRegs& r, float2* tw, int* lpos, const FftPlan& pl) {
+#pragma unroll
+    for (int u = 0; u < TAB_U; ++u) {
+        const int i = threadIdx.x + u * blockDim.x;
+        if (i < pl.N) { tw[i] = r.t[u]; if (POS) lpos[i] = r.p[u]; }
+    }
+    for (int i = threadIdx.x + TAB_U * blockDim.x; i < pl.N; i += blockDim.x) { tw[i] = pl.tw[i]; if (POS) lpos[i] = pl.pos[i]; }   // (N > 2048)
 }
 __device__ void fft_forward(float2* buf, int nlines, int lstride, const FftPlan& pl, const float2* tw) {
     int Ns = pl.N;
@@ -605,7 +673,18 @@ __device__ void fft_adjoint(float2* buf, int nlines, int lstride, const FftPlan&
     for (int s = pl.nrad - 1; s >= 0; --s) { Ns *= pl.rad[s]; fft_stage<true>(buf, nlines, lstride, Ns, pl.rad[s], pl, tw); }
 }
 
-constexpr int ROWS_PER_BLOCK = 2;
+// The row transforms work on PAIRS of real rows: z = a + i b is ONE complex transform, and the two real rows' spectra are its
+// Hermitian and anti-Hermitian parts, A[f] = (Z[f] + conj Z[W - f]) / 2, B[f] = (Z[f] - conj Z[W - f]) / (2 i).  The adjoint pass is the
+// same idea backwards: a row's gradient is Re(F^H G) of its mirrored spectrum G, which only sees G's Hermitian part (the entries
+// f = 0 and f = W / 2 enter with their real parts), so F^H (G_a + i G_b) = grad_a + i grad_b.  Half the butterflies of the
+// row-by-row form (these kernels are instruction-bound) for the same HBM traffic.
+#ifndef BNERV_FFT_LINES
+#define BNERV_FFT_LINES 1
+#endif
+constexpr int LINES_PER_BLOCK = BNERV_FFT_LINES;            // complex lines (row pairs) per block
+constexpr int ROWS_PER_BLOCK = 2 * LINES_PER_BLOCK;
+static_assert(LINES_PER_BLOCK == 1 || LINES_PER_BLOCK == 2, "the staging loops of the row kernels split their index into at most two lines");
+constexpr int ROW_U = LINES_PER_BLOCK == 1 ? 5 : 4;         // input elements per thread and batch (1280 points on 256 threads: one batch)
 constexpr int COLS_PER_BLOCK = 4;
 
 struct FftArgs {
@@ -628,29 +707,40 @@ __device__ __forceinline__ void fft_rows_fwd_body(const FftArgs& a, const int bx
     const size_t row0 = (size_t)bx * ROWS_PER_BLOCK;                    // global row index over BC*H
     const size_t nrows = (size_t)a.BC * a.H;
     const int nl = (int)min((size_t)ROWS_PER_BLOCK, nrows - row0);
-    float2* tw = buf + ROWS_PER_BLOCK * W;
-    load_twiddles(tw, a.prow);
-    for (int i0 = threadIdx.x; i0 < nl * W; i0 += blockDim.x * 8) {       // 16 loads in flight per thread, then the LDS stores
-        float pv[8], tv[8];
+    const int nlines = (nl + 1) >> 1;                                    // complex lines: rows (2 l, 2 l + 1) -> real / imaginary part
+    float2* tw = buf + LINES_PER_BLOCK * W;
+    int* lpos = reinterpret_cast<int*>(tw + W);
+    TabRegs tr;
+    tables_issue<true>(tr, a.prow);
+    bool tabs_done = false;
+    for (int i0 = threadIdx.x; i0 < nlines * W; i0 += blockDim.x * ROW_U) {   // 4 ROW_U loads in flight per thread (+ the tables), then the LDS stores
+        float pa[ROW_U], ta[ROW_U], pb[ROW_U], tb[ROW_U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < ROW_U; ++u) {
             const int i = i0 + u * blockDim.x;
-            const bool ok = i < nl * W;
-            pv[u] = ok ? a.pred[row0 * W + i] : 0.f;
-            tv[u] = ok ? a.target[row0 * W + i] : 0.f;
+            const int line = (LINES_PER_BLOCK > 1 && i >= W) ? 1 : 0, x = i - line * W;
+            const bool oka = i < nlines * W, okb = oka && 2 * line + 1 < nl;
+            const size_t o = (row0 + 2 * line) * W + x;
+            pa[u] = oka ? a.pred[o] : 0.f;     ta[u] = oka ? a.target[o] : 0.f;
+            pb[u] = okb ? a.pred[o + W] : 0.f; tb[u] = okb ? a.target[o + W] : 0.f;
         }
+        if (!tabs_done) { tables_commit<true>(tr, tw, lpos, a.prow); tabs_done = true; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < ROW_U; ++u) {
             const int i = i0 + u * blockDim.x;
-            if (i < nl * W) buf[i] = float2{pv[u] - tv[u], 0.f};
+            if (i < nlines * W) buf[i] = float2{pa[u] - ta[u], pb[u] - tb[u]};
         }
     }
+    if (!tabs_done) tables_commit<true>(tr, tw, lpos, a.prow);            // (a thread without input elements still owns table entries)
     __syncthreads();
-    fft_forward(buf, nl, W, a.prow, tw);
+    fft_forward(buf, nlines, W, a.prow, tw);
     const int Wh = a.Wh;
     for (int i = threadIdx.x; i < nl * Wh; i += blockDim.x) {
-        const int line = i / Wh, f = i - line * Wh;
-        a.T[(row0 + line) * Wh + f] = buf[line * W + a.prow.pos[f]];
+        const int row = i / Wh, f = i - row * Wh;
+        const float2* ln = buf + (row >> 1) * W;
+        const float2 z = ln[lpos[f]], m = ln[lpos[f == 0 ? 0 : W - f]];
+        // even row: (Z[f] + conj Z[W - f]) / 2;  odd row: (Z[f] - conj Z[W - f]) / (2 i)
+        a.T[(row0 + row) * Wh + f] = (row & 1) ? float2{0.5f * (z.y + m.y), 0.5f * (m.x - z.x)} : float2{0.5f * (z.x + m.x), 0.5f * (z.y - m.y)};
     }
 }
 __global__ __launch_bounds__(256) void fft_rows_fwd_kernel(const FftArgs a) { fft_rows_fwd_body(a, blockIdx.x); }
@@ -664,8 +754,10 @@ __device__ __forceinline__ void fft_cols_body(const FftArgs& a, const int bx, co
     const int nc = min(COLS_PER_BLOCK, W - v0);
     float2* T = a.T + (size_t)bc * H * W;
     float2* tw = buf + COLS_PER_BLOCK * H;
-    load_twiddles(tw, a.pcol);
-    for (int i0 = threadIdx.x; i0 < H * nc; i0 += blockDim.x * 8) {       // column gather: 8 loads in flight per thread
+    TabRegs tr;
+    tables_issue<false>(tr, a.pcol);
+    bool tabs_done = false;
+    for (int i0 = threadIdx.x; i0 < H * nc; i0 += blockDim.x * 8) {       // column gather: 8 loads in flight per thread (+ the twiddles)
         float2 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -673,6 +765,7 @@ __device__ __forceinline__ void fft_cols_body(const FftArgs& a, const int bx, co
             const int y = i / nc, c = i - y * nc;
             v[u] = i < H * nc ? T[(size_t)y * W + v0 + c] : float2{0.f, 0.f};
         }
+        if (!tabs_done) { tables_commit<false>(tr, tw, nullptr, a.pcol); tabs_done = true; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = i0 + u * blockDim.x;
@@ -680,6 +773,7 @@ __device__ __forceinline__ void fft_cols_body(const FftArgs& a, const int bx, co
             if (i < H * nc) buf[c * H + y] = v[u];
         }
     }
+    if (!tabs_done) tables_commit<false>(tr, tw, nullptr, a.pcol);
     __syncthreads();
     fft_forward(buf, nc, H, a.pcol, tw);
     float acc = 0.f;
@@ -710,39 +804,77 @@ __global__ __launch_bounds__(256) void fft_rows_adj_kernel(const FftArgs a) {
     const size_t row0 = (size_t)blockIdx.x * ROWS_PER_BLOCK;
     const size_t nrows = (size_t)a.BC * a.H;
     const int nl = (int)min((size_t)ROWS_PER_BLOCK, nrows - row0);
-    float2* tw = buf + ROWS_PER_BLOCK * W;
-    load_twiddles(tw, a.prow);
+    const int nlines = (nl + 1) >> 1;
+    float2* tw = buf + LINES_PER_BLOCK * W;
+    int* lpos = reinterpret_cast<int*>(tw + W);
     const int Wh = a.Wh;
-    for (int i0 = threadIdx.x; i0 < nl * Wh; i0 += blockDim.x * 8) {      // kept columns + their conjugate mirrors, into DIF order
-        float2 v[8];
+    TabRegs tr;
+    tables_issue<true>(tr, a.prow);
+    constexpr int AU = 4;
+    // P = G_a + i G_b of the row pair, G = kept columns + their conjugate mirrors (self-mirrored columns with their real parts), into DIF order
+    for (int i0 = threadIdx.x, first = 1; first || i0 < nlines * Wh; i0 += blockDim.x * AU, first = 0) {   // (every thread runs the first batch: it holds the barrier)
+        float2 va[AU], vb[AU];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < AU; ++u) {
             const int i = i0 + u * blockDim.x;
-            v[u] = i < nl * Wh ? a.T[row0 * Wh + i] : float2{0.f, 0.f};
+            const int line = (LINES_PER_BLOCK > 1 && i >= Wh) ? 1 : 0, f = i - line * Wh;
+            const bool oka = i < nlines * Wh, okb = oka && 2 * line + 1 < nl;
+            const size_t o = (row0 + 2 * line) * Wh + f;
+            va[u] = oka ? a.T[o] : float2{0.f, 0.f};
+            vb[u] = okb ? a.T[o + Wh] : float2{0.f, 0.f};
         }
+        if (first) { tables_commit<true>(tr, tw, lpos, a.prow); __syncthreads(); }     // (the position table is read below)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < AU; ++u) {
             const int i = i0 + u * blockDim.x;
-            if (i < nl * Wh) {
-                const int line = i / Wh, f = i - line * Wh;
-                buf[line * W + a.prow.pos[f]] = v[u];
-                if (f > 0 && 2 * f != W) buf[line * W + a.prow.pos[W - f]] = float2{v[u].x, -v[u].y};
+            if (i < nlines * Wh) {
+                const int line = (LINES_PER_BLOCK > 1 && i >= Wh) ? 1 : 0, f = i - line * Wh;
+                float2 ga = va[u], gb = vb[u];
+                const bool self = f == 0 || 2 * f == W;
+                if (self) { ga.y = 0.f; gb.y = 0.f; }
+                buf[line * W + lpos[f]] = float2{ga.x - gb.y, ga.y + gb.x};                       // G_a[f] + i G_b[f]
+                if (!self) buf[line * W + lpos[W - f]] = float2{ga.x + gb.y, gb.x - ga.y};         // conj G_a[f] + i conj G_b[f]
             }
         }
     }
-    __syncthreads();
-    fft_adjoint(buf, nl, W, a.prow, tw);
-    for (int i0 = threadIdx.x; i0 < nl * W; i0 += blockDim.x * 8) {
-        float gv[8];
+    // the gradient this launch adds to: loaded under the transform
+    float ga[2 * ROW_U], gb[2 * ROW_U];
+    const bool one_batch = nlines * W <= 2 * ROW_U * (int)blockDim.x;
+    if (one_batch) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * blockDim.x;
-            gv[u] = (a.accumulate && i < nl * W) ? a.grad[row0 * W + i] : 0.f;
+        for (int u = 0; u < 2 * ROW_U; ++u) {
+            const int i = threadIdx.x + u * blockDim.x;
+            const int line = (LINES_PER_BLOCK > 1 && i >= W) ? 1 : 0, x = i - line * W;
+            const bool oka = i < nlines * W, okb = oka && 2 * line + 1 < nl;
+            const size_t o = (row0 + 2 * line) * W + x;
+            ga[u] = (a.accumulate && oka) ? a.grad[o] : 0.f;
+            gb[u] = (a.accumulate && okb) ? a.grad[o + W] : 0.f;
+        }
+    }
+    __syncthreads();
+    fft_adjoint(buf, nlines, W, a.prow, tw);
+    for (int i0 = threadIdx.x; i0 < nlines * W; i0 += blockDim.x * 2 * ROW_U) {
+        if (!one_batch) {
+#pragma unroll
+            for (int u = 0; u < 2 * ROW_U; ++u) {
+                const int i = i0 + u * blockDim.x;
+                const int line = (LINES_PER_BLOCK > 1 && i >= W) ? 1 : 0, x = i - line * W;
+                const bool oka = i < nlines * W, okb = oka && 2 * line + 1 < nl;
+                const size_t o = (row0 + 2 * line) * W + x;
+                ga[u] = (a.accumulate && oka) ? a.grad[o] : 0.f;
+                gb[u] = (a.accumulate && okb) ? a.grad[o + W] : 0.f;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 2 * ROW_U; ++u) {
             const int i = i0 + u * blockDim.x;
-            if (i < nl * W) a.grad[row0 * W + i] = gv[u] + a.gscale * buf[i].x;
+            if (i < nlines * W) {
+                const int line = (LINES_PER_BLOCK > 1 && i >= W) ? 1 : 0, x = i - line * W;
+                const size_t o = (row0 + 2 * line) * W + x;
+                const float2 r = buf[i];
+                a.grad[o] = ga[u] + a.gscale * r.x;
+                if (2 * line + 1 < nl) a.grad[o + W] = gb[u] + a.gscale * r.y;
+            }
         }
     }
 }
@@ -811,8 +943,13 @@ __global__ __launch_bounds__(256) void loss_head_kernel(const LossHeadArgs a) {
 struct LossMidArgs { FftArgs f; CoefArgs c; int ncolblk, n_cols; };
 __global__ __launch_bounds__(256) void loss_mid_kernel(const LossMidArgs a) {
     const int b = blockIdx.x;
-    if (b < a.n_cols) fft_cols_body(a.f, b % a.ncolblk, b / a.ncolblk, a.ncolblk);
-    else ms_coef_body(a.c, b - a.n_cols);
+    if (b < a.n_cols) {
+        // neighbouring column panels share the 128-byte lines of every row of T: give each XCD (blocks b, b + 8, ...) a CONTIGUOUS run of
+        // panels, so that a line is fetched into one L2 instead of four
+        const int xcd = b & 7, k = b >> 3, per = a.n_cols >> 3, extra = a.n_cols & 7;
+        const int lb = xcd * per + min(xcd, extra) + k;
+        fft_cols_body(a.f, lb % a.ncolblk, lb / a.ncolblk, a.ncolblk);
+    } else ms_coef_body(a.c, b - a.n_cols);
 }
 struct LossTailArgs { SsimArgs s; CoarseChain cc; FinalArgs fin; int gx, gy, n0, BC; };
 __global__ __launch_bounds__(256) void loss_tail_kernel(const LossTailArgs a) {
@@ -1040,7 +1177,7 @@ extern "C" int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* dp) {
             return bnerv_set_error(BNERV_E_ARG, "loss: FFT size %dx%d has a prime factor > %d", d.H, d.W, BNERV_FFT_MAX_RADIX);
         a.pred = d.pred; a.target = d.target; a.T = reinterpret_cast<float2*>(ws + L.T); a.Wh = d.W / 2 + 1; a.partial = ws + L.fft_part; a.grad = d.grad;
         a.BC = BC; a.H = d.H; a.W = d.W; a.gscale = d.c_fft / ((float)d.B * (float)nps * 2.0f); a.accumulate = 1;
-        lds_row = (size_t)(ROWS_PER_BLOCK + 1) * d.W * sizeof(float2); lds_col = (size_t)(COLS_PER_BLOCK + 1) * d.H * sizeof(float2);   // + twiddle table
+        lds_row = (size_t)(LINES_PER_BLOCK + 1) * d.W * sizeof(float2) + (size_t)d.W * sizeof(int); lds_col = (size_t)(COLS_PER_BLOCK + 1) * d.H * sizeof(float2);   // + twiddle table (+ position table)
         BNERV_REQUIRE(lds_row <= 160 * 1024 && lds_col <= 160 * 1024, "loss: frame %dx%d too large for the LDS FFT", d.H, d.W);
         nrowblk = cdiv(BC * d.H, ROWS_PER_BLOCK);
     }
