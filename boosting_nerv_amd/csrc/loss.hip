@@ -206,10 +206,19 @@ struct SsimArgs {
 };
 
 // ---- forward: per-tile sum of cs (LAST=false) or ssim (LAST=true) over the valid region ----
+// The filter passes run on PACKED pairs of maps (v_pk_fma_f32: two fused multiply-adds per issued instruction; these kernels are bound
+// by instruction issue): (x, y) live interleaved in LDS, so a tap is one 8-byte read and pk_fma(g, (x, y)), pk_fma(g, (x x, y y)),
+// fma(g, x y) -- five instructions for the eight of the scalar form; the second pass reads (v0, v1), (v2, v3), v4 likewise.  Every
+// lane of a packed operation is the same IEEE fma in the same tap order as before: the numbers keep their bits.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 __device__ __forceinline__ void ssim_fwd_body(const SsimArgs& a, const bool LAST, const int bx, const int by, const int bc, const int nbc) {
+#pragma clang fp contract(off)                           // the SSIM algebra as written (products rounded, then added -- as the reference's tensor ops do), identical in every instantiation; the filter taps are explicit fmas
     constexpr int WH = STH + HW_, WW = STW + HW_;        // 26 x 42 input window
-    __shared__ float sX[WH][WW], sY[WH][WW];
-    __shared__ float sV[5][STH][WW];
+    __shared__ pk2 sXY[WH][WW];
+    __shared__ pk2 sV01[STH][WW], sV23[STH][WW];
+    __shared__ float sV4[STH][WW];
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const int oy0 = by * STH, ox0 = bx * STW;
@@ -219,33 +228,36 @@ __device__ __forceinline__ void ssim_fwd_body(const SsimArgs& a, const bool LAST
         const int r = i / WW, c = i - r * WW;
         const int y = oy0 + r, x = ox0 + c;
         const bool in = y < a.H && x < a.W;
-        sX[r][c] = in ? X[(size_t)y * a.W + x] : 0.f;
-        sY[r][c] = in ? Y[(size_t)y * a.W + x] : 0.f;
+        sXY[r][c] = pk2{in ? X[(size_t)y * a.W + x] : 0.f, in ? Y[(size_t)y * a.W + x] : 0.f};
     }
     __syncthreads();
     // vertical (along H) first, as the reference filters dim 2 then dim 3
     for (int i = tid; i < STH * WW; i += 256) {
         const int r = i / WW, c = i - r * WW;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+        pk2 v01 = {0.f, 0.f}, v23 = {0.f, 0.f};
+        float v4 = 0.f;
 #pragma unroll
         for (int k = 0; k < WS_; ++k) {
-            const float g = a.win.g[k], x = sX[r + k][c], y = sY[r + k][c];
-            v0 = fmaf(g, x, v0); v1 = fmaf(g, y, v1); v2 = fmaf(g, x * x, v2); v3 = fmaf(g, y * y, v3); v4 = fmaf(g, x * y, v4);
+            const float g = a.win.g[k];
+            const pk2 gg = {g, g}, xy = sXY[r + k][c];
+            v01 = pk_fma(gg, xy, v01); v23 = pk_fma(gg, xy * xy, v23); v4 = fmaf(g, xy.x * xy.y, v4);
         }
-        sV[0][r][c] = v0; sV[1][r][c] = v1; sV[2][r][c] = v2; sV[3][r][c] = v3; sV[4][r][c] = v4;
+        sV01[r][c] = v01; sV23[r][c] = v23; sV4[r][c] = v4;
     }
     __syncthreads();
     float acc = 0.f;
     const int Hv = a.H - HW_, Wv = a.W - HW_;
     for (int i = tid; i < STH * STW; i += 256) {
         const int r = i / STW, c = i - r * STW;
-        float m1 = 0.f, m2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+        pk2 m = {0.f, 0.f}, e = {0.f, 0.f};
+        float exy = 0.f;
 #pragma unroll
         for (int k = 0; k < WS_; ++k) {
             const float g = a.win.g[k];
-            m1 = fmaf(g, sV[0][r][c + k], m1); m2 = fmaf(g, sV[1][r][c + k], m2);
-            exx = fmaf(g, sV[2][r][c + k], exx); eyy = fmaf(g, sV[3][r][c + k], eyy); exy = fmaf(g, sV[4][r][c + k], exy);
+            const pk2 gg = {g, g};
+            m = pk_fma(gg, sV01[r][c + k], m); e = pk_fma(gg, sV23[r][c + k], e); exy = fmaf(g, sV4[r][c + k], exy);
         }
+        const float m1 = m.x, m2 = m.y, exx = e.x, eyy = e.y;
         if (oy0 + r < Hv && ox0 + c < Wv) {
             const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
             const float s1 = exx - m11, s2 = eyy - m22, s12 = exy - m12;
@@ -336,8 +348,8 @@ struct CoarseChain { const float* own[LV]; int H[LV], W[LV]; int n; };     // le
 template <bool LEVEL0>
 __device__ __forceinline__ void ssim_bwd_body(const SsimArgs& a, const CoarseChain* cc, const int bx, const int by, const int bc, const int nbc) {
     constexpr int GH = STH + HW_, GW = STW + HW_;        // 26 x 42 statistic-gradient region
-    __shared__ float sG[3][GH][GW];
-    __shared__ float sA[3][STH][GW];
+    __shared__ pk2 sG01[GH][GW], sA01[STH][GW];          // packed pairs of maps, as in the forward pass
+    __shared__ float sG2[GH][GW], sA2[STH][GW];
     const int tid = threadIdx.x;
     const int py0 = by * STH, px0 = bx * STW;
     const int wy0 = py0 - HW_, wx0 = px0 - HW_;
@@ -352,20 +364,20 @@ __device__ __forceinline__ void ssim_bwd_body(const SsimArgs& a, const CoarseCha
             const size_t o = (size_t)oy * a.W + ox;
             g0 = Gp[o]; g1 = Gp[mstride + o]; g2 = Gp[2 * mstride + o];
         }
-        sG[0][r][c] = g0; sG[1][r][c] = g1; sG[2][r][c] = g2;
+        sG01[r][c] = pk2{g0, g1}; sG2[r][c] = g2;
     }
     __syncthreads();
     for (int i = tid; i < STH * GW; i += 256) {
         const int r = i / GW, c = i - r * GW;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        pk2 a01 = {0.f, 0.f};
+        float a2 = 0.f;
 #pragma unroll
         for (int k = 0; k < WS_; ++k) {
             const float g = a.win.g[k];
-            a0 = fmaf(g, sG[0][r + HW_ - k][c], a0);
-            a1 = fmaf(g, sG[1][r + HW_ - k][c], a1);
-            a2 = fmaf(g, sG[2][r + HW_ - k][c], a2);
+            a01 = pk_fma(pk2{g, g}, sG01[r + HW_ - k][c], a01);
+            a2 = fmaf(g, sG2[r + HW_ - k][c], a2);
         }
-        sA[0][r][c] = a0; sA[1][r][c] = a1; sA[2][r][c] = a2;
+        sA01[r][c] = a01; sA2[r][c] = a2;
     }
     __syncthreads();
     const float coef = a.coef[bc];
@@ -375,14 +387,15 @@ __device__ __forceinline__ void ssim_bwd_body(const SsimArgs& a, const CoarseCha
         const int r = i / STW, c = i - r * STW;
         const int y = py0 + r, x = px0 + c;
         if (y >= a.H || x >= a.W) continue;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        pk2 a01 = {0.f, 0.f};
+        float a2 = 0.f;
 #pragma unroll
         for (int k = 0; k < WS_; ++k) {
             const float g = a.win.g[k];
-            a0 = fmaf(g, sA[0][r][c + HW_ - k], a0);
-            a1 = fmaf(g, sA[1][r][c + HW_ - k], a1);
-            a2 = fmaf(g, sA[2][r][c + HW_ - k], a2);
+            a01 = pk_fma(pk2{g, g}, sA01[r][c + HW_ - k], a01);
+            a2 = fmaf(g, sA2[r][c + HW_ - k], a2);
         }
+        const float a0 = a01.x, a1 = a01.y;
         const float xv = X[(size_t)y * a.W + x], yv = Y[(size_t)y * a.W + x];
         float d = coef * (a0 + 2.f * xv * a1 + yv * a2);
         if (a.dcoarse) d += 0.25f * a.dcoarse[((size_t)bc * a.Hc + (y + a.ph) / 2) * a.Wc + (x + a.pw) / 2];
