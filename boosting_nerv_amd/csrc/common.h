@@ -30,48 +30,98 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// Epilogue math on PACKED pairs (v_pk_fma_f32 / v_pk_mul_f32: two lanes of arithmetic per issued instruction).  The conv kernels are bound
+// by instruction issue, and beside the f32 MFMA the vector instructions do not hide at all: the GELU pair and the
+// sin / cos pair of an epilogue were ~29 and ~25 VALU per ELEMENT; as pairs they are ~24 and ~34 per TWO elements.  Every packed lane is the
+// IEEE operation of the scalar form in the same order (contraction off, every fused multiply-add written out), so the scalar entry points
+// below -- the same code on one lane -- give the same bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+
 // h = gelu(x) and g = gelu'(x) together, sharing ONE exp: e = exp(-x^2/2) is both the pdf factor and the tail of
 //   erf(z) = sign(z) * (1 - (a1 t + ... + a5 t^5) e^{-z^2}),  t = 1/(1 + p|z|),  z = x/sqrt(2)      (Abramowitz-Stegun 7.1.26)
 // |error| <= 1.5e-7 on erf, i.e. 7.5e-8 on the normal cdf: at the level of one fp32 ulp of the results.  Used where both values
-// are produced at once (the TAT conv0 epilogue); ~29 VALU per element instead of ~54 for gelu_f + gelu_grad_f.
-__device__ __forceinline__ void gelu_pair_f(float x, float* h, float* g) {
-    // e = exp(-x^2/2) <= 1 as one v_exp_f32 (1 ulp): the argument's rounding error |arg| * 2^-24 is relative to e itself, i.e.
-    // below 2e-10 absolute everywhere -- far inside the A-S bound; expf() spends ~10 VALU on ranges that cannot occur here
-    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
-    const float az = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);   // v_rcp_f32 (1 ulp) -- the IEEE division sequence costs ~10 VALU
-    float poly = 1.061405429f;
-    poly = fmaf(poly, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float erf_abs = 1.0f - poly * t * e;
-    const float cdf = 0.5f + 0.5f * copysignf(erf_abs, x);
+// are produced at once (the TAT conv0 epilogue).
+//   e = exp(-x^2/2) <= 1 as one v_exp_f32 (1 ulp): the argument's rounding error |arg| * 2^-24 is relative to e itself, i.e. below 2e-10
+//   absolute everywhere -- far inside the A-S bound; expf() spends ~10 VALU on ranges that cannot occur here.  t through v_rcp_f32 (1 ulp):
+//   the IEEE division sequence costs ~10 VALU.
+__device__ __forceinline__ void gelu_pair2_f(f32x2 x, f32x2* h, f32x2* g) {
+#pragma clang fp contract(off)
+    const f32x2 arg = (x * x) * splat2(-0.72134752044448170368f);
+    const f32x2 e = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+    const f32x2 az = f32x2{fabsf(x.x), fabsf(x.y)} * splat2(0.70710678118654752440f);
+    const f32x2 den = pk_fma2(splat2(0.3275911f), az, splat2(1.0f));
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f32x2 poly = splat2(1.061405429f);
+    poly = pk_fma2(poly, t, splat2(-1.453152027f));
+    poly = pk_fma2(poly, t, splat2(1.421413741f));
+    poly = pk_fma2(poly, t, splat2(-0.284496736f));
+    poly = pk_fma2(poly, t, splat2(0.254829592f));
+    const f32x2 erf_abs = pk_fma2(-(poly * t), e, splat2(1.0f));
+    const f32x2 erf_s = {copysignf(erf_abs.x, x.x), copysignf(erf_abs.y, x.y)};
+    const f32x2 cdf = pk_fma2(splat2(0.5f), erf_s, splat2(0.5f));
     *h = x * cdf;
-    *g = fmaf(x, 0.39894228040143267794f * e, cdf);
+    *g = pk_fma2(x, splat2(0.39894228040143267794f) * e, cdf);
+}
+__device__ __forceinline__ void gelu_pair4_f(f32x4 x, f32x4* h, f32x4* g) {
+    f32x2 h0, g0, h1, g1;
+    gelu_pair2_f(f32x2{x.x, x.y}, &h0, &g0);
+    gelu_pair2_f(f32x2{x.z, x.w}, &h1, &g1);
+    *h = f32x4{h0.x, h0.y, h1.x, h1.y};
+    *g = f32x4{g0.x, g0.y, g1.x, g1.y};
+}
+__device__ __forceinline__ void gelu_pair_f(float x, float* h, float* g) {      // one element: the same operations, the same bits
+    f32x2 h2, g2;
+    gelu_pair2_f(splat2(x), &h2, &g2);
+    *h = h2.x; *g = g2.x;
 }
 
 // sin and cos together for the block activation (sin) and its saved derivative (cos): 3-term Cody-Waite reduction by pi/2 and
 // the cephes single-precision minimax polynomials on [-pi/4, pi/4]; |x| <= 8192 (activations are O(10)), libm beyond.
 // Measured against float64 through an identity 1x1 conv (tests/test_gpu_ops.py): max |error| < 2.4e-7 on [-8192, 8192].
-// ~25 VALU per pair instead of ~60 executed for sincosf (whose code also carries the Payne-Hanek path).
+__device__ __forceinline__ void sincos2_f(f32x2 x, f32x2* s, f32x2* c) {
+#pragma clang fp contract(off)
+    if (fabsf(x.x) > 8192.0f || fabsf(x.y) > 8192.0f) {
+        float s0, c0, s1, c1;
+        sincosf(x.x, &s0, &c0); sincosf(x.y, &s1, &c1);
+        *s = f32x2{s0, s1}; *c = f32x2{c0, c1};
+        return;
+    }
+    const f32x2 kx = x * splat2(0.63661977236758134308f);            // x * 2/pi
+    const f32x2 k = {rintf(kx.x), rintf(kx.y)};
+    f32x2 r = pk_fma2(-k, splat2(1.5703125f), x);                     // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188e-8
+    r = pk_fma2(-k, splat2(4.837512969970703125e-4f), r);
+    r = pk_fma2(-k, splat2(7.54978995489188e-8f), r);
+    const f32x2 z = r * r;
+    f32x2 sp = pk_fma2(z, splat2(-1.9515295891e-4f), splat2(8.3321608736e-3f));
+    sp = pk_fma2(sp, z, splat2(-1.6666654611e-1f));
+    const f32x2 sr = pk_fma2(sp * z, r, r);
+    f32x2 cp = pk_fma2(z, splat2(2.443315711809948e-5f), splat2(-1.388731625493765e-3f));
+    cp = pk_fma2(cp, z, splat2(4.166664568298827e-2f));
+    const f32x2 cr = pk_fma2(cp * z, z, pk_fma2(splat2(-0.5f), z, splat2(1.0f)));
+    // quadrant: odd -> swap, bit 1 -> sign of sin, bit 1 of q + 1 -> sign of cos (sign flips as xor on the bits)
+    const unsigned q0 = (unsigned)(int)k.x, q1 = (unsigned)(int)k.y;
+    // (element values copied to floats first: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 on this compiler)
+    const float srx = sr.x, sry = sr.y, crx = cr.x, cry = cr.y;
+    const unsigned sr0 = __builtin_bit_cast(unsigned, srx), cr0 = __builtin_bit_cast(unsigned, crx);
+    const unsigned sr1 = __builtin_bit_cast(unsigned, sry), cr1 = __builtin_bit_cast(unsigned, cry);
+    const unsigned ss0 = (q0 & 1u) ? cr0 : sr0, cc0 = (q0 & 1u) ? sr0 : cr0;
+    const unsigned ss1 = (q1 & 1u) ? cr1 : sr1, cc1 = (q1 & 1u) ? sr1 : cr1;
+    *s = f32x2{__builtin_bit_cast(float, ss0 ^ ((q0 << 30) & 0x80000000u)), __builtin_bit_cast(float, ss1 ^ ((q1 << 30) & 0x80000000u))};
+    *c = f32x2{__builtin_bit_cast(float, cc0 ^ (((q0 + 1u) << 30) & 0x80000000u)), __builtin_bit_cast(float, cc1 ^ (((q1 + 1u) << 30) & 0x80000000u))};
+}
+__device__ __forceinline__ void sincos4_f(f32x4 x, f32x4* s, f32x4* c) {
+    f32x2 s0, c0, s1, c1;
+    sincos2_f(f32x2{x.x, x.y}, &s0, &c0);
+    sincos2_f(f32x2{x.z, x.w}, &s1, &c1);
+    *s = f32x4{s0.x, s0.y, s1.x, s1.y};
+    *c = f32x4{c0.x, c0.y, c1.x, c1.y};
+}
 __device__ __forceinline__ void sincos_f(float x, float* s, float* c) {
-    if (fabsf(x) > 8192.0f) { sincosf(x, s, c); return; }
-    const float k = rintf(x * 0.63661977236758134308f);            // x * 2/pi
-    float r = fmaf(-k, 1.5703125f, x);                             // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188e-8
-    r = fmaf(-k, 4.837512969970703125e-4f, r);
-    r = fmaf(-k, 7.54978995489188e-8f, r);
-    const float z = r * r;
-    float sp = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
-    sp = fmaf(sp, z, -1.6666654611e-1f);
-    const float sr = fmaf(sp * z, r, r);
-    float cp = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    cp = fmaf(cp, z, 4.166664568298827e-2f);
-    const float cr = fmaf(cp * z, z, fmaf(-0.5f, z, 1.0f));
-    const int q = (int)k;
-    const float ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
-    *s = (q & 2) ? -ss : ss;
-    *c = ((q + 1) & 2) ? -cc : cc;
+    f32x2 s2, c2;
+    sincos2_f(splat2(x), &s2, &c2);
+    *s = s2.x; *c = c2.x;
 }
 
 // ---- wave64 / block reductions ----

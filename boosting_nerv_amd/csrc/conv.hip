@@ -974,8 +974,7 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     f32x4 sv, cv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(acc[m][e] + bias_l, &s_, &c_); sv[e] = s_; cv[e] = c_; }
+                    sincos4_f(acc[m] + bias_l, &sv, &cv);
                     bstore(ro, vo[m], so[m], sv);
                     if (d.out2) bstore(ro2, vo[m], so[m], cv);
                 }
@@ -983,8 +982,7 @@ __global__ __launch_bounds__(256, (NQ1 <= 3 ? 4 : 3)) void conv_lean_kernel(cons
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     f32x4 hv, gv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { float h_, g_; gelu_pair_f(acc[m][e] + bias_l, &h_, &g_); hv[e] = h_; gv[e] = g_; }
+                    gelu_pair4_f(acc[m] + bias_l, &hv, &gv);
                     bstore(ro, vo[m], so[m], hv);
                     if (d.out2) bstore(ro2, vo[m], so[m], gv);
                 }
@@ -1381,8 +1379,7 @@ __global__ __launch_bounds__(256, (NTB == 1 ? 3 : 2)) void conv_lean2_kernel(con
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
                         f32x4 hv, gv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { float h_, g_; gelu_pair_f(acc[m][n][e] + bias_l, &h_, &g_); hv[e] = h_; gv[e] = g_; }
+                        gelu_pair4_f(acc[m][n] + bias_l, &hv, &gv);
                         bstore(ro, vo[m], so[m], hv);
                         if (d.out2) bstore(ro2, vo[m], so[m], gv);
                     }
@@ -1390,8 +1387,7 @@ __global__ __launch_bounds__(256, (NTB == 1 ? 3 : 2)) void conv_lean2_kernel(con
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
                         f32x4 sv, cv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(acc[m][n][e] + bias_l, &s_, &c_); sv[e] = s_; cv[e] = c_; }
+                        sincos4_f(acc[m][n] + bias_l, &sv, &cv);
                         bstore(ro, vo[m], so[m], sv);
                         if (d.out2) bstore(ro2, vo[m], so[m], cv);
                     }

@@ -387,8 +387,7 @@ __device__ __forceinline__ void conv_q4_body(const KArgs& ka, const SidePack& si
 #pragma unroll
                 for (int n = 0; n < Q4_NG; ++n) {
                     f32x4 sv, cv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(acc[n][e] + bias_l[n], &s_, &c_); sv[e] = s_; cv[e] = c_; }
+                    sincos4_f(acc[n] + bias_l[n], &sv, &cv);
                     bstore(ro, vo[n], so[n], sv);
                     bstore(ro2, d.out2 ? vo[n] : OOB, so[n], cv);            // always issued (dropped when there is no second output): the DMA wait counts it
                 }
@@ -396,8 +395,7 @@ __device__ __forceinline__ void conv_q4_body(const KArgs& ka, const SidePack& si
 #pragma unroll
                 for (int n = 0; n < Q4_NG; ++n) {
                     f32x4 hv, gv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { float h_, g_; gelu_pair_f(acc[n][e] + bias_l[n], &h_, &g_); hv[e] = h_; gv[e] = g_; }
+                    gelu_pair4_f(acc[n] + bias_l[n], &hv, &gv);
                     bstore(ro, vo[n], so[n], hv);
                     bstore(ro2, d.out2 ? vo[n] : OOB, so[n], gv);
                 }

@@ -455,8 +455,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf_kernel(const KArgs ka, const S
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     f32x4 sv, cv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(acc[m][e] + bias_l, &s_, &c_); sv[e] = s_; cv[e] = c_; }
+                    sincos4_f(acc[m] + bias_l, &sv, &cv);
                     bstore(ro, vo[m], so[m], sv);
                     if (d.out2) bstore(ro2, vo[m], so[m], cv);
                 }
@@ -464,8 +463,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf_kernel(const KArgs ka, const S
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     f32x4 hv, gv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { float h_, g_; gelu_pair_f(acc[m][e] + bias_l, &h_, &g_); hv[e] = h_; gv[e] = g_; }
+                    gelu_pair4_f(acc[m] + bias_l, &hv, &gv);
                     bstore(ro, vo[m], so[m], hv);
                     if (d.out2) bstore(ro2, vo[m], so[m], gv);
                 }
@@ -995,12 +993,12 @@ __device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __re
                         const int Hs = H * sps, Ws = W * sps;
                         const unsigned pvo = (okm[m] && co < Cout) ? (unsigned)((((cps * Hs + ips) * Ws) + jps + sps * 4 * kq) * 4) : OOB;
                         const unsigned pso = (unsigned)(((((it.b * (Cout / ss)) * Hs) + sps * (ty0 + 2 * wave + (m >> 1))) * Ws + sps * (tx0 + (m & 1) * 16)) * 4);
-                        const float q4[4] = {v.x + bias_l, v.y + bias_l, v.z + bias_l, v.w + bias_l};
+                        f32x4 q4s = v + bias_l, q4c = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (EP == BNERV_EP_BIAS_SIN) sincos4_f(v + bias_l, &q4s, &q4c);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const unsigned vo_e = pvo == OOB ? OOB : pvo + (unsigned)(e * sps * 4);
-                            float s_ = q4[e], c_ = 0.f;
-                            if constexpr (EP == BNERV_EP_BIAS_SIN) sincos_f(q4[e], &s_, &c_);
+                            const float s_ = q4s[e], c_ = q4c[e];
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s_), ro, (int)vo_e, (int)pso, 0);
                             if constexpr (EP == BNERV_EP_BIAS_SIN) { if (d.out2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c_), ro2, (int)vo_e, (int)pso, 0); }
                         }
@@ -1021,8 +1019,7 @@ __device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __re
                             bstore(ro, pvo, pso, pair_up(v + bias_l));
                         } else {
                             f32x4 sv, cv;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(v[e] + bias_l, &s_, &c_); sv[e] = s_; cv[e] = c_; }
+                            sincos4_f(v + bias_l, &sv, &cv);
                             bstore(ro, pvo, pso, pair_up(sv));
                             if (d.out2) bstore(ro2, pvo, pso, pair_up(cv));
                         }
@@ -1030,14 +1027,12 @@ __device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __re
                         bstore(ro, vo, so[m], v + bias_l);
                     } else if constexpr (EP == BNERV_EP_BIAS_SIN) {
                         f32x4 sv, cv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { float s_, c_; sincos_f(v[e] + bias_l, &s_, &c_); sv[e] = s_; cv[e] = c_; }
+                        sincos4_f(v + bias_l, &sv, &cv);
                         bstore(ro, vo, so[m], sv);
                         if (d.out2) bstore(ro2, vo, so[m], cv);
                     } else if constexpr (EP == BNERV_EP_BIAS_GELU) {
                         f32x4 hv, gv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { float h_, g_; gelu_pair_f(v[e] + bias_l, &h_, &g_); hv[e] = h_; gv[e] = g_; }
+                        gelu_pair4_f(v + bias_l, &hv, &gv);
                         bstore(ro, vo, so[m], hv);
                         if (d.out2) bstore(ro2, vo, so[m], gv);
                     } else if constexpr (EP == BNERV_EP_BIAS_TANH) {

@@ -29,6 +29,13 @@ __device__ __forceinline__ float s_ep(float v, float bias, float* o2) {
     if constexpr (EP == BNERV_EP_BIAS_GELU) { float h; gelu_pair_f(v + bias, &h, o2); return h; }
     return v;
 }
+template <int EP>
+__device__ __forceinline__ f32x4 s_ep4(f32x4 v, float bias, f32x4* o2) {          // four elements at once: the packed forms of common.h
+    if constexpr (EP == BNERV_EP_BIAS) return v + bias;
+    if constexpr (EP == BNERV_EP_BIAS_SIN) { f32x4 sv; sincos4_f(v + bias, &sv, o2); return sv; }
+    if constexpr (EP == BNERV_EP_BIAS_GELU) { f32x4 h; gelu_pair4_f(v + bias, &h, o2); return h; }
+    return v;
+}
 
 // NQ = ceil(Cin / 4) rounded to 4 or 8 (16 or 32 staged channels)
 template <int IN, int EP, int NQ>
@@ -200,8 +207,8 @@ __device__ __forceinline__ void conv_small_body(const SArgs& sa, const int tile,
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[e] = acc[e] + bias + a0[e];
             } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { float c2 = 0.f; r[e] = s_ep<EP>(acc[e], bias, &c2); r2[e] = c2; }
+                r2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                r = s_ep4<EP>(acc, bias, &r2);
             }
             *reinterpret_cast<f32x4*>(d.out + o) = r;
             if constexpr (EP == BNERV_EP_BIAS_SIN || EP == BNERV_EP_BIAS_GELU) { if (d.out2) *reinterpret_cast<f32x4*>(d.out2 + o) = r2; }
@@ -209,9 +216,8 @@ __device__ __forceinline__ void conv_small_body(const SArgs& sa, const int tile,
     } else if (d.out_s == 2 && (Cout & 3) == 0) {
         // PixelShuffle(2): lanes li = 4 c + 2 i + j.  Lanes j = 0 / 1 (neighbours) hold the even / odd output columns of the same row:
         // they swap halves so that each stores 4 CONSECUTIVE output pixels -- lane j = 0 the columns 2 gx .. 2 gx + 3, lane j = 1 the next four.
-        float c2v[4], rv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { c2v[e] = 0.f; rv[e] = s_ep<EP>(acc[e], bias, &c2v[e]); }
+        f32x4 c2v = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 rv = s_ep4<EP>(acc, bias, &c2v);
         const int j = li & 1;
         f32x4 o1, o2;
         {
@@ -234,14 +240,14 @@ __device__ __forceinline__ void conv_small_body(const SArgs& sa, const int tile,
             const int s = d.out_s, s2 = s * s, c = co / s2, rem = co - c * s2, i = rem / s, j = rem - i * s;
             const int Cf = Cout / s2, HF = H * s, WF = W * s;
             const size_t rowo = (((size_t)b * Cf + c) * HF + (size_t)(gy * s + i)) * (size_t)WF;
+            f32x4 c2 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 r = s_ep4<EP>(acc, bias, &c2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (gx + e < W) {
-                    float c2 = 0.f;
-                    const float r = s_ep<EP>(acc[e], bias, &c2);
                     const size_t oo = rowo + (size_t)((gx + e) * s + j);
-                    d.out[oo] = r;
-                    if constexpr (EP == BNERV_EP_BIAS_SIN) { if (d.out2) d.out2[oo] = c2; }
+                    d.out[oo] = r[e];
+                    if constexpr (EP == BNERV_EP_BIAS_SIN) { if (d.out2) d.out2[oo] = c2[e]; }
                 }
             }
         }
