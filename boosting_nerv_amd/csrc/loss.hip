@@ -224,11 +224,22 @@ __device__ __forceinline__ void ssim_fwd_body(const SsimArgs& a, const bool LAST
     const int oy0 = by * STH, ox0 = bx * STW;
     const float* X = a.X + (size_t)bc * a.H * a.W;
     const float* Y = a.Y + (size_t)bc * a.H * a.W;
-    for (int i = tid; i < WH * WW; i += 256) {
-        const int r = i / WW, c = i - r * WW;
-        const int y = oy0 + r, x = ox0 + c;
-        const bool in = y < a.H && x < a.W;
-        sXY[r][c] = pk2{in ? X[(size_t)y * a.W + x] : 0.f, in ? Y[(size_t)y * a.W + x] : 0.f};
+    {   // the whole window in flight (10 loads per thread), then the LDS stores: one memory round trip per block instead of five
+        constexpr int NLD = (WH * WW + 255) / 256;
+        pk2 ld[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + u * 256;
+            const int r = i / WW, c = i - r * WW;
+            const int y = oy0 + r, x = ox0 + c;
+            const bool in = i < WH * WW && y < a.H && x < a.W;
+            ld[u] = pk2{in ? X[(size_t)y * a.W + x] : 0.f, in ? Y[(size_t)y * a.W + x] : 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + u * 256;
+            if (i < WH * WW) (&sXY[0][0])[i] = ld[u];
+        }
     }
     __syncthreads();
     // vertical (along H) first, as the reference filters dim 2 then dim 3
@@ -267,10 +278,13 @@ __device__ __forceinline__ void ssim_fwd_body(const SsimArgs& a, const bool LAST
             if (LAST) { lum = (2.f * m12 + a.C1) / (m11 + m22 + a.C1); acc += lum * cs; }
             else acc += cs;
             if (a.G) {
-                float dm = (2.f / B2) * (m1 * cs - m2), dxx = -cs / B2, dxy = 2.f / B2;
+                // the statistic gradients take 1 / B2 (and 1 / B1) through v_rcp_f32 (1 ulp) -- three IEEE divisions were a quarter of this
+                // pass's instructions; the VALUE path (cs, lum) keeps the exact quotient
+                const float dxy0 = 2.f * __builtin_amdgcn_rcpf(B2);
+                float dm = dxy0 * (m1 * cs - m2), dxx = -0.5f * cs * dxy0, dxy = dxy0;
                 if (LAST) {
                     const float B1 = m11 + m22 + a.C1;
-                    dm = (2.f / B1) * (m2 - m1 * lum) * cs + lum * dm;
+                    dm = (2.f * __builtin_amdgcn_rcpf(B1)) * (m2 - m1 * lum) * cs + lum * dm;
                     dxx *= lum; dxy *= lum;
                 }
                 const size_t plane = (size_t)a.H * a.W, o = (size_t)bc * plane + (size_t)(oy0 + r) * a.W + (ox0 + c);
@@ -290,12 +304,15 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const SsimArgs a) { ssim_
 // every level's statistics in ONE launch (the levels only depend on the pyramid): block -> (level, tile) through the running tile counts
 struct SsimAllArgs { SsimArgs lv[LV]; int first[LV + 1]; };
 __global__ __launch_bounds__(256) void ssim_fwd_all_kernel(const SsimAllArgs a) {
+    // neighbouring tiles share 10 of their 26 x 42 window rows / columns: each XCD (linear block ids b, b + 8, ...) takes a contiguous run of tiles
+    const int lb = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int gbx = lb % (int)gridDim.x, gby = lb / (int)gridDim.x;
     int l = 0;
 #pragma unroll
-    for (int k = 1; k < LV; ++k) if ((int)blockIdx.x >= a.first[k]) l = k;
-    const int t = (int)blockIdx.x - a.first[l];
+    for (int k = 1; k < LV; ++k) if (gbx >= a.first[k]) l = k;
+    const int t = gbx - a.first[l];
     const int bx = t % a.lv[l].tiles_x, by = t / a.lv[l].tiles_x;
-    ssim_fwd_body(a.lv[l], l == LV - 1, bx, by, blockIdx.y, gridDim.y);      // (one body: its LDS arrays exist once)
+    ssim_fwd_body(a.lv[l], l == LV - 1, bx, by, gby, gridDim.y);      // (one body: its LDS arrays exist once)
 }
 
 // ---- ms_ssim per (b,c) and the chain coefficients; one block (5 waves) per (b,c) ----
@@ -356,15 +373,25 @@ __device__ __forceinline__ void ssim_bwd_body(const SsimArgs& a, const CoarseCha
     const int Hv = a.H - HW_, Wv = a.W - HW_;
     const size_t plane = (size_t)a.H * a.W, mstride = (size_t)nbc * plane;
     const float* Gp = a.G + (size_t)bc * plane;
-    for (int i = tid; i < GH * GW; i += 256) {
-        const int r = i / GW, c = i - r * GW;
-        const int oy = wy0 + r, ox = wx0 + c;
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-        if (oy >= 0 && oy < Hv && ox >= 0 && ox < Wv) {
-            const size_t o = (size_t)oy * a.W + ox;
-            g0 = Gp[o]; g1 = Gp[mstride + o]; g2 = Gp[2 * mstride + o];
+    {   // the whole 26 x 42 region of the three maps in flight (15 loads per thread), then the LDS stores
+        constexpr int NLD = (GH * GW + 255) / 256;
+        float l0[NLD], l1[NLD], l2[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + u * 256;
+            const int r = i / GW, c = i - r * GW;
+            const int oy = wy0 + r, ox = wx0 + c;
+            l0[u] = 0.f; l1[u] = 0.f; l2[u] = 0.f;
+            if (i < GH * GW && oy >= 0 && oy < Hv && ox >= 0 && ox < Wv) {
+                const size_t o = (size_t)oy * a.W + ox;
+                l0[u] = Gp[o]; l1[u] = Gp[mstride + o]; l2[u] = Gp[2 * mstride + o];
+            }
         }
-        sG01[r][c] = pk2{g0, g1}; sG2[r][c] = g2;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + u * 256;
+            if (i < GH * GW) { (&sG01[0][0])[i] = pk2{l0[u], l1[u]}; (&sG2[0][0])[i] = l2[u]; }
+        }
     }
     __syncthreads();
     for (int i = tid; i < STH * GW; i += 256) {
@@ -966,8 +993,7 @@ __global__ __launch_bounds__(256) void loss_mid_kernel(const LossMidArgs a) {
 }
 struct LossTailArgs { SsimArgs s; CoarseChain cc; FinalArgs fin; int gx, gy, n0, BC; };
 __global__ __launch_bounds__(256) void loss_tail_kernel(const LossTailArgs a) {
-    const int b = blockIdx.x;
-    if (b < a.n0) { const int bx = b % a.gx, r = b / a.gx; ssim_bwd_body<true>(a.s, &a.cc, bx, r % a.gy, r / a.gy, a.BC); }
+    if ((int)blockIdx.x < a.n0) { const int b = xcd_remap((int)blockIdx.x, a.n0); const int bx = b % a.gx, r = b / a.gx; ssim_bwd_body<true>(a.s, &a.cc, bx, r % a.gy, r / a.gy, a.BC); }
     else if (threadIdx.x < 64) loss_final_body(a.fin);
 }
 __global__ void msssim_final_kernel(const float* __restrict__ msval, float* __restrict__ out, int B, int C) {
