@@ -298,8 +298,17 @@ __device__ __forceinline__ void ssim_fwd_body(const SsimArgs& a, const bool LAST
     __syncthreads();
     if (tid == 0) a.partial[(size_t)bc * (a.tiles_x * a.tiles_y) + by * a.tiles_x + bx] = red[0] + red[1] + red[2] + red[3];
 }
+// XCD-contiguous tile order of a (tiles_x, tiles_y, planes) grid: the dispatcher deals linear block ids round-robin over the 8 XCDs;
+// with this remap each XCD works on a contiguous run of tiles, whose shared window rows / columns it finds in its own L2
+struct Tile3 { int x, y, z; };
+__device__ __forceinline__ Tile3 xcd_tile3() {
+    const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+    const int lb = xcd_remap((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), (int)(gridDim.x * gridDim.y * gridDim.z));
+    const int z = lb / (gx * gy), r = lb - z * (gx * gy);
+    return Tile3{r % gx, r / gx, z};
+}
 template <bool LAST>
-__global__ __launch_bounds__(256) void ssim_fwd_kernel(const SsimArgs a) { ssim_fwd_body(a, LAST, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z); }
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(const SsimArgs a) { const Tile3 t = xcd_tile3(); ssim_fwd_body(a, LAST, t.x, t.y, t.z, gridDim.z); }
 
 // every level's statistics in ONE launch (the levels only depend on the pyramid): block -> (level, tile) through the running tile counts
 struct SsimAllArgs { SsimArgs lv[LV]; int first[LV + 1]; };
@@ -445,16 +454,18 @@ __device__ __forceinline__ void ssim_bwd_body(const SsimArgs& a, const CoarseCha
     }
 }
 template <bool LEVEL0>
-__global__ __launch_bounds__(256) void ssim_bwd_from_g_kernel(const SsimArgs a) { ssim_bwd_body<LEVEL0>(a, nullptr, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z); }
-__global__ __launch_bounds__(256) void ssim_bwd_level0_chain_kernel(const SsimArgs a, const CoarseChain cc) { ssim_bwd_body<true>(a, &cc, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z); }
+__global__ __launch_bounds__(256) void ssim_bwd_from_g_kernel(const SsimArgs a) { const Tile3 t = xcd_tile3(); ssim_bwd_body<LEVEL0>(a, nullptr, t.x, t.y, t.z, gridDim.z); }
+__global__ __launch_bounds__(256) void ssim_bwd_level0_chain_kernel(const SsimArgs a, const CoarseChain cc) { const Tile3 t = xcd_tile3(); ssim_bwd_body<true>(a, &cc, t.x, t.y, t.z, gridDim.z); }
 // levels 1 .. LV-1 in one launch, each writing only its OWN term (no coarser contribution: the level-0 launch combines them)
 __global__ __launch_bounds__(256) void ssim_bwd_coarse_all_kernel(const SsimAllArgs a) {
+    const int lb = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int gbx = lb % (int)gridDim.x, gby = lb / (int)gridDim.x;
     int l = 1;
 #pragma unroll
-    for (int k = 2; k < LV; ++k) if ((int)blockIdx.x >= a.first[k]) l = k;
-    const int t = (int)blockIdx.x - a.first[l];
+    for (int k = 2; k < LV; ++k) if (gbx >= a.first[k]) l = k;
+    const int t = gbx - a.first[l];
     const int tx = cdiv_d(a.lv[l].W, STW);
-    ssim_bwd_body<false>(a.lv[l], nullptr, t % tx, t / tx, blockIdx.y, gridDim.y);
+    ssim_bwd_body<false>(a.lv[l], nullptr, t % tx, t / tx, gby, gridDim.y);
 }
 
 // =====================================================================================================================
@@ -835,7 +846,10 @@ __device__ __forceinline__ void fft_cols_body(const FftArgs& a, const int bx, co
         T[(size_t)y * W + v0 + c] = buf[c * H + y];
     }
 }
-__global__ __launch_bounds__(256) void fft_cols_kernel(const FftArgs a) { fft_cols_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
+__global__ __launch_bounds__(256) void fft_cols_kernel(const FftArgs a) {      // (XCD-contiguous panels: see loss_mid_kernel)
+    const int lb = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    fft_cols_body(a, lb % (int)gridDim.x, lb / (int)gridDim.x, gridDim.x);
+}
 
 __global__ __launch_bounds__(256) void fft_rows_adj_kernel(const FftArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
