@@ -67,8 +67,12 @@ __device__ __forceinline__ void conv_q4_body(const KArgs& ka, const SidePack& si
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;                                    // [2][S_IN] input tiles, filled by LDS-DMA
     float* s_w = smem + 2 * S_IN;                          // [ci][quad][4] compact weight quads
-    float* s_red = s_w + S_W;                              // [4 waves][2][16] per-channel partial sums (DGELU_SAVED / DSIN)
-    float* s_aff = s_red + 128;                            // [2][16] affine prologue parameters of the current sample
+    float* s_red = s_w + S_W;                              // [2 sets][4 waves][2][16] per-channel partial sums (DGELU_SAVED / DSIN).  Two sets, by tile parity:
+                                                           // wave 0 reads tile i's sums at the TOP of tile i + 1 while the other waves write tile i + 1's at its
+                                                           // end with no barrier in between -- with one set a starved wave 0 could read sums of the wrong tile
+                                                           // (seen as a last-bit difference of a TAT gradient once in ~10..100 steps); a set is rewritten only two
+                                                           // tiles later, behind the barrier that closes the tile in which it was read
+    float* s_aff = s_red + 256;                            // [2][16] affine prologue parameters of the current sample
     float* s_beta = s_aff + 32;                            // [9 taps][16] sum_ci shift[ci] * W(co, ci, tap)  (affine prologue, folded)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -165,10 +169,11 @@ __device__ __forceinline__ void conv_q4_body(const KArgs& ka, const SidePack& si
             for (int k = 0; k < NPRE; ++k) dma16(rx, slot_inside(k, ty0, tx0) ? voff[k] : OOB, sb, lbase + (unsigned)k * 4096u);
         }
     };
-    auto flush_partials = [&](const LItem& a) {            // wave 0: sum the 4 waves' channel sums of tile `a`, fixed order
+    auto flush_partials = [&](const LItem& a, const int set) {            // wave 0: sum the 4 waves' channel sums of tile `a`, fixed order
         if (wave == 0 && lane < 32) {
             const int q = lane >> 4, c = lane & 15;
-            const float s = ((s_red[(0 * 2 + q) * 16 + c] + s_red[(1 * 2 + q) * 16 + c]) + s_red[(2 * 2 + q) * 16 + c]) + s_red[(3 * 2 + q) * 16 + c];
+            const float* sr = s_red + set * 128;
+            const float s = ((sr[(0 * 2 + q) * 16 + c] + sr[(1 * 2 + q) * 16 + c]) + sr[(2 * 2 + q) * 16 + c]) + sr[(3 * 2 + q) * 16 + c];
             const size_t row = (size_t)(a.ty * tiles_x + a.tx) * d.B + a.b;            // [tiles][B][2][Cout]
             if (c < Cout) d.partial[(row * 2 + q) * Cout + c] = s;
         }
@@ -263,8 +268,9 @@ __device__ __forceinline__ void conv_q4_body(const KArgs& ka, const SidePack& si
     int buf = 0;
     LItem prev = it;
     bool have_prev = false;
+    int red_set = 0;                                       // s_red set this tile's epilogue writes (the previous tile wrote red_set ^ 1)
     int trace_iter = 0; (void)trace_iter;
-    for (; itx < r1; itx += nlb, ++trace_iter) {
+    for (; itx < r1; itx += nlb, ++trace_iter, red_set ^= 1) {
         TRACE(0);
         f32x4 acc[Q4_NG];
 #pragma unroll
@@ -275,7 +281,7 @@ __device__ __forceinline__ void conv_q4_body(const KArgs& ka, const SidePack& si
         TRACE(1);
         if (has_next) issue(nxt, buf ^ 1);                 // lands under the matrix phase; the other buffer was last read before the barrier below
         TRACE(2);
-        if constexpr (RED) { if (have_prev) flush_partials(prev); }
+        if constexpr (RED) { if (have_prev) flush_partials(prev, red_set ^ 1); }
         // the epilogue's auxiliary tensors (residual / saved activations) are fetched NOW, into registers: they land under the matrix
         // phase instead of costing one exposed memory latency per tensor in the epilogue
         constexpr int NAUX = (EP == BNERV_EP_BIAS_RES) ? 1 : (EP == BNERV_EP_DGELU_SAVED) ? 2 : (EP == BNERV_EP_DSIN) ? 3 : 0;
@@ -429,7 +435,7 @@ __device__ __forceinline__ void conv_q4_body(const KArgs& ka, const SidePack& si
                 }
                 if (lane < 4) {
 #pragma unroll
-                    for (int n = 0; n < Q4_NG; ++n) { s_red[(wave * 2 + 0) * 16 + 4 * n + lane] = ps[n]; s_red[(wave * 2 + 1) * 16 + 4 * n + lane] = pt[n]; }
+                    for (int n = 0; n < Q4_NG; ++n) { s_red[red_set * 128 + (wave * 2 + 0) * 16 + 4 * n + lane] = ps[n]; s_red[red_set * 128 + (wave * 2 + 1) * 16 + 4 * n + lane] = pt[n]; }
                 }
             }
         }
@@ -458,7 +464,7 @@ __device__ __forceinline__ void conv_q4_body(const KArgs& ka, const SidePack& si
     }
     if constexpr (RED) {
         lds_barrier();
-        flush_partials(prev);
+        flush_partials(prev, red_set ^ 1);                 // (the loop's increment flipped the set once more after the last tile)
     }
     side_run_hosted(side, smem, vb, vgrid);                // queued slab reductions, least-loaded blocks first (sidejob.h)
 }
@@ -469,7 +475,7 @@ inline size_t q4_lds_bytes() {
     using G = Geo<3>;
     constexpr int NSLOT = Q4_NCH * G::ROWS * G::SEGS;
     constexpr int NPRE = (NSLOT + 255) / 256;
-    return ((size_t)2 * NPRE * 256 * 4 + (size_t)Q4_NCH * Q4_QPAD * 4 + 128 + 32 + 9 * 16) * sizeof(float);
+    return ((size_t)2 * NPRE * 256 * 4 + (size_t)Q4_NCH * Q4_QPAD * 4 + 256 + 32 + 9 * 16) * sizeof(float);
 }
 // shapes this family takes (the mode is checked by the launcher)
 inline bool q4_shape_ok(const KArgs& ka) {

@@ -79,6 +79,6 @@ for k in range(NO):
     spreads.append(max(st) - min(st))
     pair_diffs += [abs(a - b) for i, a in enumerate(st) for b in st[i + 1:]]
     print(f"| {seed} | {h1:.4f} | {h2:.4f} | " + ", ".join(f"{v:.4f}" for v in st) + f" | {spreads[-1]:.4f} | {gaps[-1]:+.4f} |", flush=True)
-print(f"\nHIP runs of one order are bit-identical: reported above.  |HIP - mean(stock)|: " + ", ".join(f"{abs(g):.4f}" for g in gaps) +
+print(f"\nHIP runs of one order: both reported above (the path is bitwise reproducible: equal digits).  |HIP - mean(stock)|: " + ", ".join(f"{abs(g):.4f}" for g in gaps) +
       f" dB (mean {statistics.mean(abs(g) for g in gaps):.4f});  stock vs stock on identical inputs, all pairs: mean {statistics.mean(pair_diffs):.4f}, max {max(pair_diffs):.4f} dB.")
 print(f"wall {time.time() - t0:.0f} s")
