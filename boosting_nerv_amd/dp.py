@@ -109,7 +109,13 @@ class GradBucket:
         next to the rest of the backward.  finish() must follow the backward."""
         if not self.two or (self.world == 1 and not self.force) or self._early_inflight:
             return
-        self._ensure_grads("early")
+        lo, hi = self._range("early")
+        missing = sum(1 for p in self.params[lo:hi] if p.grad is None)
+        if missing:
+            # a zero-filled segment would be all-reduced now and scattered OVER the real gradients by finish(): refuse (the caller's
+            # backward produces these gradients after the hook -- one bucket is the valid form for it)
+            raise RuntimeError(f"GradBucket.exchange_early: {missing} early parameter(s) have no gradient yet at the hook; "
+                               "this backward cannot use two bucket segments")
         self._gather("early")
         seg = self.bucket[:self.split]
         if self._side is not None:

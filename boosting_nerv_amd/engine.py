@@ -38,8 +38,17 @@ class TrainStep:
         # dp_buckets == 2 (or BNERV_DP_BUCKETS=2): the bucket in two segments -- the decoder layers' gradients start their all-reduce on a
         # side stream from an autograd hook at the decoder / stem boundary, next to the rest of the backward (dp.GradBucket); needs a
         # model that names its late parameters and calls the hook (model_nerv.NeRV_Boost).  Default 1: see DESIGN section 5.
+        # Two segments are valid only where every early (decoder) gradient is COMPLETE when the stem-output hook fires: the plain
+        # step.  A subclass whose backward finishes parameter gradients later (CompressionStep: the convs consume de-quantised weights,
+        # the real weight / quantiser gradients appear in the CEM backward, after the hook) would gather zeros for them -- so the
+        # environment switch is honoured by TrainStep itself only, and exchange_early() refuses a segment with a missing gradient.
         import os as _os
-        nb = int(dp_buckets if dp_buckets is not None else _os.environ.get("BNERV_DP_BUCKETS", "1"))
+        if dp_buckets is None:
+            dp_buckets = int(_os.environ.get("BNERV_DP_BUCKETS", "1")) if type(self) is TrainStep else 1
+        nb = int(dp_buckets)
+        if nb == 2 and type(self) is not TrainStep:
+            raise ValueError(f"{type(self).__name__}: dp_buckets=2 needs a backward whose decoder gradients are final at the stem boundary "
+                             "(the plain TrainStep); use one bucket")
         late = model.dp_late_parameters() if (nb == 2 and hasattr(model, "dp_late_parameters")) else None
         self.bucket = GradBucket(model.parameters(), process_group, force=force_bucket, late_params=late) if (world_size > 1 or force_bucket) else None
         self._early_ok = True                                # False while a graph that cannot hold the collective is being captured
@@ -78,14 +87,30 @@ class TrainStep:
         # loss_fn(...).backward() + psnr_fn_single(...) of train_nerv_all.py:337-347 as ONE fused launch sequence: the loss
         # gradient seeds backward directly and the per-sample PSNR comes from the same L2 sums (stats[:, 4])
         loss, stats, grad = ops.loss_value_grad_stats(img_out, self.static_img, self.loss_type)
-        import os
-        if os.environ.get("BNERV_LAZY_FLUSH", "1") != "0" and getattr(self.model, "lazy_flush_ok", False):
+        if self._lazy_flush_valid():
             with ops.lazy_flush():              # the blocks' slab reductions are flushed by their first reader, not once per block
                 img_out.backward(grad)
         else:
             img_out.backward(grad)
         self.loss_out = loss
         self.psnr_out = stats[:, 4]
+
+    def _lazy_flush_valid(self):
+        """Lazy flushing (ops.lazy_flush) lets backward RETURN weight / bias gradients and TAT channel sums whose slab reductions are
+        still queued; only this package's operators (grouped dense, dense GEMM, stand-alone affine) flush before reading.  The invariant
+        that makes this safe -- checked here, every step, not only promised by the model's `lazy_flush_ok` flag -- is that NOTHING else
+        reads a gradient inside the backward: no parameter holds a .grad (AccumulateGrad would add into it: zero_grad(set_to_none=True)
+        above), no parameter carries a tensor hook, and no module carries backward hooks.  Anything else takes the per-block flush."""
+        import os
+        if os.environ.get("BNERV_LAZY_FLUSH", "1") == "0" or not getattr(self.model, "lazy_flush_ok", False):
+            return False
+        for p in self.params:
+            if p.grad is not None or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+                return False
+        for m in self.model.modules():
+            if m._backward_hooks or m._backward_pre_hooks:
+                return False
+        return True
 
     def _planned_fwd_bwd(self):
         """_fwd_bwd inside a capture: the weight fragments of every wide split conv call of the step come from ONE launch at the
@@ -175,10 +200,15 @@ class TrainStep:
             self._cap_ctx = L.new_ctx()
         else:
             L.reserve_ctx(self._cap_ctx)
-        with L.use_ctx(self._cap_ctx):
-            self._capture_in_ctx(pool)
-        if hasattr(self.opt, "finish_capture"):
-            self.opt.finish_capture()           # descriptor tables the captured optimizer launch points at (uploaded once, outside the graph)
+        if hasattr(self.opt, "begin_capture"):
+            self.opt.begin_capture()            # this capture's own descriptor tables (optimizer.Adan.launch_step, capture contract)
+        try:
+            with L.use_ctx(self._cap_ctx):
+                self._capture_in_ctx(pool)
+        finally:
+            if hasattr(self.opt, "finish_capture"):
+                # uploaded once, outside the graph; the tables live as long as this object's graphs
+                self._opt_tables = self.opt.finish_capture()
 
     def _capture_in_ctx(self, pool):
         import os
@@ -240,6 +270,9 @@ class TrainStep:
     def step_frame(self, i):
         """Train frame i of the clip given to bind_clip().  Same step as __call__(frames[i:i+1], norms[i:i+1])."""
         assert self._clip is not None, "step_frame: call bind_clip(frames, norms) first"
+        i = int(i)
+        if not 0 <= i < self._clip.shape[0]:    # (the fetch kernel clamps the index it reads from the schedule record: never hand it a bad one)
+            raise IndexError(f"step_frame: frame {i} outside the bound clip of {self._clip.shape[0]} frames")
         if not self._fetching:
             self._fetching = True
             self.graph_a = self.graph_b = None
@@ -284,6 +317,8 @@ class CompressionStep(TrainStep):
 
     def _fwd_bwd(self):
         a, m = self.cargs, self.model
+        if self._fetching:
+            self._fetch()                       # bind_clip() / step_frame(): the step starts with the frame fetch, as TrainStep's does
         self.opt.zero_grad(set_to_none=True)
         m.cal_params(self.entropy_model)
         inp = self.static_img if self.takes_image else self.static_idx

@@ -34,7 +34,7 @@ class Adan(Optimizer):
                         foreach=foreach, fused=fused)
         super().__init__(params, defaults)
         self._sched = {}          # group index -> (pinned host [5], device [5])
-        self._cap_tab = {}        # group index -> (pinned host, device) descriptor table of a captured launch, reserved outside the capture
+        self._cap_open = None     # begin_capture() .. finish_capture(): group index -> (pinned host, device) descriptor table of THIS capture
         self._chunk_cache = {}    # group index -> (key, device descriptor table, n, blocks, tensors the table points into, pending host table)
         self.state_epoch = 0      # bumped whenever state tensors are replaced: a captured step (engine.TrainStep) re-captures
 
@@ -49,7 +49,7 @@ class Adan(Optimizer):
         for group in self.param_groups:
             group.setdefault("no_prox", False)
         self.__dict__.setdefault("_sched", {})
-        self.__dict__.setdefault("_cap_tab", {})
+        self.__dict__["_cap_open"] = None
         self._invalidate()
 
     def load_state_dict(self, state_dict):
@@ -102,10 +102,6 @@ class Adan(Optimizer):
                 # long before 512 graph launches are outstanding; the guard makes that an invariant instead of an observation)
                 self._sched[gi] = (torch.zeros(self._RING, 8, dtype=torch.float32).pin_memory(), torch.zeros(8, dtype=torch.float32, device=dev),
                                    [None] * self._RING)
-            if gi not in self._cap_tab:
-                # room for the descriptor table of a CAPTURED optimizer launch (launch_step inside a hipGraph capture may not allocate)
-                nb = len(group["params"]) * C.sizeof(L.AdanEntry)
-                self._cap_tab[gi] = (torch.empty(nb, dtype=torch.uint8).pin_memory(), torch.empty(nb, dtype=torch.uint8, device=dev))
             ring, devbuf, events = self._sched[gi]
             slot = group["step"] % self._RING
             if events[slot] is not None:
@@ -134,7 +130,12 @@ class Adan(Optimizer):
     @torch.no_grad()
     def launch_step(self, clip=1.0):
         """Device side of a step: ONE fused launch over a device-resident descriptor table (any number of tensors).  No sync; the
-        only host<->device traffic is the table upload when a tensor address changed (never in a replayed step)."""
+        only host<->device traffic is the table upload when a tensor address changed (never in a replayed step).
+
+        Capture contract: a captured launch records only the ADDRESS of its descriptor table; the content is uploaded by
+        finish_capture().  Inside a stream capture this method therefore raises unless a begin_capture() .. finish_capture() bracket
+        is open (engine.TrainStep._capture opens one); every bracket gets a table of its own, which the caller keeps alive with its
+        graph (finish_capture() returns it), so a second capture never rewrites the table an earlier graph still replays with."""
         lib = L.load()
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
@@ -147,7 +148,12 @@ class Adan(Optimizer):
                          st["exp_avg_diff"].data_ptr(), st["neg_pre_grad"].data_ptr()) for p, st in zip(ps, sts))
             capturing = torch.cuda.is_current_stream_capturing()
             ck = (gi, capturing)        # a captured launch owns its table: an eager step in between must not rewrite the addresses it replays with
+            if capturing and self._cap_open is None:
+                raise L.BnervError("Adan.launch_step() inside a stream capture needs an open begin_capture() .. finish_capture() bracket "
+                                   "(the captured launch reads a descriptor table that finish_capture() uploads)")
             cached = self._chunk_cache.get(ck)
+            if capturing and cached is not None and cached[1] is not self._cap_open[gi][1]:
+                cached = None               # a table of an earlier capture: that graph keeps it; this capture writes its own
             if cached is None or cached[0] != key:
                 # (not p.grad: it is alive whenever the step launches, and pinning it would move the next eager gradient elsewhere)
                 keep = [(p, st["exp_avg"], st["exp_avg_sq"], st["exp_avg_diff"], st["neg_pre_grad"]) for p, st in zip(ps, sts)]
@@ -164,10 +170,10 @@ class Adan(Optimizer):
                     blocks += lib.bnerv_adan_table_blocks(p.numel())
                 raw = bytes(tab)
                 if capturing:
-                    # nothing may allocate pinned or device memory inside a capture: prepare_step() (always called before it) set both aside
-                    host, dev_tab = self._cap_tab[gi]
+                    # nothing may allocate pinned or device memory inside a capture: begin_capture() set both aside
+                    host, dev_tab = self._cap_open[gi]
                     if host.numel() < len(raw):
-                        raise L.BnervError("fused Adan: the capture-time descriptor table is larger than the one prepare_step() reserved")
+                        raise L.BnervError("fused Adan: the capture-time descriptor table is larger than the one begin_capture() reserved")
                     C.memmove(host.data_ptr(), raw, len(raw))
                 else:
                     host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
@@ -183,14 +189,28 @@ class Adan(Optimizer):
                                 self._sched[gi][1].data_ptr())
             L.check(lib.bnerv_adan_table(L.stream(), cached[1].data_ptr(), cached[2], cached[3], C.byref(hyper)), "bnerv_adan_table")
 
+    def begin_capture(self):
+        """Before a hipGraph capture that will contain launch_step(): reserve THIS capture's descriptor tables (pinned host + device,
+        one pair per parameter group, sized for every parameter) -- nothing may allocate inside the capture."""
+        tabs = {}
+        for gi, group in enumerate(self.param_groups):
+            nb = max(len(group["params"]), 1) * C.sizeof(L.AdanEntry)
+            dev = group["params"][0].device
+            host = torch.empty(nb, dtype=torch.uint8)
+            tabs[gi] = (host.pin_memory() if dev.type == "cuda" else host, torch.empty(nb, dtype=torch.uint8, device=dev))
+        self._cap_open = tabs
+
     def finish_capture(self):
         """After a hipGraph capture that contained launch_step(): upload the descriptor tables that capture referenced (the captured
-        launch holds the table's ADDRESS; its content is written here, once, outside the graph)."""
+        launch holds the table's ADDRESS; its content is written here, once, outside the graph) and close the bracket.  Returns the
+        device tables: the owner of the graph keeps them alive as long as the graph."""
         for cached in self._chunk_cache.values():
             if cached[5] is not None:
                 cached[1].copy_(cached[5], non_blocking=True)
-                torch.cuda.current_stream().synchronize()          # the pinned buffer is rewritten by the next capture
+                torch.cuda.current_stream().synchronize()          # the pinned buffer dies with the bracket
                 cached[5] = None
+        tabs, self._cap_open = self._cap_open, None
+        return [] if tabs is None else [t[1] for t in tabs.values()]
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -162,7 +162,7 @@ def train(local_rank, args):
         values, hw = evaluate(model, full_loader, local_rank, args, args.dump_vis, coding=True, entropy_model=entropy_model)
         top = rt.BestTracker(args.metric_names).update(values)
         text = f'PSNR for output {hw} for quant {args.quant_str}: ' + ''.join(
-            f'best_{n}: {rt.fmt(v, 2 if "psnr" in n else 4)} | ' for n, v in zip(args.metric_names, top))
+            f'best_{n}: {rt.fmt(v, 4)} | ' for n, v in zip(args.metric_names, top))      # 4 decimals for every metric (train_nerv_compression.py:317)
         if is_main:
             print(text, flush=True)
             # the files the reference's --eval_only writes under --outf (train_nerv_compression.py:311-325): eval.txt and eval.csv

@@ -436,3 +436,92 @@ def test_inpainting_transform_and_masked_step_match_reference_golden(mode):
     gold = float(npz[f"{k}/loss_L1_freq"])
     assert abs(loss.item() - gold) < 1e-4 * abs(gold), (loss.item(), gold)
     torch.testing.assert_close(cpu_ref.psnr_fn_single(img, gt), torch.from_numpy(npz[f"{k}/psnr"]), rtol=1e-5, atol=1e-4)
+
+
+def test_two_bucket_segments_are_refused_where_the_backward_finishes_gradients_late(monkeypatch):
+    """BNERV_DP_BUCKETS=2 must not reach CompressionStep (its decoder gradients appear in the CEM backward, AFTER the
+    stem-output hook: the early segment would all-reduce zeros and finish() would scatter them over the real gradients), and
+    exchange_early() must refuse a segment with a missing gradient instead of zero-filling it."""
+    import torch.nn as nn
+    from boosting_nerv_amd import engine
+    from boosting_nerv_amd.dp import GradBucket
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    from boosting_nerv_amd.optimizer import Adan
+    monkeypatch.setenv("BNERV_DP_BUCKETS", "2")
+    torch.manual_seed(1)
+    args = configs.tiny_nerv()
+    model = NeRV_Boost(1, args=args)
+    opt = Adan(model.parameters(), lr=1e-3)
+    dev = torch.device("cpu")
+    plain = engine.TrainStep(model, opt, "L1", False, (1, 3, 180, 320), dev, use_graph=False, force_bucket=True)
+    assert plain.bucket.two and model.dp_hook is not None           # the plain step honours the switch ...
+    model.dp_hook = None
+
+    class _Args:
+        loss, model, embed, clip_max_norm = "L1", "NeRV_Boost", "pe_1.25_80", 0.0
+    comp = engine.CompressionStep(model, opt, None, _Args(), (1, 3, 180, 320), dev, use_graph=False, force_bucket=True)
+    assert not comp.bucket.two and model.dp_hook is None            # ... the rate-distortion step does not
+    with pytest.raises(ValueError):
+        class _Sub(engine.TrainStep):
+            pass
+        _Sub(model, opt, "L1", False, (1, 3, 180, 320), dev, use_graph=False, force_bucket=True, dp_buckets=2)
+
+    # exchange_early() with an early gradient that does not exist yet: refused, nothing gathered
+    stem, dec = nn.Linear(4, 4), nn.Linear(4, 2)
+    b = GradBucket(list(stem.parameters()) + list(dec.parameters()), late_params=list(stem.parameters()), force=True)
+    assert b.two
+    with pytest.raises(RuntimeError, match="no gradient yet"):
+        b.exchange_early()
+    assert not b._early_inflight and all(p.grad is None for p in dec.parameters())
+
+
+def test_step_frame_rejects_indices_outside_the_bound_clip():
+    """the fetch kernel clamps the index it reads; the host refuses a bad one before anything is launched."""
+    from boosting_nerv_amd import engine
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    from boosting_nerv_amd.optimizer import Adan
+    torch.manual_seed(1)
+    model = NeRV_Boost(1, args=configs.tiny_nerv())
+    step = engine.TrainStep(model, Adan(model.parameters(), lr=1e-3), "L1", False, (1, 3, 180, 320), torch.device("cpu"), use_graph=False)
+    step.bind_clip(torch.zeros(4, 3, 180, 320), torch.arange(1, 5, dtype=torch.float64) / 4)
+    for bad in (-1, 4, 100):
+        with pytest.raises(IndexError):
+            step.step_frame(bad)
+
+
+def test_lazy_flush_is_taken_only_when_nothing_else_reads_gradients_in_backward():
+    """engine.TrainStep checks the lazy-flush invariant itself (no .grad to accumulate into, no tensor / module hooks)."""
+    from boosting_nerv_amd import engine
+    from boosting_nerv_amd.model_nerv import NeRV_Boost
+    from boosting_nerv_amd.optimizer import Adan
+    torch.manual_seed(1)
+    model = NeRV_Boost(1, args=configs.tiny_nerv())
+    step = engine.TrainStep(model, Adan(model.parameters(), lr=1e-3), "L1", False, (1, 3, 180, 320), torch.device("cpu"), use_graph=False)
+    assert step._lazy_flush_valid()
+    p = next(model.parameters())
+    p.grad = torch.zeros_like(p)                                     # zero_grad(set_to_none=False) style: AccumulateGrad would read + add
+    assert not step._lazy_flush_valid()
+    p.grad = None
+    h = p.register_hook(lambda g: g)
+    assert not step._lazy_flush_valid()
+    h.remove()
+    assert step._lazy_flush_valid()
+    h = model.head_layer.register_full_backward_hook(lambda m, gi, go: None)
+    assert not step._lazy_flush_valid()
+    h.remove()
+    assert step._lazy_flush_valid()
+
+
+def test_adan_captured_launch_needs_the_capture_bracket():
+    """a captured Adan launch reads a table finish_capture() uploads; every bracket owns its tables."""
+    from boosting_nerv_amd.optimizer import Adan
+    w = torch.nn.Parameter(torch.zeros(8))
+    opt = Adan([w], lr=1e-3)
+    assert opt._cap_open is None
+    opt.begin_capture()
+    t1 = opt._cap_open[0][1]
+    tabs = opt.finish_capture()
+    assert opt._cap_open is None and len(tabs) == 1 and tabs[0] is t1
+    opt.begin_capture()
+    assert opt._cap_open[0][1] is not t1                           # a second capture never shares the first one's table
+    opt.finish_capture()
