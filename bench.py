@@ -152,7 +152,7 @@ def step_kernel_roofline(dev, Cc, H, W, reps=20):
     kw = dict(B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3)
     plane = Cc * H * W * 4.0
     wb = Cc * Cc * 9 * 4.0
-    cases = [   # name, launches per step, tensors moved (in planes), launcher
+    cases = [   # name (its first word is the row key the PMC traffic profiles are matched by), launches per step, tensors moved (in planes), launcher
         ("K2s conv0 fwd: affine->conv->bias->gelu,gelu'", 2, 3, lambda: ops._conv(x, w, b, out, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=sc, shift=sh, out2=out2, **kw)),
         ("K3s conv1 fwd: affine->conv->bias->+res", 2, 3, lambda: ops._conv(h, w, b, out, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_RES, scale=sc, shift=sh, aux0=y0, **kw)),
         ("K1 block conv fwd: conv->bias->sin,cos", 1, 3, lambda: ops._conv(x, w, b, out, in_mode=L.IN_PLAIN, ep_mode=L.EP_BIAS_SIN, out2=out2, **kw)),
@@ -169,15 +169,17 @@ def step_kernel_roofline(dev, Cc, H, W, reps=20):
     flops1 = 2.0 * Cc * Cc * 9 * H * W
     rows, tf, tt, nl = [], 0.0, 0.0, 0
     troof = 0.0
+    keys = {"K2s": "k2s", "K3s": "k3s", "K1": "k1", "wA|dK3s": "pair_dk3s", "wA|dK2s": "pair_dk2s", "wP|dK1": "pair_dk1", "TAT": "tat_fwd"}
     for name, n, planes, fn in cases:
         t = _time_launches(fn, reps)       # (slab reductions are deferred exactly as in the step: they ride on the following launch)
         ops._flush_deferred()
-        flops = flops1 * (2 if "pair" in name else 1)      # a pair is two convolutions
+        nconv = 2 if ("pair" in name or name.startswith("TAT")) else 1      # a pair / a fused block is two convolutions
+        flops = flops1 * nconv
         ach = flops / t / 1e12
-        nbytes = planes * plane + wb
+        nbytes = planes * plane + nconv * wb
         t_m, t_h = flops / (PEAK_FP32_MFMA_TFLOPS * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
-        rows.append({"kernel": name, "per_step": n, "avg_launch_us": round(t * 1e6, 2), "achieved": round(ach, 2), "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                     "bytes_per_launch": nbytes, "algorithmic_GB_per_s": round(nbytes / t / 1e9, 1), "bound": "mfma" if t_m >= t_h else "hbm",
+        rows.append({"kernel": name, "row": keys[name.split()[0]], "per_step": n, "avg_launch_us": round(t * 1e6, 2), "achieved": round(ach, 2), "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                     "flops_per_launch": flops, "bytes_per_launch": nbytes, "algorithmic_GB_per_s": round(nbytes / t / 1e9, 1), "bound": "mfma" if t_m >= t_h else "hbm",
                      "frac_of_own_roof": round(max(t_m, t_h) / t, 4)})
         tf += n * flops
         tt += n * t
@@ -185,37 +187,51 @@ def step_kernel_roofline(dev, Cc, H, W, reps=20):
         troof += n * max(t_m, t_h)
     ach = tf / tt / 1e12
     slow = min(rows, key=lambda r: r["achieved"])
-    k2s = rows[0]
-    # HBM bytes per launch of the K2s kernel: PMC figure of the same kernel and shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate passes, gfx950 x2 FETCH correction), committed with its summary -- bench.py cannot run under the counter collector
-    traffic, traffic_src = None, None
-    # The PMC figure is only valid for the kernel sources it was measured on: tools/pmc_traffic.py stamps the profile with a SHA-256
-    # of those sources, and a profile whose stamp differs from the tree (or that has none) is refused -- `traffic` stays null rather
-    # than silently describing another kernel.
-    cand = [("r03_traffic.json", (12, 720, 1280)), ("r03_traffic_wide.json", None), ("r03_traffic_c4.json", None)]
-    for name, shape in cand:
+    # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 FETCH
+    # correction; tools/pmc_traffic.py), committed with their summaries -- bench.py cannot run under the counter collector.  A profile
+    # belongs to ONE row (`row` + `shape`) and is only valid for the kernel sources it was measured on: it carries a SHA-256 of those
+    # sources, and a profile whose stamp differs from the tree is refused -- `traffic` stays null rather than describing another kernel.
+    import glob
+    stale = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_traffic*.json"))):
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            tj = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if tuple(tj.get("shape", shape or ())) != (Cc, H, W):
+        if tuple(tj.get("shape", ())) != (Cc, H, W):
+            continue
+        row = next((r for r in rows if r["row"] == tj.get("row", "k2s")), None)
+        if row is None:
             continue
         if tj.get("src_sha256") != kernel_sources_sha(tj.get("sources", [])):
-            traffic_src = f"profiles/{name} is STALE (measured on other kernel sources): traffic withheld; rerun tools/pmc_traffic.py"
+            stale.append(os.path.basename(path))
             continue
-        traffic, traffic_src = float(tj["hbm_bytes_per_launch"]), tj["source"] + " [" + tj["kernel"] + "]"
+        row["traffic"] = float(tj["hbm_bytes_per_launch"])
+        row["traffic_over_algorithmic"] = round(row["traffic"] / row["bytes_per_launch"], 4)
+        row["traffic_source"] = tj["source"] + " [" + tj["kernel"] + "]"
+    # the DOMINANT kernel of the family = the row with the most time per step (launches per step x average launch): the top-level
+    # object describes THAT kernel against its own roof; the flop-weighted family figure of earlier rounds stays under `family`
+    dom = max(rows, key=lambda r: r["per_step"] * r["avg_launch_us"])
     pipe = None
     if Cc > 16:
         # these layers run on the 16-bit matrix pipe, six bf16 products per f32 product: the hardware roof of THAT instruction mix in
         # f32-equivalent flops is the dense bf16 peak / 6; `peak` / `frac` stay priced against the fp32 MFMA peak of the arithmetic type
         pipe = {"instruction": "v_mfma_f32_16x16x32_bf16, 6 products per f32 product (bf16x6)", "peak": round(PEAK_BF16_MFMA_TFLOPS / 6, 1),
                 "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS / 6), 4), "unit": "TFLOP/s (f32-equivalent)"}
-    return {"kernel": f"final-stage conv family of the step ({Cc}->{Cc} 3x3 @{H}x{W}): flop-weighted over the {nl} launches of a step listed below", "bound": "mfma", "split_pipe": pipe,
-            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-            "avg_launch_us": round(tt / nl * 1e6, 2), "flops_per_launch": flops1, "bytes_per_launch": k2s["bytes_per_launch"],
-            "slowest": {"kernel": slow["kernel"], "achieved": slow["achieved"], "frac": slow["frac"]},
-            "frac_of_per_kernel_roof": round(troof / tt, 4), "kernels": rows}
+    if dom["bound"] == "mfma":
+        top = {"bound": "mfma", "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"]}
+    else:
+        top = {"bound": "hbm", "achieved": dom["algorithmic_GB_per_s"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dom["algorithmic_GB_per_s"] / PEAK_HBM_GBS, 4)}
+    top.update({"kernel": f"{dom['kernel']} ({Cc}->{Cc} 3x3 @{H}x{W}); dominant = most time per step of the final-stage conv family ({dom['per_step']} x {dom['avg_launch_us']} us)",
+                "traffic": dom.get("traffic"), "traffic_unit": "bytes/launch",
+                "traffic_source": dom.get("traffic_source") or ("no valid PMC profile of this row" + (f" (stale, measured on other kernel sources: {', '.join(stale)})" if stale else "") + "; run tools/pmc_traffic.py"),
+                "avg_launch_us": dom["avg_launch_us"], "flops_per_launch": dom["flops_per_launch"], "bytes_per_launch": dom["bytes_per_launch"],
+                "family": {"what": f"final-stage conv family of the step ({Cc}->{Cc} 3x3 @{H}x{W}): flop-weighted over the {nl} launches of a step listed under `kernels`",
+                           "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                           "frac_of_per_kernel_roof": round(troof / tt, 4), "avg_launch_us": round(tt / nl * 1e6, 2), "split_pipe": pipe,
+                           "slowest": {"kernel": slow["kernel"], "achieved": slow["achieved"], "frac": slow["frac"]}},
+                "kernels": rows})
+    return top
 
 
 def kernel_sources_sha(files):
@@ -240,30 +256,50 @@ def cpu_model_string():
     return "unknown"
 
 
-def cpu_baseline(args, model_cpu_sd, frames, norm_idxs, budget_s=30.0, warmup=3, max_steps=20):
-    """SURVEY 8(d) protocol: the oracle restatement of the SAME train step on every host core, `warmup` untimed + up to
-    `max_steps` timed steps, bounded by `budget_s` of timed work (C1 takes ~3 s per step on 64 cores; the 1080p models 10-25 s,
-    so their sample is one warm-up + whatever fits the budget -- the sample string says what was run)."""
+def cpu_baseline(args, model_cpu_sd, frames, norm_idxs, budget_s=30.0, max_steps=20):
+    """SURVEY 8(d) protocol: the oracle restatement of the SAME train step on this box's host cores for a bounded sample.  The thread
+    count is MEASURED, not assumed (the MKLDNN convolutions of these shapes do not scale to every core of a 2-socket host): after one
+    untimed step, one untimed + two timed steps at each of 16 / 32 / 64 threads (as many as the box has), then the remaining budget at
+    the best setting; the reported value is the best setting's rate over all its timed steps, `cores` its thread count, `sweep` the
+    per-setting rates.  Models whose step takes longer than a tenth of the budget (the 1080p configs: 10-25 s per step) skip the sweep
+    and run what fits at min(cores, 64) threads -- the sample string says what was run."""
     from oracle import cpu_ref
-    ncores = min(os.cpu_count() or 1, 64)      # one thread per physical core at most: SMT siblings / >64 threads slow the MKLDNN convs down
-    torch.set_num_threads(ncores)
+    hw = os.cpu_count() or 1
     sd = {k: v.clone().float().requires_grad_(True) for k, v in model_cpu_sd.items()}
     adan = cpu_ref.AdanState(list(sd.values()), lr=args.lr)
     kind = args.model
-    t_w = time.time()
-    nw = 0
-    while nw < warmup and (nw == 0 or time.time() - t_w < budget_s / 2):
-        cpu_ref.train_step(kind, sd, adan, frames[nw % frames.shape[0]:nw % frames.shape[0] + 1], norm_idxs[nw % frames.shape[0]:nw % frames.shape[0] + 1], args.loss)
-        nw += 1
-    n, t0 = 0, time.time()
-    while n < max_steps and (n == 0 or (time.time() - t0) < budget_s):
-        i = (n + nw) % frames.shape[0]
+    k = [0]
+
+    def one():
+        i = k[0] % frames.shape[0]
+        k[0] += 1
+        t = time.time()
         cpu_ref.train_step(kind, sd, adan, frames[i:i + 1], norm_idxs[i:i + 1], args.loss)
+        return time.time() - t
+
+    t_all = time.time()
+    torch.set_num_threads(min(hw, 64))
+    one()                                                    # untimed: lazy initialisation, page faults of the first step
+    t_probe = one()
+    sweep, best = {}, min(hw, 64)
+    if t_probe * 10 <= budget_s:
+        for nt in sorted({min(hw, c) for c in (16, 32, 64)}):
+            torch.set_num_threads(nt)
+            one()
+            ts = [one(), one()]
+            sweep[nt] = round(len(ts) / sum(ts), 4)
+        best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    n, t0 = 0, time.time()
+    while n < max_steps and (n == 0 or (time.time() - t_all) < budget_s + 15.0) and (n == 0 or time.time() - t0 < budget_s):
+        one()
         n += 1
     dt = time.time() - t0
-    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model_string(),
-            "sample": f"{n} timed full train steps (fwd + {args.loss} + bwd + Adan) of the same model / frame size after {nw} warm-up, "
-                      f"oracle/cpu_ref.py on torch CPU fp32, {torch.get_num_threads()} threads, timed budget {budget_s:.0f} s"}
+    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": best, "host_cores": hw, "kind": "port", "cpu": cpu_model_string(),
+            "sweep_frames_per_s_by_threads": sweep or None,
+            "sample": f"{n} timed full train steps (fwd + {args.loss} + bwd + Adan) of the same model / frame size at the best of the swept thread counts "
+                      f"({best} threads; sweep: 1 untimed + 2 timed steps per setting{'' if sweep else ' skipped, one step takes more than a tenth of the budget'}), "
+                      f"oracle/cpu_ref.py on torch CPU fp32, timed budget {budget_s:.0f} s"}
 
 
 def parity_leg(args, model, opt, step_fn, frames, norm, takes_image, s0, n_iter, set_lr, K=3, budget_s=60.0):
@@ -473,6 +509,64 @@ def main():
             else:
                 step(frames[i:i + 1], norm[i:i + 1])
 
+    # ---- N > 1: make the run self-diagnosing (nothing here is inside the timed region) -----------------------------------------------
+    # (a) the flat bucket's all-reduce alone, timed on its own (bucket-size fp32 tensor, 20 repetitions after 3 warm-ups);
+    # (b) both bucket layouts of the step -- one segment, and two segments with the early one overlapped with the stem's backward
+    #      -- 20 steps each after their own eager warm-up + capture; the faster one (max over ranks, so every rank
+    #     picks the same) runs the W warm-up and the K timed steps.  BNERV_DP_BUCKETS pins the layout and skips the probe.
+    dp_diag = None
+    if (world > 1 or force_bucket) and a.config != "c5":
+        def timed_steps(stp, k0, k):
+            for s_ in range(k0, k0 + k):
+                i_ = s_ % n_iter
+                adjust_lr(opt, (s_ / n_iter) / args.epochs, i_, args)
+                stp.step_frame(i_) if by_index else stp(frames[i_:i_ + 1], norm[i_:i_ + 1])
+
+        def probe(stp, k=20):
+            timed_steps(stp, 0, 6)                              # 3 eager + capture + 2 replays
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t_ = time.time()
+            timed_steps(stp, 6, k)
+            torch.cuda.synchronize()
+            tt_ = torch.tensor([(time.time() - t_) / k * 1e3], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            return round(tt_.item(), 4)
+
+        buf = torch.zeros(n_params, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t_ = time.time()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ar = torch.tensor([(time.time() - t_) / 20 * 1e6], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        dp_diag = {"allreduce_us": round(ar.item(), 1), "allreduce_bytes": n_params * 4,
+                   "allreduce_what": "one all_reduce(SUM) of a bucket-size fp32 tensor on this process group, mean of 20 back-to-back calls after 3 warm-ups, host-synchronised, max over ranks"}
+        pinned = os.environ.get("BNERV_DP_BUCKETS")
+        if pinned is None and hasattr(model, "dp_late_parameters"):
+            probe_ms = {"1": probe(step)}
+            model.dp_hook = None
+            step2 = TrainStep(model, opt, args.loss, takes_image, (per_gpu_batch, 3, r["h"], r["w"]), dev, use_graph=not a.no_graph,
+                              warmup_eager=3, world_size=world, force_bucket=force_bucket, dp_buckets=2)
+            if by_index:
+                step2.bind_clip(frames, norm)
+            probe_ms["2"] = probe(step2)
+            if probe_ms["2"] < probe_ms["1"]:
+                step = step2
+            else:
+                model.dp_hook = None                            # (step 1's graph was captured without the hook; eager steps must not call step 2's)
+                del step2
+            dp_diag["probe_ms_per_step"] = probe_ms
+        dp_diag["dp_buckets"] = 2 if (step.bucket is not None and step.bucket.two) else 1
+
     run(0, max(a.warmup, 5))
     if world > 1:
         dist.barrier()
@@ -523,7 +617,14 @@ def main():
                           "per_gpu_batch": per_gpu_batch, "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
                           "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else 0),
                           "collective_in_graph": bool(getattr(step, "collective_in_graph", False)), "replicas_in_sync": replicas_in_sync,
+                          "dp_mode": (None if step.bucket is None else "eager" if step.graph_a is None else "in_graph" if step.collective_in_graph else "two_graph"),
+                          "dp_buckets": (None if dp_diag is None else dp_diag["dp_buckets"]),
                           "last_loss": round(loss, 6), "last_train_psnr_db": round(psnr, 4)}}
+        if dp_diag is not None:
+            out["dp"] = dp_diag
+            out["allreduce_us"] = dp_diag["allreduce_us"]
+        if world > 1 and not replicas_in_sync:
+            out["error"] = "replicas diverged: the ranks do not hold the same parameter bits after the timed steps (the gradient exchange did not run, or ran out of order)"
         c_last = last_stage_channels(model)
         out["roofline"] = step_kernel_roofline(dev, c_last, r["h"], r["w"], reps=20 if r["h"] <= 720 else 8)
         fl, by = STEP_WORK[a.config]
@@ -554,6 +655,19 @@ def main():
             t_h = time.time() - t_h
             out["host_frames"] = {"value": round(n_h / t_h, 2), "unit": "frames/s", "ms_per_step": round(t_h / n_h * 1e3, 4),
                                   "what": f"{n_h} steps with the frame copied from pinned host memory each step ({frames[0].numel() * 4 / 1e6:.1f} MB over PCIe) before the same captured step"}
+        if a.config == "c1":
+            # the "eval PSNR" half of BASELINE's metric needs the whole schedule (300 epochs): recorded once per round through the CLI
+            # (tools/recipe_record.py -> profiles/rNN_cli_c1_e300.json), quoted here next to the live numbers, never as `value`
+            import glob
+            rec = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[4-9]_cli_c1_e300.json")))
+            if rec:
+                try:
+                    rj = json.load(open(rec[-1]))
+                    out["recipe"] = {k: rj.get(k) for k in ("recipe", "epochs", "frames_trained", "wall_s", "train_wo_eval_s", "end_to_end_frames_per_s", "pred_seen_psnr_db",
+                                                             "quant_seen_psnr_db", "bpp", "bit_identical_checkpoints", "dataloader_path", "source")}
+                    out["recipe"]["recorded"] = "a committed record of an earlier run of the full schedule on an MI355X (not measured by this invocation)"
+                except (OSError, ValueError):
+                    pass
         ev, nev = eval_psnr(model, frames, norm, takes_image)
         out["eval_psnr_db"] = round(ev, 3)
         out["config"]["eval"] = f"pred_seen_psnr over the first {nev} frames of the shard after {max(a.warmup, 5) + a.steps + (out['parity']['steps'] if 'parity' in out else 0)} train steps from random init (fp32 model)"

@@ -42,6 +42,20 @@ class SyntheticVideo:
         return torch.round(out.clamp(0, 1) * 255.0) / 255.0
 
 
+def dump_png(directory, n_frames, height, width, device="cpu"):
+    """Write the clip as frame_%04d.png files: the layout the reference's VideoDataSet reads (hnerv_utils.py:19-47; sorted directory
+    listing, PNG -> ToTensor), so the loader path can be driven with real files.  The frames are on an 8-bit grid, so the PNGs hold
+    them exactly."""
+    import os
+    from PIL import Image
+    os.makedirs(directory, exist_ok=True)
+    vid = SyntheticVideo(n_frames, height, width)
+    for i in range(n_frames):
+        arr = (vid.frame(i, device=device) * 255.0).round().clamp(0, 255).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+        Image.fromarray(arr).save(os.path.join(directory, f"frame_{i:04d}.png"))
+    return directory
+
+
 def parse_spec(spec):
     """'synthetic:bunny' | 'synthetic:uvg' | 'synthetic:NxHxW'"""
     s = spec.split(":", 1)[1].lower()

@@ -234,6 +234,28 @@ def gen_full_models(R):
     np.savez_compressed(os.path.join(OUT, "full_models.npz"), **out)
 
 
+def gen_full_c1_grads(R):
+    """C1 at full size, gradient ELEMENTS (norms alone would pass a sign / permutation error that keeps the norm):
+    the run of gen_full_models for c1 once more (same seeds, same frame, same t) and, of EVERY parameter gradient, 512 elements at fixed
+    sampled positions (the whole tensor when it has 512 elements or fewer) with mean / std -- stem.2.weight (1.1 M elements), the TAT
+    convs, the up-convs, the head and every modulation MLP alike."""
+    out = {}
+    torch.manual_seed(1)
+    m = _model(R, configs.c1())
+    out["sd_sha256"] = np.array(sd_hash(m.state_dict()))
+    g = torch.Generator().manual_seed(5)
+    frame = torch.rand(1, 3, 720, 1280, generator=g)
+    norm_idx = torch.tensor([37 / 132], dtype=torch.float64)
+    img, lst, _ = m(norm_idx, norm_idx=norm_idx)
+    loss = R.hnerv_utils.loss_fn(img, frame, "L1_freq")
+    loss.backward()
+    out["loss_L1_freq"] = np.float64(loss.item())
+    for pn, p in m.named_parameters():
+        summary(p.grad, f"grad/{pn}", out, 512)
+        out[f"gnorm/{pn}"] = np.float64(p.grad.double().norm().item())
+    np.savez_compressed(os.path.join(OUT, "full_c1_grads.npz"), **out)
+
+
 def gen_full_1080(R):
     """C3 (HNeRV-boost 3M, model_hnerv.py:224-251, encoder included) and C4 (E-NeRV-boost 3M, model_enerv.py:279-317) at
     1080x1920, torch.manual_seed(1) construction: image / per-stage output summaries at one frame, loss L1_freq, PSNR and
@@ -513,8 +535,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = ref_harness.load_reference()
-    which = sys.argv[1:] or ["pe", "blocks", "cnx", "tiny", "full", "full1080", "loss", "optim", "host", "cem", "cem_model", "full_c5", "inpaint"]
-    fns = dict(pe=gen_pe, blocks=gen_blocks, cnx=gen_convnext_blocks, tiny=gen_tiny_models, full=gen_full_models, full1080=gen_full_1080, loss=gen_loss, optim=gen_optim, host=gen_host, cem=gen_cem, cem_model=gen_cem_model, full_c5=gen_full_c5, inpaint=gen_inpaint)
+    which = sys.argv[1:] or ["pe", "blocks", "cnx", "tiny", "full", "full1080", "loss", "optim", "host", "cem", "cem_model", "full_c5", "inpaint", "full_c1_grads"]
+    fns = dict(pe=gen_pe, blocks=gen_blocks, cnx=gen_convnext_blocks, tiny=gen_tiny_models, full=gen_full_models, full1080=gen_full_1080, loss=gen_loss, optim=gen_optim, host=gen_host, cem=gen_cem, cem_model=gen_cem_model, full_c5=gen_full_c5, inpaint=gen_inpaint, full_c1_grads=gen_full_c1_grads)
     for w in which:
         print("generating", w, flush=True)
         fns[w](R)

@@ -287,6 +287,39 @@ def test_fft_loss_full_size_properties(ops):
         assert abs(loss.item() - (60 * 0.25 + 0.125)) < 1e-3, (H, W, loss.item())
 
 
+def test_recipe_loss_at_1080p_against_oracle_and_independent_msssim(ops):
+    """the recipe's loss at BASELINE's 1080x1920 -- Fusion10_freq value and gradient, and ops.msssim, against the
+    CPU oracle (cpu_ref.loss_fn / msssim_ref: the MS-SSIM pyramid is ODD here, 1080 -> 540 -> 270 -> 135 -> 68, so the padded average
+    pool and the un-merged launch path run) and the MS-SSIM value against the independently written float64 form from the definition
+    (tests/msssim_independent.py).  The L1 / FFT terms are pinned to the reference by the 1080p model goldens (loss_L1_freq); this is
+    the term they do not cover."""
+    import numpy as np
+    import msssim_independent as ind
+    g = torch.Generator().manual_seed(11)
+    tgt = torch.rand(1, 3, 1080, 1920, generator=g)
+    tgt = torch.nn.functional.avg_pool2d(tgt, 3, stride=1, padding=1)          # some structure at every scale
+    pred = (tgt + 0.08 * torch.randn(tgt.shape, generator=g)).clamp(0, 1).requires_grad_(True)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ref = cpu_ref.loss_fn(pred, tgt, "Fusion10_freq")
+    rgrad, = torch.autograd.grad(ref, [pred])
+    pg = gpu(pred)
+    loss, stats = ops.loss_with_stats(pg, tgt.to(DEV), "Fusion10_freq")
+    assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item()), (loss.item(), ref.item())
+    ggrad, = torch.autograd.grad(loss, [pg])
+    idx = torch.from_numpy(np.sort(np.random.RandomState(3).choice(pred.numel(), 512, replace=False)))
+    gs, rs = ggrad.flatten().cpu()[idx], rgrad.flatten()[idx]
+    close(gs, rs, rtol=2e-3, atol=2e-3 * float(rgrad.abs().max()), msg="1080p Fusion10_freq gradient samples")
+    close(ggrad, rgrad, rtol=2e-3, atol=2e-3 * float(rgrad.abs().max()), msg="1080p Fusion10_freq gradient (whole)")
+    l2, st2, g2 = ops.loss_value_grad_stats(pg, tgt.to(DEV), "Fusion10_freq")       # the train step's fused form: the same bits
+    assert l2.item() == loss.item() and torch.equal(g2, ggrad)
+    ms_h = ops.msssim(pg, tgt.to(DEV)).cpu().double().numpy()
+    ms_r = msssim_ref.ms_ssim(pred.detach(), tgt, data_range=1, size_average=False).double().numpy()
+    ms_i = ind.ms_ssim(pred.detach().numpy(), tgt.numpy())
+    assert np.abs(ms_h - ms_r).max() < 2e-5, (ms_h, ms_r)
+    assert np.abs(ms_h - ms_i).max() < 2e-5 and np.abs(ms_r - ms_i).max() < 5e-6, (ms_h, ms_r, ms_i)
+    assert abs(float(stats[0, 3]) - float(ms_i[0])) < 2e-5                       # the loss statistics carry the same MS-SSIM
+
+
 # ---------------------------------------------------------------------------------------------------------------- Adan
 def test_adan_against_reference_trajectory():
     from boosting_nerv_amd.optimizer import Adan
