@@ -166,6 +166,13 @@ def step_kernel_roofline(dev, Cc, H, W, reps=20):
             dict(x=x, g=dout, dw=dw, db=db, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=1, **kw),
             dict(x=dout, w=w, bias=None, out=out, in_mode=L.IN_PLAIN, ep_mode=L.EP_PLAIN, transposed=1, **kw))),
     ]
+    # round 4: where the library takes the whole TAT block forward as one launch (include/bnerv.h bnerv_tat_block_fwd: the 12-channel
+    # stages), THAT launch is what the step runs instead of K2s + K3s -- probe it the way ops._tat_forward does and swap the rows
+    import ctypes as _C
+    _td = L.TatDesc(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(w), L.ptr(b), L.ptr(sc), L.ptr(sh), L.ptr(sc), L.ptr(sh), L.ptr(h), L.ptr(gp), L.ptr(out), B, Cc, H, W, L.ctx().handle)
+    if L.load().bnerv_tat_block_fwd(L.stream(), _C.byref(_td)) == 0:
+        cases = [("TAT block fwd, ONE launch: affine->conv0->bias->gelu,gelu'->affine->conv1->bias->+x0", 2, 4,
+                  lambda: ops._tat_forward(x, sc, sh, sc, sh, w, b, w, b, True))] + cases[2:]
     flops1 = 2.0 * Cc * Cc * 9 * H * W
     rows, tf, tt, nl = [], 0.0, 0.0, 0
     troof = 0.0

@@ -39,6 +39,11 @@ class ConvDesc(C.Structure):
                 ("transposed", C.c_int), ("wCo", C.c_int), ("wCi", C.c_int), ("ctx", _fp)]
 
 
+class TatDesc(C.Structure):
+    _fields_ = [("x0", _fp), ("w0", _fp), ("b0", _fp), ("w1", _fp), ("b1", _fp), ("scale0", _fp), ("shift0", _fp), ("scale1", _fp), ("shift1", _fp),
+                ("h", _fp), ("gp", _fp), ("out", _fp), ("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("ctx", _fp)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("x", _fp), ("g", _fp), ("gaux", _fp), ("scale", _fp), ("shift", _fp), ("dw", _fp), ("db", _fp),
                 ("ws", _fp), ("ws_bytes", C.c_size_t),
@@ -123,6 +128,7 @@ SYMBOLS = {
     "bnerv_conv_igemm": (_I, [_V, C.POINTER(ConvDesc)]),
     "bnerv_conv_splitk_ws_bytes": (_Z, [C.POINTER(ConvDesc)]),
     "bnerv_conv_partial_rows": (_I, [C.POINTER(ConvDesc)]),
+    "bnerv_tat_block_fwd": (_I, [_V, C.POINTER(TatDesc)]),
     "bnerv_conv_wgrad_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bnerv_conv_wgrad_pair": (_I, [_V, C.POINTER(ConvDesc), C.POINTER(WgradDesc)]),
     "bnerv_conv_wgrad": (_I, [_V, C.POINTER(WgradDesc)]),
@@ -160,7 +166,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class BnervError(RuntimeError):

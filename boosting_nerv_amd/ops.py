@@ -384,10 +384,19 @@ def _tat_forward(y0, s0, t0, s1, t1, w0, b0, w1, b1, train=True):
     B, Cc, H, W = y0.shape
     # conv0's epilogue stores h = gelu(v) and gp = gelu'(v) instead of v: conv1, its weight gradient and the dGELU epilogue of
     # the backward then run without erf/exp (v itself has no other consumer)
-    h = torch.empty_like(y0)
-    gp = torch.empty_like(y0) if train else None          # decode / eval (no_grad): gelu' is never read, so it is not written
-    _conv(y0, w0, b0, h, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=s0, shift=t0, out2=gp)
     out = torch.empty_like(y0)
+    hs = torch.empty_like(y0) if train else None
+    gp = torch.empty_like(y0) if train else None          # decode / eval (no_grad): neither h nor gelu' is read again, so they are not written
+    # the whole block as ONE launch where the library takes it (12-channel stages: include/bnerv.h bnerv_tat_block_fwd, csrc/tatf.hip)
+    td = L.TatDesc(L.ptr(y0), L.ptr(w0), L.ptr(b0), L.ptr(w1), L.ptr(b1), L.ptr(s0), L.ptr(t0), L.ptr(s1), L.ptr(t1), L.ptr(hs), L.ptr(gp), L.ptr(out),
+                   B, Cc, H, W, L.ctx().handle)
+    rc = L.load().bnerv_tat_block_fwd(L.stream(), C.byref(td))
+    if rc == 0:
+        return hs, gp, out
+    if rc != 1:
+        L.check(rc, "bnerv_tat_block_fwd")
+    h = hs if train else torch.empty_like(y0)
+    _conv(y0, w0, b0, h, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=s0, shift=t0, out2=gp)
     _conv(h, w1, b1, out, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_RES, scale=s1, shift=t1, aux0=y0)
     return h, gp, out
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BNERV_ABI_VERSION 5
+#define BNERV_ABI_VERSION 6
 
 #define BNERV_OK 0
 #define BNERV_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -213,6 +213,32 @@ int bnerv_conv_partial_rows(const bnerv_conv_desc* d);
  * With partial == NULL the layer runs unsplit. */
 size_t bnerv_conv_splitk_ws_bytes(const bnerv_conv_desc* d);
 int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* d);
+
+/* The TAT residual block forward as ONE launch (ABI 6; csrc/tatf.hip).  Replaces ResBlock_SFT.forward (model_blocks.py:74-89):
+ *     out = x0 + conv1( sft1( gelu( conv0( sft0(x0) ) ) ) ),   sft_i(a) = a*(1+scale_i[b,c]) + shift_i[b,c]   (SFTLayer, model_blocks.py:92-105)
+ * both convolutions 3x3, stride 1, zero padding 1 (applied AFTER each affine), C -> C channels with bias; GELU exact (model_blocks.py:81).
+ * Train form (h and gp given): also writes h = gelu(v) and gp = gelu'(v), v = conv0(sft0(x0)) + b0 -- exactly what the two-call form
+ * (bnerv_conv_igemm with BNERV_IN_AFFINE / BNERV_EP_BIAS_GELU, then BNERV_IN_AFFINE / BNERV_EP_BIAS_RES) leaves behind, so the backward
+ * (bnerv_conv_wgrad_pair x 2) is unchanged.  Decode form (h == gp == NULL): only `out` is written.
+ * Returns 1 when the block is not this kernel's (C outside 9..12, W % 4 != 0, unaligned tensors, a handful of tiles): the caller then
+ * issues the two bnerv_conv_igemm calls.  The intermediate tile stays in LDS (one-pixel halo recomputed per 16x32 tile). */
+typedef struct {
+    const float* x0;       /* [B, C, H, W] */
+    const float* w0;       /* [C, C, 3, 3] conv0 */
+    const float* b0;       /* [C] or NULL */
+    const float* w1;       /* [C, C, 3, 3] conv1 */
+    const float* b1;       /* [C] or NULL */
+    const float* scale0;   /* [B, C] */
+    const float* shift0;   /* [B, C] */
+    const float* scale1;   /* [B, C] */
+    const float* shift1;   /* [B, C] */
+    float* h;              /* [B, C, H, W] gelu(v)   (NULL with gp: decode) */
+    float* gp;             /* [B, C, H, W] gelu'(v) */
+    float* out;            /* [B, C, H, W] */
+    int B, C, H, W;
+    bnerv_ctx* ctx;        /* stream context (may be NULL; nothing is hosted by this launch) */
+} bnerv_tat_desc;
+int bnerv_tat_block_fwd(void* stream, const bnerv_tat_desc* d);
 
 /* Weight + bias gradient (autograd's backward of F.conv2d wrt weight/bias at the same call sites):
  *   dw[co][ci][t] = sum_{b,p} g[b][co][p] * a[b][ci][p + t - pad],  db[co] = sum_{b,p} g[b][co][p]

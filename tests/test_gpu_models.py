@@ -247,7 +247,8 @@ def test_big_models_captured_recipe_steps_against_oracle(name, cfg):
     from boosting_nerv_amd.optimizer import Adan
     from boosting_nerv_amd.synth import SyntheticVideo
     args = cfg()
-    args.loss, args.lr_type, args.epochs = "Fusion10_freq", getattr(args, "lr_type", "cosine_0.1_1_0.1"), 300
+    # (the recipes' flags that oracle.configs leaves to the CLI: scripts/regression/UVG/hnerv_boost.sh:7-12, enerv_boost.sh:7-12)
+    args.loss, args.lr_type, args.epochs, args.lr, args.warmup = "Fusion10_freq", "cosine_0.1_1_0.1", 300, {"c3": 0.003, "c4": 0.0015}[name], 0.0
     torch.manual_seed(1)
     model = _build(name, args).to(DEV)
     opt = Adan(model.parameters(), lr=args.lr)
