@@ -44,6 +44,13 @@ constexpr int RING_PER_WAVE = RING / 4;                    // 13
 static_assert(RING % 4 == 0 && RING_PER_WAVE <= 16, "the ring is one wave-op per wave");
 constexpr int LDS_FLOATS = 4 + 2 * S_IN + NCH * H_PLANE + 8 + 2 * S_W + 64 + 2 * 9 * 16;
 
+#ifdef BNERV_TRACE_TAT
+__device__ unsigned long long g_trace_tat[256 * 4 * 4 * 16];      // [block][wave][tile < 4][stamp]
+#define TTR(slot) do { if (lane == 0 && trace_tile < 4) g_trace_tat[(((int)blockIdx.x * 4 + wave) * 4 + trace_tile) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TTR(slot) do {} while (0)
+#endif
+
 struct TatArgs {
     bnerv_tat_desc d;
     int tiles_x, tiles_y, total_items;
@@ -67,35 +74,35 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned voff, unsigned soff, 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// one wave-op: 64 pixels x 12 output channels x (12 channels x 9 taps); a = the lane's own pixel at tap (0, 0) of channel 0
+// one wave-op: 64 pixels x 12 output channels x (12 channels x 9 taps); a = the lane's own pixel at tap (0, 0) of channel 0.
+// The block runs ONE wave per SIMD, and a lone wave sees the full LDS round trip (~100+ cycles for a 4-byte read against 72 cycles of
+// MFMA per tap row): the A values are therefore read DEPTH tap rows ahead (3 registers per row -- the register file is this wave's alone).
 template <int PLANE, int RS>
 __device__ __forceinline__ void kloop(f32x4 (&acc)[NG], const float* a, const float (&wr)[NCH][NWR]) {
-    float a_cur[3], a_nxt[3];
+    constexpr int DEPTH = 4, NT = NCH * 3;                 // tap rows in flight; tap rows of the K loop (t = ci * 3 + ky)
+    float av[NT + DEPTH][3];                               // (fully unrolled: every index is a constant, a value lives DEPTH rows)
 #pragma unroll
     for (int n = 0; n < NG; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) a_cur[kx] = a[kx];
+    for (int t = 0; t < DEPTH; ++t)
 #pragma unroll
-    for (int ci = 0; ci < NCH; ++ci) {
+        for (int kx = 0; kx < 3; ++kx) av[t][kx] = a[(t / 3) * PLANE + (t % 3) * RS + kx];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int nci = ky == 2 ? ci + 1 : ci, nky = ky == 2 ? 0 : ky + 1;
-            if (nci < NCH) {
+    for (int t = 0; t < NT; ++t) {
+        const int ci = t / 3, ky = t % 3, tn = t + DEPTH;
+        if (tn < NT) {
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) a_nxt[kx] = a[nci * PLANE + nky * RS + kx];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int n = 0; n < NG; ++n) {
-                    const int q = (ky * 3 + kx) * NG + n;
-                    acc[n] = mfma_qsel(q & 3, a_cur[kx], wr[ci][q >> 2], acc[n]);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) a_cur[kx] = a_nxt[kx];
+            for (int kx = 0; kx < 3; ++kx) av[tn][kx] = a[(tn / 3) * PLANE + (tn % 3) * RS + kx];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int n = 0; n < NG; ++n) {
+                const int q = (ky * 3 + kx) * NG + n;
+                acc[n] = mfma_qsel(q & 3, av[t][kx], wr[ci][q >> 2], acc[n]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -307,7 +314,9 @@ __global__ __launch_bounds__(256, 1) void tat_fused_kernel(const TatArgs ka) {
     }
 
     int buf = 0;
-    for (; itx < r1; itx += nlb) {
+    int trace_tile = 0; (void)trace_tile;
+    for (; itx < r1; itx += nlb, ++trace_tile) {
+        TTR(0);
         const bool has_next = itx + nlb < r1;
         LItem nxt = it;
         if (has_next) { nxt = advance(it); issue(nxt, buf ^ 1); }
@@ -317,6 +326,7 @@ __global__ __launch_bounds__(256, 1) void tat_fused_kernel(const TatArgs ka) {
         const bool border = ty0 < 2 || ty0 + FTH + 2 > H || tx0 < 4 || tx0 + FTW + 2 > W;
         const unsigned ob = (unsigned)((((it.b * C) * H + ty0 + 4 * wave) * W + tx0) * 4);
         f32x4 acc[NG];
+        TTR(1);
 
         // ---- phase 0: h = gelu(conv0) on the tile (wave-ops 0, 1) and its one-pixel ring (wave-op 2).  One code body for the three (the
         // K loop is 324 MFMAs: unrolling the wave-ops would put ~55 KB of instructions in the tile loop)
@@ -324,6 +334,7 @@ __global__ __launch_bounds__(256, 1) void tat_fused_kernel(const TatArgs ka) {
         for (int op = 0; op < 3; ++op) {
             const bool ring = op == 2;
             kloop<IN_PLANE, IN_RS>(acc, sin_b + (ring ? ring_a : (4 * wave + 2 * op + (lane >> 5) + 1) * IN_RS + (lane & 31) + 3), wr0);
+            TTR(2 + 2 * op);
             const int row = ring ? rrow : 4 * wave + 2 * op + (lb >> 3);      // tile row / column of this lane's four-pixel block
             const int colb = ring ? rcol : 4 * (lb & 7);
             const int gy = ty0 + row, gx0 = tx0 + colb;
@@ -345,14 +356,17 @@ __global__ __launch_bounds__(256, 1) void tat_fused_kernel(const TatArgs ka) {
                     bstore(rg, vo, so, gv);
                 }
             }
+            TTR(3 + 2 * op);
         }
         lds_barrier();                                     // the h tile is complete
+        TTR(8);
 
         // ---- phase 1: out = conv1(h) + b1 + shift term + x0
 #pragma nounroll
         for (int op = 0; op < 2; ++op) {
             const int row = 4 * wave + 2 * op + (lb >> 3);
             kloop<H_PLANE, H_RS>(acc, s_h + (4 * wave + 2 * op + (lane >> 5)) * H_RS + (lane & 31) + 3, wr1);
+            TTR(9 + 2 * op);
             const int gy = ty0 + row, gx0 = tx0 + 4 * (lb & 7);
             const bool px_ok = gy < H && gx0 < W;
 #pragma unroll
@@ -362,6 +376,7 @@ __global__ __launch_bounds__(256, 1) void tat_fused_kernel(const TatArgs ka) {
                 const bool ok = px_ok && (4 * n + lj < C);
                 bstore(ro, ok ? ovoff : OOB, ob + (unsigned)(2 * op * W * 4) + (unsigned)n * nstep, v);
             }
+            TTR(10 + 2 * op);
         }
         if (has_next) {
             // this tile's stores are younger than the next tile's DMA: all but them are complete
@@ -376,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void tat_fused_kernel(const TatArgs ka) {
             }
             buf ^= 1;
         }
+        TTR(13);
         it = nxt;
     }
 }
@@ -384,6 +400,9 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 }  // namespace
 
+#ifdef BNERV_TRACE_TAT
+extern "C" int bnerv_debug_trace_tat_read(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_tat), sizeof(g_trace_tat)); }
+#endif
 // 1: not this kernel's block (the caller issues the two convolution calls); BNERV_OK; negative BNERV_E_*.
 extern "C" int bnerv_tat_block_fwd(void* stream, const bnerv_tat_desc* dp) {
     BNERV_REQUIRE(dp != nullptr, "bnerv_tat_block_fwd: null descriptor");
@@ -391,7 +410,11 @@ extern "C" int bnerv_tat_block_fwd(void* stream, const bnerv_tat_desc* dp) {
     BNERV_REQUIRE(d.x0 && d.w0 && d.w1 && d.scale0 && d.shift0 && d.scale1 && d.shift1 && d.out, "bnerv_tat_block_fwd: null tensor");
     BNERV_REQUIRE((d.h == nullptr) == (d.gp == nullptr), "bnerv_tat_block_fwd: h and gp are written together (train) or not at all (decode)");
     BNERV_REQUIRE(d.B > 0 && d.C > 0 && d.H > 0 && d.W > 0, "bnerv_tat_block_fwd: bad shape %d x %d x %d x %d", d.B, d.C, d.H, d.W);
-    { const char* e = getenv("BNERV_TATF"); if (e && e[0] == '0') return 1; }      // A/B switch (read per call: tests and tools flip it)
+    // OPT-IN (BNERV_TATF=1; read per call: tests and tools flip it).  Measured on MI355X (profiles/r04_tatf_trace.md): 118-121 us per 720p
+    // block against 89 us for the two launches it replaces -- with one wave per SIMD nothing overlaps the f32 MFMA (K loops 5 x 3.85 k
+    // cycles, epilogues 6.9 k, LDS-DMA issue 1.8 k per tile), the halo recompute is a fifth wave-op per four, and 1800 tiles on 256 blocks
+    // are 8 rounds for 7.03.  Kept as a tested alternative form, not dispatched by default.
+    { const char* e = getenv("BNERV_TATF"); if (!(e && e[0] == '1')) return 1; }
     const size_t bytes = (size_t)d.B * d.C * d.H * d.W * 4;
     if (!(d.C > 8 && d.C <= NCH && d.W % 4 == 0 && d.H >= 3 && d.W >= 4 && bytes + (size_t)(2 * d.W + 4) * 4 < LEAN_MAX_BYTES &&
           aligned16(d.x0) && aligned16(d.out) && aligned16(d.h) && aligned16(d.gp)))

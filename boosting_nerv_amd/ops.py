@@ -13,6 +13,7 @@ ATen):
   loss / psnr / msssim     loss_fn, psnr_fn_single, ms_ssim      hnerv_utils.py:335-403, :410-412
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn.functional as F
@@ -387,10 +388,13 @@ def _tat_forward(y0, s0, t0, s1, t1, w0, b0, w1, b1, train=True):
     out = torch.empty_like(y0)
     hs = torch.empty_like(y0) if train else None
     gp = torch.empty_like(y0) if train else None          # decode / eval (no_grad): neither h nor gelu' is read again, so they are not written
-    # the whole block as ONE launch where the library takes it (12-channel stages: include/bnerv.h bnerv_tat_block_fwd, csrc/tatf.hip)
-    td = L.TatDesc(L.ptr(y0), L.ptr(w0), L.ptr(b0), L.ptr(w1), L.ptr(b1), L.ptr(s0), L.ptr(t0), L.ptr(s1), L.ptr(t1), L.ptr(hs), L.ptr(gp), L.ptr(out),
-                   B, Cc, H, W, L.ctx().handle)
-    rc = L.load().bnerv_tat_block_fwd(L.stream(), C.byref(td))
+    # the whole block as ONE launch (12-channel stages: include/bnerv.h bnerv_tat_block_fwd, csrc/tatf.hip).  OPT-IN, BNERV_TATF=1: on MI355X
+    # the one-launch form measured 118-121 us per 720p block against 89 us for the two launches, so the default is two
+    rc = 1
+    if os.environ.get("BNERV_TATF", "0") == "1":
+        td = L.TatDesc(L.ptr(y0), L.ptr(w0), L.ptr(b0), L.ptr(w1), L.ptr(b1), L.ptr(s0), L.ptr(t0), L.ptr(s1), L.ptr(t1), L.ptr(hs), L.ptr(gp), L.ptr(out),
+                       B, Cc, H, W, L.ctx().handle)
+        rc = L.load().bnerv_tat_block_fwd(L.stream(), C.byref(td))
     if rc == 0:
         return hs, gp, out
     if rc != 1:
