@@ -220,62 +220,154 @@ class _DenseGrouped(torch.autograd.Function):
     def backward(ctx, *dys):
         if _lazy_depth > 0:
             _flush_deferred()               # the incoming gradients may be deferred slab reductions (the TAT blocks' channel sums)
-        n, B, acts = ctx.n, ctx.B, ctx.acts
+        n = ctx.n
         sv = ctx.saved_tensors
         xc, wc, ys, auxs = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:4 * n]
-        lib = L.load()
-        dev = ys[0].device
         need_x = [ctx.needs_input_grad[2 + i] for i in range(n)]
-        descs, keep = [], []
-        dws, dbs, dxps, nchunks = [], [], [], []
-        I0 = wc[0].shape[1]
-        shared = ctx.same_x and n > 1 and any(need_x) and all(w.shape[0] <= L.DENSE_DX_CHUNK and w.shape[1] == I0 for w in wc)
-        shared_buf = torch.empty(n, B, I0, dtype=torch.float32, device=dev) if shared else None
-        for i in range(n):
-            x, w = xc[i], wc[i]
-            O, I = w.shape
-            dy = dys[i]
-            if dy is None:
-                dy = torch.zeros(B, O, dtype=torch.float32, device=dev)
-            dy = L.f32c(dy).reshape(B, O)
-            dw = torch.empty(O, I, dtype=torch.float32, device=dev)
-            db = torch.empty(O, dtype=torch.float32, device=dev) if ctx.has_b[i] else None
-            dpre = torch.empty(B, O, dtype=torch.float32, device=dev)
-            nch = (O + L.DENSE_DX_CHUNK - 1) // L.DENSE_DX_CHUNK
-            if shared:
-                dxp = shared_buf[i]
-            elif need_x[i]:
-                dxp = torch.empty(nch, B, I, dtype=torch.float32, device=dev)
-            else:
-                dxp = None
-            descs.append(L.DenseBwdDesc(L.ptr(x), L.ptr(w), L.ptr(ys[i]), L.ptr(auxs[i]), L.ptr(dy), L.ptr(dpre), L.ptr(dw), L.ptr(db),
-                                        L.ptr(dxp), I, O, acts[i], 0))
-            keep.append((dy, dpre))
-            dws.append(dw); dbs.append(db); dxps.append(dxp); nchunks.append(nch)
-        for i0 in range(0, n, L.MAX_DENSE_GROUPS):
-            chunk = descs[i0:i0 + L.MAX_DENSE_GROUPS]
-            arr = (L.DenseBwdDesc * len(chunk))(*chunk)
-            L.check(lib.bnerv_dense_grouped_bwd(L.stream(), arr, len(chunk), B), "bnerv_dense_grouped_bwd")
-        dxs = [None] * n
-        if shared:
-            tot = torch.empty(B, I0, dtype=torch.float32, device=dev)
-            _reduce_slabs(shared_buf, n, B * I0, tot)
-            first = next(i for i in range(n) if need_x[i])
-            dxs[first] = tot               # the same tensor was passed n times: its whole gradient goes to one slot
-        else:
-            for i in range(n):
-                if dxps[i] is None:
-                    continue
-                if nchunks[i] == 1:
-                    dxs[i] = dxps[i][0]
-                else:
-                    I = wc[i].shape[1]
-                    tot = torch.empty(B, I, dtype=torch.float32, device=dev)
-                    _reduce_slabs(dxps[i], nchunks[i], B * I, tot)
-                    dxs[i] = tot
+        dxs, dws, dbs = _dense_grouped_bwd(ctx.acts, xc, wc, ys, auxs, dys, need_x, ctx.has_b, ctx.same_x, ctx.B)
         dws = [dw.reshape(sh) for dw, sh in zip(dws, ctx.wshapes)]
         dxs = [None if dx is None else dx.reshape(sh) for dx, sh in zip(dxs, ctx.xshapes)]
         return (None, None) + tuple(dxs) + tuple(dws) + tuple(dbs)
+
+
+def _dense_grouped_bwd(acts, xc, wc, ys, auxs, dys, need_x, has_b, same_x, B):
+    """Backward of n grouped dense layers y_i = act_i(W_i x_i + b_i) (bnerv_dense_grouped_bwd): returns ([dx_i or None], [dW_i [O, I]], [db_i or
+    None]).  same_x: every layer read the SAME input tensor -- its gradient is the sum over the layers, returned in the first needed slot."""
+    n = len(xc)
+    lib = L.load()
+    dev = ys[0].device
+    descs, keep = [], []
+    dws, dbs, dxps, nchunks = [], [], [], []
+    I0 = wc[0].shape[1]
+    shared = same_x and n > 1 and any(need_x) and all(w.shape[0] <= L.DENSE_DX_CHUNK and w.shape[1] == I0 for w in wc)
+    shared_buf = torch.empty(n, B, I0, dtype=torch.float32, device=dev) if shared else None
+    for i in range(n):
+        x, w = xc[i], wc[i]
+        O, I = w.shape
+        dy = dys[i]
+        if dy is None:
+            dy = torch.zeros(B, O, dtype=torch.float32, device=dev)
+        dy = L.f32c(dy).reshape(B, O)
+        dw = torch.empty(O, I, dtype=torch.float32, device=dev)
+        db = torch.empty(O, dtype=torch.float32, device=dev) if has_b[i] else None
+        dpre = torch.empty(B, O, dtype=torch.float32, device=dev)
+        nch = (O + L.DENSE_DX_CHUNK - 1) // L.DENSE_DX_CHUNK
+        if shared:
+            dxp = shared_buf[i]
+        elif need_x[i]:
+            dxp = torch.empty(nch, B, I, dtype=torch.float32, device=dev)
+        else:
+            dxp = None
+        descs.append(L.DenseBwdDesc(L.ptr(x), L.ptr(w), L.ptr(ys[i]), L.ptr(auxs[i]), L.ptr(dy), L.ptr(dpre), L.ptr(dw), L.ptr(db),
+                                    L.ptr(dxp), I, O, acts[i], 0))
+        keep.append((dy, dpre))
+        dws.append(dw); dbs.append(db); dxps.append(dxp); nchunks.append(nch)
+    for i0 in range(0, n, L.MAX_DENSE_GROUPS):
+        chunk = descs[i0:i0 + L.MAX_DENSE_GROUPS]
+        arr = (L.DenseBwdDesc * len(chunk))(*chunk)
+        L.check(lib.bnerv_dense_grouped_bwd(L.stream(), arr, len(chunk), B), "bnerv_dense_grouped_bwd")
+    dxs = [None] * n
+    if shared:
+        tot = torch.empty(B, I0, dtype=torch.float32, device=dev)
+        _reduce_slabs(shared_buf, n, B * I0, tot)
+        first = next(i for i in range(n) if need_x[i])
+        dxs[first] = tot               # the same tensor was passed n times: its whole gradient goes to one slot
+    else:
+        for i in range(n):
+            if dxps[i] is None:
+                continue
+            if nchunks[i] == 1:
+                dxs[i] = dxps[i][0]
+            else:
+                I = wc[i].shape[1]
+                tot = torch.empty(B, I, dtype=torch.float32, device=dev)
+                _reduce_slabs(dxps[i], nchunks[i], B * I, tot)
+                dxs[i] = tot
+    return dxs, dws, dbs
+
+
+class _TimeHead(torch.autograd.Function):
+    """PositionEncoding -> stem | stem_t -> every TAT modulation MLP as ONE forward launch (include/bnerv.h bnerv_time_head_fwd); the
+    backward is the unchanged grouped dense backward of the four layers depths."""
+
+    @staticmethod
+    def forward(ctx, pos, bases, n_mlp, *params):
+        lib = L.load()
+        dev = pos.device
+        B, Lv = pos.shape[0], bases.numel()
+        p2 = [L.f32c(t).reshape(t.shape[0], -1) if t.dim() > 1 else L.f32c(t) for t in params]
+        sw0, sb0, sw1, sb1, tw0, tb0, tw1, tb1 = p2[:8]
+        mw = p2[8:]
+        SH, SO, TH, TO = sw0.shape[0], sw1.shape[0], tw0.shape[0], tw1.shape[0]
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        pe, sy0, saux0, sy1, saux1 = f(B, 2 * Lv), f(B, SH), f(B, SH), f(B, SO), f(B, SO)
+        ty0, taux0, ty1, taux1 = f(B, TH), f(B, TH), f(B, TO), f(B, TO)
+        hs = [f(B, TO) for _ in range(n_mlp)]
+        outs = [f(B, mw[4 * i + 2].shape[0]) for i in range(n_mlp)]
+        d = L.TimeHeadDesc(L.ptr(pos), L.ptr(bases), L.ptr(pe), L.ptr(sw0), L.ptr(sb0), L.ptr(sw1), L.ptr(sb1), L.ptr(sy0), L.ptr(saux0), L.ptr(sy1), L.ptr(saux1),
+                           L.ptr(tw0), L.ptr(tb0), L.ptr(tw1), L.ptr(tb1), L.ptr(ty0), L.ptr(taux0), L.ptr(ty1), L.ptr(taux1), B, Lv, SH, SO, TH, TO, n_mlp,
+                           int(os.environ.get("BNERV_TH_DEBUG", "0")))
+        ml = (L.TimeHeadMlp * max(n_mlp, 1))()
+        for i in range(n_mlp):
+            w1, b1, w2, b2 = mw[4 * i:4 * i + 4]
+            ml[i].w1, ml[i].b1, ml[i].w2, ml[i].b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+            ml[i].hs, ml[i].out, ml[i].C = hs[i].data_ptr(), outs[i].data_ptr(), w2.shape[0]
+        L.check(lib.bnerv_time_head_fwd(L.stream(), C.byref(d), ml), "bnerv_time_head_fwd")
+        ctx.n_mlp, ctx.B = n_mlp, B
+        ctx.pshapes = [tuple(t.shape) for t in params]
+        ctx.save_for_backward(pe, sy0, saux0, sy1, saux1, ty0, taux0, ty1, taux1, *hs, *outs, *p2)
+        return (sy1, ty1, *outs)
+
+    @staticmethod
+    def backward(ctx, d_sy1, d_ty1, *d_outs):
+        if _lazy_depth > 0:
+            _flush_deferred()               # the modulation gradients are deferred slab reductions of the TAT blocks
+        n, B = ctx.n_mlp, ctx.B
+        sv = ctx.saved_tensors
+        pe, sy0, saux0, sy1, saux1, ty0, taux0, ty1, taux1 = sv[:9]
+        hs, outs, p2 = sv[9:9 + n], sv[9 + n:9 + 2 * n], sv[9 + 2 * n:]
+        sw0, sb0, sw1, sb1, tw0, tb0, tw1, tb1 = p2[:8]
+        mw = p2[8:]
+        none, relu, sin = L.ACT_NONE, L.ACT_RELU, L.ACT_SIN
+        g = [None] * len(p2)
+        d_zt = d_ty1
+        if n:
+            w1s, w2s = [mw[4 * i] for i in range(n)], [mw[4 * i + 2] for i in range(n)]
+            dx4, dw4, db4 = _dense_grouped_bwd([none] * n, hs, w2s, outs, [None] * n, d_outs, [True] * n, [True] * n, False, B)
+            dx3, dw3, db3 = _dense_grouped_bwd([relu] * n, [ty1] * n, w1s, hs, [None] * n, dx4, [True] * n, [True] * n, True, B)
+            tot = next(t for t in dx3 if t is not None)
+            d_zt = tot if d_ty1 is None else tot + L.f32c(d_ty1).reshape(tot.shape)
+            for i in range(n):
+                g[8 + 4 * i], g[8 + 4 * i + 1], g[8 + 4 * i + 2], g[8 + 4 * i + 3] = dw3[i], db3[i], dw4[i], db4[i]
+        dx2, dw2, db2 = _dense_grouped_bwd([sin, sin], [sy0, ty0], [sw1, tw1], [sy1, ty1], [saux1, taux1], [d_sy1, d_zt], [True, True], [True, True], False, B)
+        dx1, dw1, db1 = _dense_grouped_bwd([sin, sin], [pe, pe], [sw0, tw0], [sy0, ty0], [saux0, taux0], dx2, [False, False], [True, True], True, B)
+        g[0], g[1], g[2], g[3] = dw1[0], db1[0], dw2[0], db2[0]
+        g[4], g[5], g[6], g[7] = dw1[1], db1[1], dw2[1], db2[1]
+        g = [None if t is None else t.reshape(sh) for t, sh in zip(g, ctx.pshapes)]
+        return (None, None, None, *g)
+
+
+TIME_HEAD_MAX_B = 4
+
+
+def time_head(pos, bases, stem, stem_t, mlps):
+    """pos [B] fp64, bases fp32 [L]; stem / stem_t = (w0, b0, w1, b1) of the two 2-layer sin MLPs; mlps = [(w1, b1, w2, b2), ...] of the TAT
+    modulation branches (relu inside).  Returns (stem_out [B, SO], z_t [B, TO], [out_i [B, C_i]]).  None when the shapes are not the
+    one-launch kernel's (the caller runs the five grouped launches)."""
+    B, Lv = pos.shape[0], bases.numel()
+    # OPT-IN (BNERV_TIME_HEAD=1).  Measured on MI355X (DESIGN section 11): 14.4 us against 13.0 us for the five launches replayed on their
+    # own, and 1.508 against 1.494 ms per C1 step -- every stem block re-reads the 164 KB first stem matrix (44 MB through L2 instead of
+    # 164 KB) and the chain's four dependent memory round trips are as long inside one launch as across launch boundaries.
+    if os.environ.get("BNERV_TIME_HEAD", "0") != "1" or pos.dtype != torch.float64 or not pos.is_cuda:
+        return None
+    SH, TH, TO = stem[0].shape[0], stem_t[0].shape[0], stem_t[2].shape[0]
+    if B > TIME_HEAD_MAX_B or 2 * Lv > 256 or SH > 512 or TH > 64 or TO > 32 or len(mlps) > L.MAX_DENSE_GROUPS:
+        return None
+    if any(t is None for t in (*stem, *stem_t)) or any(t is None for m in mlps for t in m):
+        return None
+    flat = [t for m in mlps for t in m]
+    out = _TimeHead.apply(pos.contiguous(), bases.to(device=pos.device, dtype=torch.float32).contiguous(), len(mlps), *stem, *stem_t, *flat)
+    return out[0], out[1], list(out[2:])
 
 
 DENSE_GEMM_MIN_B = 16
