@@ -1128,6 +1128,31 @@ static int run_ms_forward(hipStream_t st, const float* X, const float* Y, float*
         BNERV_LAUNCH_CHECK("ms_coef");
         return BNERV_OK;
     }
+    {
+        // odd pyramid (1080 -> 540 -> 270 -> 135 -> 68: the 1080p configs): the padded 2x2 means level by level, then EVERY level's statistics in
+        // ONE launch (the levels only depend on the pyramid; the same body per tile as the level-by-level launches, so the same bits) and the
+        // coefficients: 6 launches instead of 10.  BNERV_LOSS_FUSED=0 keeps the level-by-level form.
+        const char* e = getenv("BNERV_LOSS_FUSED");
+        if (!(e && e[0] == '0')) {
+            PyrArgs pa{}; SsimAllArgs sa{}; CoefArgs ca{};
+            int rc = fill_even_forward(X, Y, ws, L, BC, chain, want_g, pa, sa, ca);
+            if (rc) return rc;
+            const float* Xl = X; const float* Yl = Y;
+            for (int l = 0; l < LV - 1; ++l) {
+                const int Hl = L.pyr.H[l], Wl = L.pyr.W[l], Ho = L.pyr.H[l + 1], Wo = L.pyr.W[l + 1];
+                const size_t n = (size_t)BC * Ho * Wo;
+                int gx = (int)((n + 255) / 256); if (gx > 4096) gx = 4096;
+                hipLaunchKernelGGL(avgpool2_kernel, dim3(gx, 1, 2), dim3(256), 0, st, Xl, Yl, ws + L.pyrX[l + 1], ws + L.pyrY[l + 1], BC, Hl, Wl, Ho, Wo, Hl % 2, Wl % 2);
+                BNERV_LAUNCH_CHECK("avgpool2");
+                Xl = ws + L.pyrX[l + 1]; Yl = ws + L.pyrY[l + 1];
+            }
+            hipLaunchKernelGGL(ssim_fwd_all_kernel, dim3(sa.first[LV], BC), dim3(256), 0, st, sa);
+            BNERV_LAUNCH_CHECK("ssim_fwd_all");
+            hipLaunchKernelGGL(ms_coef_kernel, dim3(BC), dim3(320), 0, st, ca);
+            BNERV_LAUNCH_CHECK("ms_coef");
+            return BNERV_OK;
+        }
+    }
     const float* Xl = X; const float* Yl = Y;
     CoefArgs ca{};
     static const float weights[LV] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};

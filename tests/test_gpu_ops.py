@@ -806,9 +806,11 @@ def test_wide_split_kernels_keep_the_f32_contract():
     assert r3.returncode == 1 and "OUTSIDE" in r3.stdout, r3.stdout[-3000:] + r3.stderr[-2000:]
 
 
-@pytest.mark.parametrize("shape", [(1, 3, 720, 1280), (2, 3, 176, 208), (1, 1, 192, 352)])
+@pytest.mark.parametrize("shape", [(1, 3, 720, 1280), (2, 3, 176, 208), (1, 1, 192, 352), (1, 3, 1080, 1920), (2, 3, 180, 270)])
 def test_fused_msssim_launches_equal_the_level_by_level_form(ops, shape, monkeypatch):
-    """Frames whose pyramid has even sides take the fused MS-SSIM launches (one pyramid kernel, one statistics launch for all five
+    """(The last two shapes have ODD pyramid levels -- 1080 -> ... -> 135 -> 68, and odd from level 0: there only the statistics of the five
+    levels share one launch (round 4), the padded 2x2 means and the gradient chain stay level by level.)
+    Frames whose pyramid has even sides take the fused MS-SSIM launches (one pyramid kernel, one statistics launch for all five
     levels, the coarser levels' gradients in one launch and their 0.25-chain evaluated inside the level-0 launch: 5 launches instead of
     15).  Same formulas on the same data; the compiler contracts a few multiply-adds differently in the two forms, so the comparison
     with the level-by-level form (BNERV_LOSS_FUSED=0) allows rounding: values to 4 ulp, the gradient to 3e-5 of its largest entry."""
