@@ -96,7 +96,7 @@ def _time_launches(fn, reps):
     try:
         side, ctx, g = torch.cuda.Stream(), L.new_ctx(), torch.cuda.CUDAGraph()
         with L.use_ctx(ctx):
-            with torch.cuda.graph(g, stream=side):
+            with L.graph_capture(g, stream=side):
                 for _ in range(reps):
                     fn()
                 ops._flush_deferred()

@@ -226,6 +226,48 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def graph_capture(graph, **kw):
+    """torch.cuda.graph(graph, ...) with the capture in THREAD-LOCAL error mode, after quiesce_collectives().
+
+    torch.distributed's ProcessGroupNCCL keeps a watchdog thread that polls the end event of every EAGER collective with
+    hipEventQuery until it has seen it complete (every 100 ms; torch.cuda.synchronize() does not retire the work item, the next poll
+    does).  Two HIP rules turn that poll into a process abort (the watchdog rethrows on its own thread -> std::terminate -> SIGABRT;
+    this was the round-4 abort of the GPU suite, DESIGN section 12.1, reproduced at will by tools/repro_watchdog_capture.py):
+      (1) while ANY thread captures in torch's default GLOBAL mode, hipEventQuery from another thread on an event recorded on a
+          non-default stream fails with hipErrorStreamCaptureUnsupported; in thread-local mode only the capturing thread is policed.
+          This package's captures issue kernel launches, event record / wait edges and async copies on streams of their own -- the
+          cross-thread policing protects nothing here, so every capture of the package goes through this helper;
+      (2) in ANY mode, querying an event whose last record was on a stream that is capturing NOW fails (hipErrorCapturedEvent): a stream
+          that hosted an eager collective must never be captured while that collective's work item may be alive -- dp.GradBucket keeps
+          separate side streams for its eager and its captured exchange for this reason."""
+    kw.setdefault("capture_error_mode", "thread_local")
+    quiesce_collectives()
+    return torch.cuda.graph(graph, **kw)
+
+
+_WATCHDOG_POLL_S = 0.1      # ProcessGroupNCCL's kWatchdogThreadSleepMillis
+
+
+def quiesce_collectives():
+    """Before a stream capture in a process that has an NCCL(=RCCL) process group: let the watchdog retire every eager work item.
+    There is no API that waits for the watchdog; after a device synchronisation every work item is complete, and two and a half poll
+    periods later the watchdog has seen that.  Belt to graph_capture's braces (either alone survives the reproducer); costs 0.25 s per
+    capture, nothing per step, nothing at all without a process group."""
+    import time
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    try:
+        if "nccl" not in str(dist.get_backend()):
+            return
+    except Exception:       # noqa: BLE001
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    torch.cuda.synchronize()
+    time.sleep(2.5 * _WATCHDOG_POLL_S)
+
+
 def f32c(t):
     """contiguous fp32 view/copy (plumbing: kernels require dense NCHW fp32)."""
     if t.dtype != torch.float32:

@@ -42,7 +42,13 @@ class GradBucket:
         p0 = self.params[0]
         self.bucket = torch.zeros(off, dtype=torch.float32, device=p0.device)
         self._chunks, self._key = {}, {}
+        # two side streams: torch runs a synchronous collective on the CURRENT stream and records its end event there, and the process
+        # group's watchdog thread keeps querying that event for up to 100 ms after the collective has finished.  HIP refuses the query
+        # of an event whose last record was on a stream that is capturing now (the watchdog then aborts the process), so the stream
+        # of the eager exchange (warm-up steps) is never the one a capture forks onto (_lib.graph_capture)
         self._side = torch.cuda.Stream(device=p0.device) if (self.two and p0.is_cuda) else None
+        self._side_cap = torch.cuda.Stream(device=p0.device) if (self.two and p0.is_cuda) else None
+        self._side_used = None
         self._early_inflight = False
         self._work = None
 
@@ -119,9 +125,11 @@ class GradBucket:
         self._gather("early")
         seg = self.bucket[:self.split]
         if self._side is not None:
-            self._side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._side):
+            side = self._side_cap if torch.cuda.is_current_stream_capturing() else self._side
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
                 dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
+            self._side_used = side
         else:
             self._work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._early_inflight = True
@@ -135,8 +143,9 @@ class GradBucket:
         self._ensure_grads("late")
         self._gather("late")
         dist.all_reduce(self.bucket[self.split:], op=dist.ReduceOp.SUM, group=self.group)
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+        if self._side_used is not None:
+            torch.cuda.current_stream().wait_stream(self._side_used)
+            self._side_used = None
         elif self._work is not None:
             self._work.wait()
             self._work = None

@@ -213,12 +213,13 @@ class TrainStep:
     def _capture_in_ctx(self, pool):
         import os
         import torch.distributed as dist
+        from . import _lib as L
         self._early_ok = False
         self._record_wplan()
         self._early_ok = True
         cap = dict(pool=pool, stream=self._cap_stream)
         if self.bucket is None:
-            with torch.cuda.graph(self.graph_a, **cap):
+            with L.graph_capture(self.graph_a, **cap):
                 self._planned_fwd_bwd()
                 self.opt.launch_step()
             return
@@ -236,7 +237,7 @@ class TrainStep:
         backend = dist.get_backend(self.bucket.group) if dist.is_initialized() else ""
         if backend == "nccl" and os.environ.get("BNERV_DP_INGRAPH", "1") != "0":
             try:
-                with torch.cuda.graph(self.graph_a, **cap):
+                with L.graph_capture(self.graph_a, **cap):
                     self._planned_fwd_bwd()                   # (two buckets: the hook starts the early segment's all-reduce in here)
                     self.bucket.finish()                      # gather -> all-reduce -> [join] -> scatter
                     self.opt.launch_step()
@@ -250,10 +251,11 @@ class TrainStep:
         self.collective_in_graph = False
         self._early_ok = False                              # graph A cannot hold a collective: one exchange between the two graphs
         self.bucket._early_inflight = False
-        with torch.cuda.graph(self.graph_a, **cap):
+        self.bucket._side_used = None
+        with L.graph_capture(self.graph_a, **cap):
             head()
         self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b, **cap):
+        with L.graph_capture(self.graph_b, **cap):
             tail()
 
     # ---- one step ------------------------------------------------------------------------------------------------------
@@ -388,7 +390,7 @@ class DecodeGraph:
                 L.check(lib.bnerv_ctx_wplan_run(c.handle, L.stream()), "bnerv_ctx_wplan_run")
                 try:
                     self.graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.graph, stream=side):
+                    with L.graph_capture(self.graph, stream=side):
                         self.out = model(self.inp, self.embed, norm_idx=self.norm)[0]
                 finally:
                     lib.bnerv_ctx_wplan_end(c.handle)
