@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- train frames/sec of the Boosting-NeRV conditional-decoder path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W                       (1 GPU)
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (N GPUs, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W       (N = 1: in this process; N > 1: re-launches itself, one rank per GPU)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (the driver's N > 1 form)
 
 A "step" is one pass of the hot path over one batch: forward of the decoder, Fusion10_freq loss, backward, [one flat-bucket
 RCCL all-reduce when N > 1], fused Adan -- exactly train_nerv_all.py:328-348 of the reference -- on frames already resident
@@ -166,21 +166,14 @@ def step_kernel_roofline(dev, Cc, H, W, reps=20):
             dict(x=x, g=dout, dw=dw, db=db, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=1, **kw),
             dict(x=dout, w=w, bias=None, out=out, in_mode=L.IN_PLAIN, ep_mode=L.EP_PLAIN, transposed=1, **kw))),
     ]
-    # round 4: where the library takes the whole TAT block forward as one launch (include/bnerv.h bnerv_tat_block_fwd: the 12-channel
-    # stages), THAT launch is what the step runs instead of K2s + K3s -- probe it the way ops._tat_forward does and swap the rows
-    import ctypes as _C
-    _td = L.TatDesc(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(w), L.ptr(b), L.ptr(sc), L.ptr(sh), L.ptr(sc), L.ptr(sh), L.ptr(h), L.ptr(gp), L.ptr(out), B, Cc, H, W, L.ctx().handle)
-    if L.load().bnerv_tat_block_fwd(L.stream(), _C.byref(_td)) == 0:
-        cases = [("TAT block fwd, ONE launch: affine->conv0->bias->gelu,gelu'->affine->conv1->bias->+x0", 2, 4,
-                  lambda: ops._tat_forward(x, sc, sh, sc, sh, w, b, w, b, True))] + cases[2:]
     flops1 = 2.0 * Cc * Cc * 9 * H * W
     rows, tf, tt, nl = [], 0.0, 0.0, 0
     troof = 0.0
-    keys = {"K2s": "k2s", "K3s": "k3s", "K1": "k1", "wA|dK3s": "pair_dk3s", "wA|dK2s": "pair_dk2s", "wP|dK1": "pair_dk1", "TAT": "tat_fwd"}
+    keys = {"K2s": "k2s", "K3s": "k3s", "K1": "k1", "wA|dK3s": "pair_dk3s", "wA|dK2s": "pair_dk2s", "wP|dK1": "pair_dk1"}
     for name, n, planes, fn in cases:
         t = _time_launches(fn, reps)       # (slab reductions are deferred exactly as in the step: they ride on the following launch)
         ops._flush_deferred()
-        nconv = 2 if ("pair" in name or name.startswith("TAT")) else 1      # a pair / a fused block is two convolutions
+        nconv = 2 if "pair" in name else 1      # a pair is two convolutions
         flops = flops1 * nconv
         ach = flops / t / 1e12
         nbytes = planes * plane + nconv * wb
@@ -443,9 +436,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch ourselves one rank per GPU (what the reference does with mp.spawn from one command,
+        # train_nerv_all.py:139-148) -- the same torch.distributed.run line the driver uses, on a free local port
+        import socket
+        share_ = os.environ.get("BNERV_BENCH_SHARE_GPU", "0") == "1"
+        if not share_ and torch.cuda.device_count() < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if world != a.gpus:
-        if a.gpus > 1 and world == 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`")
+        raise SystemExit(f"bench.py --gpus {a.gpus} started with WORLD_SIZE={world}: launch one rank per GPU (or run plain `python bench.py --gpus N`)")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
     # Test hook (never set by the driver): BNERV_BENCH_SHARE_GPU=1 runs all ranks of an N > 1 launch on device 0 over gloo, so the
     # multi-GPU code path of this script can be smoke-tested on a 1-GPU box.  The numbers of such a run mean nothing.
@@ -558,14 +565,33 @@ def main():
         dp_diag = {"allreduce_us": round(ar.item(), 1), "allreduce_bytes": n_params * 4,
                    "allreduce_what": "one all_reduce(SUM) of a bucket-size fp32 tensor on this process group, mean of 20 back-to-back calls after 3 warm-ups, host-synchronised, max over ranks"}
         pinned = os.environ.get("BNERV_DP_BUCKETS")
+
+        def restore_fresh():
+            """The probes train for real (2 x 26 steps): put parameters and Adan state back to the seeded initial state IN PLACE (the
+            captured graphs keep their addresses), so the warm-up and the timed steps -- and the eval PSNR / loss quoted after them --
+            start from random init exactly as the N = 1 line does (step count 0: the next step is Adan's first again)."""
+            with torch.no_grad():
+                for p_, p0_ in zip(model.parameters(), params0):
+                    p_.copy_(p0_)
+                for st_ in opt.state.values():
+                    for v_ in st_.values():
+                        if torch.is_tensor(v_):
+                            v_.zero_()
+            for g_ in opt.param_groups:
+                g_["step"] = 0
+
         if pinned is None and hasattr(model, "dp_late_parameters"):
+            params0 = [p_.detach().clone() for p_ in model.parameters()]
             probe_ms = {"1": probe(step)}
+            restore_fresh()
             model.dp_hook = None
             step2 = TrainStep(model, opt, args.loss, takes_image, (per_gpu_batch, 3, r["h"], r["w"]), dev, use_graph=not a.no_graph,
                               warmup_eager=3, world_size=world, force_bucket=force_bucket, dp_buckets=2)
             if by_index:
                 step2.bind_clip(frames, norm)
             probe_ms["2"] = probe(step2)
+            restore_fresh()
+            del params0
             if probe_ms["2"] < probe_ms["1"]:
                 step = step2
             else:

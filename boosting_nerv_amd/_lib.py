@@ -39,22 +39,6 @@ class ConvDesc(C.Structure):
                 ("transposed", C.c_int), ("wCo", C.c_int), ("wCi", C.c_int), ("ctx", _fp)]
 
 
-class TatDesc(C.Structure):
-    _fields_ = [("x0", _fp), ("w0", _fp), ("b0", _fp), ("w1", _fp), ("b1", _fp), ("scale0", _fp), ("shift0", _fp), ("scale1", _fp), ("shift1", _fp),
-                ("h", _fp), ("gp", _fp), ("out", _fp), ("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("ctx", _fp)]
-
-
-class TimeHeadMlp(C.Structure):
-    _fields_ = [("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("hs", _fp), ("out", _fp), ("C", C.c_int), ("_pad", C.c_int)]
-
-
-class TimeHeadDesc(C.Structure):
-    _fields_ = [("pos", _fp), ("bases", _fp), ("pe", _fp), ("sw0", _fp), ("sb0", _fp), ("sw1", _fp), ("sb1", _fp),
-                ("sy0", _fp), ("saux0", _fp), ("sy1", _fp), ("saux1", _fp), ("tw0", _fp), ("tb0", _fp), ("tw1", _fp), ("tb1", _fp),
-                ("ty0", _fp), ("taux0", _fp), ("ty1", _fp), ("taux1", _fp),
-                ("B", C.c_int), ("L", C.c_int), ("SH", C.c_int), ("SO", C.c_int), ("TH", C.c_int), ("TO", C.c_int), ("n_mlp", C.c_int), ("_pad", C.c_int)]
-
-
 class WgradDesc(C.Structure):
     _fields_ = [("x", _fp), ("g", _fp), ("gaux", _fp), ("scale", _fp), ("shift", _fp), ("dw", _fp), ("db", _fp),
                 ("ws", _fp), ("ws_bytes", C.c_size_t),
@@ -120,7 +104,6 @@ SYMBOLS = {
     "bnerv_pe_fwd_f32_from_f64": (_I, [_V, _V, _V, _V, _I, _I]),
     "bnerv_dense_grouped_fwd": (_I, [_V, C.POINTER(DenseFwdDesc), _I, _I]),
     "bnerv_dense_grouped_bwd": (_I, [_V, C.POINTER(DenseBwdDesc), _I, _I]),
-    "bnerv_time_head_fwd": (_I, [_V, C.POINTER(TimeHeadDesc), C.POINTER(TimeHeadMlp)]),
     "bnerv_sft_affine_fwd": (_I, [_V, _V, _V, _V, _V, _I, _I, _I]),
     "bnerv_sft_affine_bwd": (_I, [_V, _V, _V, _V, _V, _V, _I, _I, _I]),
     "bnerv_reduce_slabs": (_I, [_V, _V, _I, _I, _V]),
@@ -140,7 +123,6 @@ SYMBOLS = {
     "bnerv_conv_igemm": (_I, [_V, C.POINTER(ConvDesc)]),
     "bnerv_conv_splitk_ws_bytes": (_Z, [C.POINTER(ConvDesc)]),
     "bnerv_conv_partial_rows": (_I, [C.POINTER(ConvDesc)]),
-    "bnerv_tat_block_fwd": (_I, [_V, C.POINTER(TatDesc)]),
     "bnerv_conv_wgrad_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bnerv_conv_wgrad_pair": (_I, [_V, C.POINTER(ConvDesc), C.POINTER(WgradDesc)]),
     "bnerv_conv_wgrad": (_I, [_V, C.POINTER(WgradDesc)]),
@@ -178,7 +160,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class BnervError(RuntimeError):

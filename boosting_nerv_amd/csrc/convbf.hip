@@ -680,13 +680,9 @@ struct WItem { int g, b, ty, tx, sp; };
 // PS2 = 2: the output goes through PixelShuffle(2) (conv channel 4c + 2i + j at (y, x) -> out[c][2y + i][2x + j]; the up-convs) with
 // paired 16-B stores; PS2 = 3: PixelShuffle(s), s = out_s in {3, 5}, with four 4-B stores s columns apart per accumulator quad.
 // IN_UNSHUFFLE: the input is read through the inverse map from the shuffled tensor (data gradient of an up-conv; in_s == 2).
-// PIPE (round 4): the software-pipelined form.  ONE block per CU (one wave per SIMD, the whole register file), both LDS images
-// double-buffered: the B fragments of stage s + 1 enter their second buffer by LDS-DMA (buffer_load ... lds: no registers, no ds_write)
-// issued at the top of stage s, the input chunk of stage s + 1 is loaded into registers there as well and transformed / split / written to
-// the second A buffer in four slices placed INSIDE the second half of stage s's MFMA phases -- one instruction stream in which the 16-bit
-// MFMAs (16 cycles each) cover the staging instructions, one barrier per stage instead of two.  The two-blocks-per-CU form above it
-// serialises those phases (matrix pipe 52 % busy).
-template <int IN, int EP, int SP, int NTB, int PS2, bool PIPE = false>
+// (A software-pipelined one-block-per-CU form of this kernel was built and measured slower in round 4 -- DESIGN section 11.1,
+// profiles/r04_bfw_pipe_trace.md -- and retired in round 5; git history has it.)
+template <int IN, int EP, int SP, int NTB, int PS2>
 __device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __restrict__ wfrag, const int ngroups, const SidePack& side, const int vb, const int vgrid) {
     // (vb of vgrid: this launch's block index / size, or the conv role of a paired launch)
     constexpr int KS = 3;
@@ -702,15 +698,12 @@ __device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __re
     constexpr int NWB = (SB_SLOTS + 255) / 256;
     const bnerv_conv_desc& d = ka.d;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NBUF = PIPE ? 2 : 1;
     constexpr int A_BYTES = NS * BG::PIECE, B_BYTES = SB_SLOTS * 16;
-    char* s_a = reinterpret_cast<char*>(smem);             // [NBUF][NS pieces][PIECE]
-    char* s_b = s_a + NBUF * A_BYTES;                      // [NBUF][SB_SLOTS] 16-B fragment slots
-    float* s_red = reinterpret_cast<float*>(s_b + NBUF * B_BYTES);  // [4 waves][2][NTB * 16]
+    char* s_a = reinterpret_cast<char*>(smem);             // [NS pieces][PIECE]
+    char* s_b = s_a + A_BYTES;                             // [SB_SLOTS] 16-B fragment slots
+    float* s_red = reinterpret_cast<float*>(s_b + B_BYTES);  // [4 waves][2][NTB * 16]
     float* s_aff = s_red + 4 * 2 * NTB * 16;                       // [2][aff_n]
     const int aff_n = (ka.d.Cin + 15) & ~15;
-    // (pipelined form) 3 x 16 bytes behind the affine table (or the reduction area): where masked-off staging stores go
-    const unsigned dummy_off = (unsigned)(reinterpret_cast<char*>(s_aff + (AFF ? 2 * aff_n : 0)) - s_a);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -724,7 +717,7 @@ __device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __re
     const int per = ka.total_items >> 3, extra = ka.total_items & 7;
     const int r0 = xcd * per + min(xcd, extra), r1 = r0 + per + (xcd < extra ? 1 : 0);
     int itx = r0 + lb;
-    for (int i = tid; i < NBUF * A_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(s_a)[i] = u32x4{0u, 0u, 0u, 0u};   // no NaN patterns beside zero weights
+    for (int i = tid; i < A_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(s_a)[i] = u32x4{0u, 0u, 0u, 0u};   // no NaN patterns beside zero weights
     if (itx >= r1) { side_run_hosted(side, smem, vb, vgrid); return; }
     auto decode = [&](int i) __attribute__((always_inline)) {     // item order: tile fastest, then sample, then cout group
         WItem w;
@@ -833,33 +826,6 @@ __device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __re
             }
         }
     };
-    // pipelined form: the same slice as straight-line code (it has to live in ONE basic block with the phase's MFMAs to be interleaved with
-    // them): a thread whose slot is not written (column outside the tile's 34, a channel half the chunk does not have) stores to three
-    // dummy slots behind the affine table instead of branching around the stores
-    unsigned pw_dst[4], pw_step[4];
-    auto commit_begin_pipe = [&](const WItem& a, int c, int buf_n) __attribute__((always_inline)) {
-        commit_begin(a, c);
-        const unsigned sa_off = (unsigned)(buf_n * A_BYTES);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = w_ok[j] && ra_valid > 0;
-            pw_dst[j] = ok ? sa_off + (unsigned)w_addr[j] : dummy_off;
-            pw_step[j] = ok ? (unsigned)BG::PIECE : 16u;
-        }
-    };
-    auto commit_pixel_pipe = [&](int j) __attribute__((always_inline)) {
-        float xs[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = ra[e][j];
-            if constexpr (IN != BNERV_IN_PLAIN && !UNSH) v = xform1<IN>(v, aff_sc[e], aff_sh[e], 0.f);
-            xs[e] = v;
-        }
-        u32x4 pc[NS];
-        split8<SP, 8>(xs, pc);
-#pragma unroll
-        for (int p = 0; p < NS; ++p) *reinterpret_cast<u32x4*>(s_a + pw_dst[j] + (unsigned)p * pw_step[j]) = pc[p];
-    };
     auto commit_pixel = [&](int j, char* sa) __attribute__((always_inline)) {
         if (ra_valid > 0) {                                // (a half without channels in this chunk keeps its stale slots: zero weights)
             float xs[8];
@@ -893,34 +859,11 @@ __device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __re
             if (i < SB_SLOTS) reinterpret_cast<u32x4*>(sb)[i] = rb[k];
         }
     };
-    // pipelined form: the same fragments by LDS-DMA (16 bytes per lane, LDS address = m0 + 16 * lane), waited for with vmcnt before the
-    // barrier that opens the stage which reads them.  SB_SLOTS is a multiple of 64, so the last pass is whole waves.
-    static_assert(SB_SLOTS % 64 == 0, "the B image is whole waves of 16-byte slots");
-    i32x4 rwf;
-    if constexpr (PIPE) {
-        const uintptr_t base = reinterpret_cast<uintptr_t>(wfrag);
-        rwf[0] = (int)(unsigned)(base & 0xffffffffu);
-        rwf[1] = (int)(unsigned)((base >> 32) & 0xffffu);
-        rwf[2] = (int)((unsigned)ngroups * (unsigned)nck * (unsigned)B_BYTES);
-        rwf[3] = 0x00020000;
-    }
-    auto dma_b = [&](const WItem& a, int c, int buf) __attribute__((always_inline)) {
-        if constexpr (PIPE) {
-            const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)s_b + (unsigned)buf * (unsigned)B_BYTES + (unsigned)wave * 1024u;
-            const unsigned sbase = (unsigned)(a.g * nck + c) * (unsigned)B_BYTES;
-#pragma unroll
-            for (int k = 0; k < NWB; ++k) {
-                if (k * 256 + wave * 64 < SB_SLOTS)        // (wave-uniform)
-                    asm volatile("s_mov_b32 m0, %3\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"((unsigned)tid * 16u), "s"(rwf), "s"(sbase + (unsigned)k * 4096u),
-                                 "s"(lbase + (unsigned)k * 4096u) : "memory", "m0");
-            }
-        }
-    };
-    auto commit = [&](const WItem& a, int c) __attribute__((always_inline)) {          // the whole stage at once (two-block form; the pipelined form's first stage)
+    auto commit = [&](const WItem& a, int c) __attribute__((always_inline)) {          // the whole stage at once
         commit_begin(a, c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) commit_pixel(j, s_a);
-        if constexpr (!PIPE) copy_b(a, c, s_b);
+        copy_b(a, c, s_b);
     };
     auto load_affine = [&](int b) __attribute__((always_inline)) {                 // s_aff[c] = 1 + scale[b][c], s_aff[aff_n + c] = shift[b][c]
         for (int i = tid; i < 2 * aff_n; i += 256) {
@@ -962,14 +905,13 @@ __device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __re
     // K chunks of an item: all of them, or -- split-K, EP_PLAIN -- the item's `cps` chunks from sp * cps on
     auto c_first = [&](const WItem& a) __attribute__((always_inline)) { return a.sp * ka.cps; };
     auto c_stop = [&](const WItem& a) __attribute__((always_inline)) { return min(nck, a.sp * ka.cps + ka.cps); };
-    if constexpr (PIPE) dma_b(it, c_first(it), 0);
+    
     issue(it, c_first(it));
     lds_barrier();                                         // zeroed s_a and the affine table visible
     commit(it, c_first(it));
-    if constexpr (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first stage's B fragments have landed
+          // the first stage's B fragments have landed
     WItem prev = it;
     bool have_prev = false;
-    int cur = 0;                                           // pipelined form: the LDS buffer pair of the current stage
     int trace_stage = 0; (void)trace_stage;
     while (itx < r1) {
         f32x4 acc[4][NTB];
@@ -987,17 +929,9 @@ __device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __re
             WTR(0);
             lds_barrier();                                 // (A) this stage's s_a / s_b (and s_red of the previous item) visible
             WTR(1);
-            const char* sa_cur = s_a + cur * A_BYTES;
-            const char* sb_cur = s_b + cur * B_BYTES;
-            char* sa_nxt = s_a + (cur ^ 1) * A_BYTES;       // (pipelined form) last read in the stage before this one: every wave is past it
-            if constexpr (PIPE) {
-                if (more) {
-                    if constexpr (AFF) {                   // the next item's sample: its table replaces this one's, whose staging is complete
-                        if (last_chunk && nxt.b != aff_b) { load_affine(nxt.b); lds_barrier(); aff_b = nxt.b; }
-                    }
-                    dma_b(last_chunk ? nxt : it, last_chunk ? c_nxt : c + 1, cur ^ 1);
-                }
-            }
+            const char* sa_cur = s_a;
+            const char* sb_cur = s_b;
+            
             if (more) issue(last_chunk ? nxt : it, last_chunk ? c_nxt : c + 1);
             if constexpr (RED) { if (c == c_lo && have_prev) flush_partials(prev); }
             WTR(2);
@@ -1021,10 +955,7 @@ __device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __re
 #pragma unroll
                     for (int n = 0; n < NTB; ++n) bfr[n][p] = *reinterpret_cast<const u32x4*>(sb_cur + ((n * BG::STEPS + s) * NS + p) * 1024 + b_addr);
                 };
-                // (pipelined form: with `staging` the next stage's input slices ride in the second half of the phases -- a compile-time
-                // variant of the loop, so that a phase and its slice are ONE basic block)
-                auto phases = [&](auto staging) __attribute__((always_inline)) {
-                constexpr bool STG = decltype(staging)::value;
+                {
 #pragma unroll
                 for (int p = NS - 1; p >= 0; --p) load_b(0, p);
                 load_a(0, 0);
@@ -1048,43 +979,12 @@ __device__ __forceinline__ void conv_bfw_body(const KArgs& ka, const u32x4* __re
                     BNERV_BF_PROD(0, 0)
 #undef BNERV_BF_PROD
                     if (reload) load_b(s + 1, 0);
-                    if constexpr (STG) {
-                        // the next stage's input: one pixel slice per phase (its loads were issued at the top of the stage: four phases =
-                        // ~2.3 k cycles before the first slice).  The scheduler would put the slice BEHIND the stretch's MFMAs (seen in the
-                        // ISA), where an in-order wave runs it with the matrix pipe idle: one MFMA, then up to three vector instructions,
-                        // and so on; the table reads of the first slice in front, the three LDS writes last.
-                        // Slices ride in the phases whose products are ONE scheduling stretch (the even phases and the last one: the odd
-                        // phases in between are cut into three by their B reloads): phases 4, 6, 8, 9 of the ten.
-                        static_assert(BG::STEPS == 5, "slice phases are written for five K steps");
-                        const int sl = ph == 4 ? 0 : ph == 6 ? 1 : ph == 8 ? 2 : ph == 9 ? 3 : -1;
-                        if (sl >= 0) {
-                            if (sl == 0) commit_begin_pipe(last_chunk ? nxt : it, last_chunk ? c_nxt : c + 1, cur ^ 1);
-                            commit_pixel_pipe(sl);
-                            constexpr int NM = 6 * 2 * NTB;    // (an odd phase's last stretch holds half of them: the surplus groups stay empty)
-                            if constexpr (IN != BNERV_IN_PLAIN && !UNSH) { if (sl == 0) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0); }
-#pragma unroll
-                            for (int i = 0; i < NM; ++i) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                            }
-                            __builtin_amdgcn_sched_group_barrier(0x200, NS, 0);
-                        }
-                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                };
-                if constexpr (PIPE) {
-                    if (more) phases(std::true_type{});
-                    else phases(std::false_type{});
-                } else {
-                    phases(std::false_type{});
                 }
             }
             WTR(3);
-            if constexpr (PIPE) {
-                if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next stage's B fragments have landed (the barrier (A) publishes them)
-                cur ^= 1;
-            } else {
+            {
                 lds_barrier();                             // (B) every wave is done reading this stage
                 if (more) {
                     if constexpr (AFF) {
@@ -1228,11 +1128,6 @@ __global__ __launch_bounds__(256, 2) void conv_bfw_kernel(const KArgs ka, const 
     conv_bfw_body<IN, EP, SP, NTB, PS2>(ka, wfrag, ngroups, side, (int)blockIdx.x, (int)gridDim.x);
 }
 
-template <int IN, int EP, int SP, int NTB, int PS2>
-__global__ __launch_bounds__(256, 1) void conv_bfp_kernel(const KArgs ka, const u32x4* __restrict__ wfrag, const int ngroups, const SidePack side) {
-    conv_bfw_body<IN, EP, SP, NTB, PS2, true>(ka, wfrag, ngroups, side, (int)blockIdx.x, (int)gridDim.x);
-}
-
 constexpr size_t LEAN_MAX_BYTES = 0x7ff00000;            // every tensor view must stay below the OOB marker offset
 
 template <int KS, int IN, int EP, int SP>
@@ -1319,30 +1214,6 @@ int launch_bfw(hipStream_t st, KArgs& ka) {
     ka.magic_tiles = div_magic(ka.tiles_x * ka.tiles_y);
     ka.magic_tiles_x = div_magic(ka.tiles_x);
     const size_t lds = (size_t)NS * BG::PIECE + (size_t)NTB * BG::STEPS * NS * 1024 + (size_t)(4 * 2 * NTB * 16 + ((IN == BNERV_IN_AFFINE || IN == BNERV_IN_GELU_AFFINE) ? 2 * ((d.Cin + 15) & ~15) : 0)) * sizeof(float);   // (affine table only where there is an affine prologue)
-    if constexpr (NTB >= 2 && SP == SP_BF16X6) {
-        // the software-pipelined form (one block per CU, both LDS images double-buffered): layers that give every CU a long chain of stages
-        // OPT-IN (BNERV_BFW_PIPE=N: from N work items on).  Measured on MI355X (profiles/r04_bfw_pipe_trace.md): 38 -> 38 @1080x1920 K2s
-        // 719 us against 648 us for the two-blocks-per-CU form -- a lone wave per SIMD pays ~150 cycles of issue per LDS-DMA instruction
-        // (2.1 k cycles per stage), its staging slices are not hidden by the 16-bit MFMAs it is interleaved with (8.5 k cycles per stage of
-        // 360 MFMAs against 6.5 k for the same phases with a co-resident block), and its epilogue (7.5 k cycles per item) overlaps nothing.
-        int pipe_min = 0x7fffffff;                         // work items
-        if (const char* e = getenv("BNERV_BFW_PIPE")) pipe_min = atoi(e) > 0 ? atoi(e) : 0x7fffffff;       // unset / 0 / negative: off; N: from N items on
-        const size_t lds_p = lds + (size_t)NS * BG::PIECE + (size_t)NTB * BG::STEPS * NS * 1024;
-        if (ka.total_items >= pipe_min && lds_p <= 160 * 1024) {
-            static size_t attr_p = 0;
-            if (lds_p > attr_p) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bfp_kernel<IN, EP, SP, NTB, PS2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
-                attr_p = lds_p;
-            }
-            int grid = 256;
-            if (grid > ka.total_items) grid = ka.total_items;
-            SidePack side;
-            bnerv_side_take(d.ctx, &side, 2 * grid);
-            hipLaunchKernelGGL((conv_bfp_kernel<IN, EP, SP, NTB, PS2>), dim3(grid), dim3(256), lds_p, st, ka, reinterpret_cast<const u32x4*>(scratch), ngroups, side);
-            BNERV_LAUNCH_CHECK("conv_bfp");
-            return BNERV_OK;
-        }
-    }
     // LDS depends on the layer through the affine table (2 x Cin floats): occupancy is looked up per distinct size
     static size_t attr_lds = 0, occ_lds = 0;
     static int blocks_per_cu = 0;

@@ -247,189 +247,6 @@ extern "C" int bnerv_pe_fwd_f64(void* stream, const double* pos, const float* ba
     return BNERV_OK;
 }
 
-// ---------------------------------------------------------------- the time-embedding head as ONE launch (round 4)
-// PE -> stem (I -> H -> O, sin) | stem_t (I -> TH -> TO, sin) -> every TAT modulation MLP (TO -> TO relu -> C_i) used to be a chain of
-// five dependent launches of ~4.5 us each (model_nerv.py:47-51, model_blocks.py:92-105), all of them GEMVs of a few thousand MACs except
-// the stem's second layer (4.4 MB of weights).  Here every block recomputes the tiny front of its chain redundantly from L2-resident
-// weights instead of waiting for another launch:
-//   stem blocks   PE (I values) -> stem layer 0 (thread per row, H x I) in LDS -> their slice of stem layer 1 (wave per row: coalesced
-//                 1 KB rows, the launch's only real traffic); block 0 also writes PE and layer 0's output / cosine for the backward;
-//   SFT blocks    PE -> stem_t layer 0 -> layer 1 (z_t) in LDS -> eight modulation MLPs at a time (32 threads each: thread per row);
-//                 SFT block 0 also writes stem_t's outputs.
-// Every tensor the five-launch form left behind is written, bit patterns aside (a row is one sequential fma chain here, a strided wave
-// sum there), so the backward (bnerv_dense_grouped_bwd x 4) is unchanged.
-struct THMlp { const float* w1; const float* b1; const float* w2; const float* b2; float* hs; float* out; int C; int _pad; };
-struct THArgs {
-    bnerv_time_head_desc d;
-    THMlp m[BNERV_MAX_DENSE_GROUPS];
-    int nb_stem, nb_sft, rows_per_block;
-};
-constexpr int TH_MAXB = 4, TH_MAXI = 256, TH_MAXH = 512, TH_MAXT = 64;
-constexpr int TH_NT = 1024;          // threads per block: the chains are latency-bound GEMVs -- 16 waves per block keep the L2 round trips overlapped
-
-// pre[b][r] = bias[r] + sum_i W[r][i] x[b][i] for r < R, 16 lanes per row (a row is read as coalesced 64-byte segments: the weights of
-// the layers in front of the modulation MLPs come from L2 in every block, so the access pattern has to be the cheap one).  A wave's
-// critical path is its number of DEPENDENT memory round trips, so every load of a thread is issued before the first use: fixed-bound,
-// fully unrolled loops with guards (up to 4 rows x 16 elements per thread in registers).
-template <int XS>
-__device__ __forceinline__ void th_rows16(const float* __restrict__ W, const float* __restrict__ bias, int I, int R, const float (*x)[XS],
-                                          float* pre, int pre_stride, int B) {
-    // (I % 4 == 0, rows 16-byte aligned: checked by the launcher.)  16-byte loads: the launch is bound by the NUMBER of vector-memory
-    // instructions its few CUs can issue, not by bytes -- a 160-float row is 3 loads per lane group instead of 10
-    constexpr int NG = TH_NT / 16, NRT = 4, NE = TH_MAXI / 64;     // row groups per block; rows, 16-byte pieces per thread
-    const int tid = threadIdx.x, g16 = tid >> 4, j = tid & 15;
-    const int nu = (I + 63) >> 6;
-    for (int rb = 0; rb < R; rb += NG * NRT) {
-        const int nk = min(NRT, (R - rb + NG - 1) / NG);    // (uniform: whole row passes that do not exist are skipped, not masked)
-        f32x4 wv[NRT][NE];
-#pragma unroll
-        for (int k = 0; k < NRT; ++k) {
-            if (k < nk) {
-                const int r = rb + k * NG + g16;
-#pragma unroll
-                for (int u = 0; u < NE; ++u) {
-                    if (u < nu) {
-                        const int i = 4 * j + 64 * u;
-                        wv[k][u] = (r < R && i < I) ? *reinterpret_cast<const f32x4*>(W + (size_t)r * I + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NRT; ++k) {
-            if (k < nk) {
-                const int r = rb + k * NG + g16;
-#pragma unroll
-                for (int b = 0; b < TH_MAXB; ++b) {
-                    if (b < B) {
-                        float v = 0.f;
-#pragma unroll
-                        for (int u = 0; u < NE; ++u) {
-                            const int i = 4 * j + 64 * u;
-                            if (u < nu && i < I) {
-                                const f32x4 xv = *reinterpret_cast<const f32x4*>(&x[b][i]);
-                                v = fmaf(wv[k][u].x, xv.x, v); v = fmaf(wv[k][u].y, xv.y, v); v = fmaf(wv[k][u].z, xv.z, v); v = fmaf(wv[k][u].w, xv.w, v);
-                            }
-                        }
-                        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-                        if (r < R && j == 0) pre[b * pre_stride + r] = v + (bias ? bias[r] : 0.f);
-                    }
-                }
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(TH_NT) void time_head_kernel(const THArgs a) {
-    const bnerv_time_head_desc& d = a.d;
-    __shared__ __attribute__((aligned(16))) float s_pe[TH_MAXB][TH_MAXI];
-    __shared__ __attribute__((aligned(16))) float s_y0[TH_MAXB][TH_MAXH];
-    __shared__ __attribute__((aligned(16))) float s_t0[TH_MAXB][TH_MAXT];
-    __shared__ __attribute__((aligned(16))) float s_zt[TH_MAXB][TH_MAXT];
-    __shared__ __attribute__((aligned(16))) float s_h[TH_MAXB + 2 * TH_MAXB][TH_MAXB][TH_MAXT];   // hidden vector [B][TO] + second-layer staging [B][TH_MAXH]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int B = d.B, L = d.L, I = 2 * d.L;
-    const bool stem_role = (int)blockIdx.x < a.nb_stem;
-    // ---- positional encoding (model_blocks.py:120-126): ONE IEEE fp32 multiply, accurate sinf / cosf; fp64 positions rounded to fp32 first
-    for (int e = tid; e < B * L; e += TH_NT) {
-        const int n = e / L, l = e - n * L;
-        const float v = __fmul_rn((float)d.pos[n], d.bases[l]);
-        const float sv = sinf(v), cv = cosf(v);
-        s_pe[n][l] = sv; s_pe[n][L + l] = cv;
-        if (blockIdx.x == 0) { d.pe[(size_t)n * I + l] = sv; d.pe[(size_t)n * I + L + l] = cv; }
-    }
-    __syncthreads();
-    if (d._pad == 1) return;                               // (debug: tools/khead.py times the kernel stage by stage)
-    if (stem_role) {
-        // stem layer 0 (every stem block: H x I from L2), then sin / cos one element per thread
-        th_rows16<TH_MAXI>(d.sw0, d.sb0, I, d.SH, s_pe, &s_y0[0][0], TH_MAXH, B);
-        __syncthreads();
-        for (int e = tid; e < B * d.SH; e += TH_NT) {
-            const int b = e / d.SH, r = e - b * d.SH;
-            float sv, cv;
-            sincosf(s_y0[b][r], &sv, &cv);
-            s_y0[b][r] = sv;
-            if (blockIdx.x == 0) { d.sy0[(size_t)b * d.SH + r] = sv; d.saux0[(size_t)b * d.SH + r] = cv; }
-        }
-        __syncthreads();
-        if (d._pad == 2) return;
-        // this block's rows of stem layer 1: wave per row
-        const int r0 = (int)blockIdx.x * a.rows_per_block, r1 = min(r0 + a.rows_per_block, d.SO);
-        for (int r = r0 + wave; r < r1; r += TH_NT / 64) {
-            const float* wr = d.sw1 + (size_t)r * d.SH;
-            const float bias = d.sb1 ? d.sb1[r] : 0.f;
-            f32x4 wv[TH_MAXH / 256];                          // 16 bytes per lane: a 256-float row is ONE load per lane
-#pragma unroll
-            for (int u = 0; u < TH_MAXH / 256; ++u)
-                wv[u] = 4 * lane + 256 * u < d.SH ? *reinterpret_cast<const f32x4*>(wr + 4 * lane + 256 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int b = 0; b < B; ++b) {
-                float s = 0.f;
-#pragma unroll
-                for (int u = 0; u < TH_MAXH / 256; ++u) {
-                    const int i = 4 * lane + 256 * u;
-                    if (i < d.SH) {
-                        const f32x4 xv = *reinterpret_cast<const f32x4*>(&s_y0[b][i]);
-                        s = fmaf(wv[u].x, xv.x, s); s = fmaf(wv[u].y, xv.y, s); s = fmaf(wv[u].z, xv.z, s); s = fmaf(wv[u].w, xv.w, s);
-                    }
-                }
-                s = wave_sum(s);
-                if (lane == 0) {
-                    float sv, cv;
-                    sincosf(s + bias, &sv, &cv);
-                    d.sy1[(size_t)b * d.SO + r] = sv;
-                    d.saux1[(size_t)b * d.SO + r] = cv;
-                }
-            }
-        }
-        return;
-    }
-    // ---- SFT role: stem_t, then the modulation MLPs
-    if (d._pad == 4) return;                               // (debug: stem blocks only)
-    const int sb = (int)blockIdx.x - a.nb_stem;
-    th_rows16<TH_MAXI>(d.tw0, d.tb0, I, d.TH, s_pe, &s_t0[0][0], TH_MAXT, B);
-    __syncthreads();
-    for (int e = tid; e < B * d.TH; e += TH_NT) {
-        const int b = e / d.TH, r = e - b * d.TH;
-        float sv, cv;
-        sincosf(s_t0[b][r], &sv, &cv);
-        s_t0[b][r] = sv;
-        if (sb == 0) { d.ty0[(size_t)b * d.TH + r] = sv; d.taux0[(size_t)b * d.TH + r] = cv; }
-    }
-    __syncthreads();
-    th_rows16<TH_MAXT>(d.tw1, d.tb1, d.TH, d.TO, s_t0, &s_zt[0][0], TH_MAXT, B);
-    __syncthreads();
-    for (int e = tid; e < B * d.TO; e += TH_NT) {
-        const int b = e / d.TO, r = e - b * d.TO;
-        float sv, cv;
-        sincosf(s_zt[b][r], &sv, &cv);
-        s_zt[b][r] = sv;
-        if (sb == 0) { d.ty1[(size_t)b * d.TO + r] = sv; d.taux1[(size_t)b * d.TO + r] = cv; }
-    }
-    __syncthreads();
-    // one modulation MLP per SFT block at a time (a block per MLP when the grid allows): both layers with the coalesced row routine
-    float (*s_h1)[TH_MAXT] = s_h[0];                       // [B][TO] hidden vector
-    float* s_o = &s_h[TH_MAXB][0][0];                      // [B][TH_MAXH] second-layer results before they go out
-    for (int mi = sb; mi < d.n_mlp; mi += a.nb_sft) {
-        const THMlp mm = a.m[mi];
-        th_rows16<TH_MAXT>(mm.w1, mm.b1, d.TO, d.TO, s_zt, &s_h1[0][0], TH_MAXT, B);
-        __syncthreads();
-        for (int e = tid; e < B * d.TO; e += TH_NT) {
-            const int b = e / d.TO, r = e - b * d.TO;
-            const float y = fmaxf(s_h1[b][r], 0.f);
-            s_h1[b][r] = y;
-            mm.hs[(size_t)b * d.TO + r] = y;
-        }
-        __syncthreads();
-        th_rows16<TH_MAXT>(mm.w2, mm.b2, d.TO, mm.C, s_h1, s_o, TH_MAXH, B);
-        __syncthreads();
-        for (int e = tid; e < B * mm.C; e += TH_NT) {
-            const int b = e / mm.C, r = e - b * mm.C;
-            mm.out[(size_t)b * mm.C + r] = s_o[b * TH_MAXH + r];
-        }
-        __syncthreads();
-    }
-}
-
 // Descriptor tables travel BY VALUE in the kernel-argument segment (<= 4 KB: BNERV_MAX_DENSE_GROUPS * 88 B), so a captured
 // hipGraph replays them without touching host memory.
 extern "C" int bnerv_dense_grouped_fwd(void* stream, const bnerv_dense_fwd_desc* groups, int n_groups, int B) {
@@ -495,32 +312,5 @@ extern "C" int bnerv_reduce_slabs(void* stream, const float* slabs, int n_slabs,
     else
         hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(cdiv(count, 4)), dim3(1024), 0, (hipStream_t)stream, slabs, n_slabs, count, out);
     BNERV_LAUNCH_CHECK("reduce_slabs");
-    return BNERV_OK;
-}
-
-// 1: not this launch's head (the caller issues the five grouped launches); BNERV_OK; negative BNERV_E_*.
-extern "C" int bnerv_time_head_fwd(void* stream, const bnerv_time_head_desc* dp, const bnerv_time_head_mlp* mlps) {
-    BNERV_REQUIRE(dp && mlps, "time_head_fwd: null descriptor");
-    const bnerv_time_head_desc& d = *dp;
-    BNERV_REQUIRE(d.pos && d.bases && d.pe && d.sw0 && d.sw1 && d.sy0 && d.saux0 && d.sy1 && d.saux1 && d.tw0 && d.tw1 && d.ty0 && d.taux0 && d.ty1 && d.taux1,
-                  "time_head_fwd: null tensor");
-    BNERV_REQUIRE(d.B > 0 && d.L > 0 && d.SH > 0 && d.SO > 0 && d.TH > 0 && d.TO > 0 && d.n_mlp >= 0, "time_head_fwd: bad shape");
-    if (d.B > TH_MAXB || 2 * d.L > TH_MAXI || d.SH > TH_MAXH || d.TH > TH_MAXT || d.TO > 32 || d.n_mlp > BNERV_MAX_DENSE_GROUPS) return 1;
-    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-    if ((2 * d.L) % 4 || d.SH % 4 || d.TH % 4 || d.TO % 4 || !al16(d.sw0) || !al16(d.sw1) || !al16(d.tw0) || !al16(d.tw1)) return 1;     // 16-byte row loads
-    for (int i = 0; i < d.n_mlp; ++i)
-        if (mlps[i].C > TH_MAXH || !al16(mlps[i].w1) || !al16(mlps[i].w2)) return 1;
-    THArgs a;
-    a.d = d;
-    for (int i = 0; i < d.n_mlp; ++i) {
-        BNERV_REQUIRE(mlps[i].w1 && mlps[i].w2 && mlps[i].hs && mlps[i].out && mlps[i].C > 0, "time_head_fwd: bad modulation MLP %d", i);
-        a.m[i].w1 = mlps[i].w1; a.m[i].b1 = mlps[i].b1; a.m[i].w2 = mlps[i].w2; a.m[i].b2 = mlps[i].b2; a.m[i].hs = mlps[i].hs; a.m[i].out = mlps[i].out;
-        a.m[i].C = mlps[i].C; a.m[i]._pad = 0;
-    }
-    a.rows_per_block = 16;
-    a.nb_stem = cdiv(d.SO, a.rows_per_block);
-    a.nb_sft = d.n_mlp > 0 ? d.n_mlp : 1;
-    hipLaunchKernelGGL(time_head_kernel, dim3(a.nb_stem + a.nb_sft), dim3(TH_NT), 0, (hipStream_t)stream, a);
-    BNERV_LAUNCH_CHECK("time_head");
     return BNERV_OK;
 }

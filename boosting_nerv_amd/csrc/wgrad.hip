@@ -407,15 +407,10 @@ __global__ __launch_bounds__(1024) void wgrad_finish_kernel(const float* __restr
 #define WTRACE(it_, slot) do {} while (0)
 #endif
 // GM2: 0 = g as is, 1 = g is the pixel-shuffled (x2) gradient (two float4 per channel PAIR), 2 = tanh-grad (g, gaux)
-// Q4W (round 4, KS == 3 and GM2 == 0 only): the contraction on v_mfma_f32_4x4x1_16b_f32 instead of 16x16x4.  One instruction = 16 pixels x
-// (4 output channels) x (4 weight columns): lane 4 b + t supplies g[cout 4 m + t][pixel b] as A and the input value of column 4 q + t at
-// pixel b as B, D_b[i][j] lands in lane 4 b + j, register i -- 16 per-pixel-slot partial sums that are added up once per block by four
-// xor-shuffles.  12 output channels are exactly 3 quads and the 109 columns 28 quads: no 12 -> 16 row padding (a quarter of the 16x16x4
-// work) and 112 / 112 instead of 7 x 16 = 112 columns.  A wave owns 7 of the 28 column quads for ALL 256 pixels of the tile (84
-// accumulator registers) instead of all columns for its 64 pixels, so the waves' results are disjoint and need no LDS reduction.
-template <int KS, int IN, int GM2, bool Q4W = false>
+// (A v_mfma_f32_4x4x1 form of this body -- no 12 -> 16 row padding -- was built and measured slower in round 4: DESIGN section 11.1;
+// retired in round 5, git history has it.)
+template <int KS, int IN, int GM2>
 __device__ __forceinline__ void wgrad_lean_body(const WArgs& wa, const int n_grows /* s_g rows kept */, const SidePack& side, const int vb, const int vgrid) {
-    static_assert(!Q4W || (KS == 3 && GM2 == 0), "the 4x4x1 form serves the 12-channel 3x3 layers with a plain gradient");
     // (vb of vgrid: this launch's block index / size, or the weight-gradient part of a paired launch)
     using G = Geo<KS>;
     constexpr int NTW = (KS == 3) ? 7 : 1;
@@ -645,30 +640,6 @@ __device__ __forceinline__ void wgrad_lean_body(const WArgs& wa, const int n_gro
     f32x4 acc[NTW];
 #pragma unroll
     for (int n = 0; n < NTW; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // 4x4x1 form: column quads 7 wave .. 7 wave + 6, lane (b = lane >> 2, t = lane & 3)
-    constexpr int NQW = 7, NMQ = 3;
-    f32x4 acc4[Q4W ? NMQ : 1][Q4W ? NQW : 1];
-    int bq[Q4W ? NQW : 1];
-    const int a4 = (lane & 3) * CSG + (lane >> 2);
-    if constexpr (Q4W) {
-#pragma unroll
-        for (int m = 0; m < NMQ; ++m)
-#pragma unroll
-            for (int q = 0; q < NQW; ++q) acc4[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < NQW; ++q) {
-            const int n = 4 * (NQW * wave + q) + (lane & 3);
-            int off;
-            if (n < nW) {
-                const int ci = n / G::T, tap = n - ci * G::T;
-                off = ci * G::PLANE + (tap / KS) * G::RS + (tap % KS) + G::COL0;
-            } else {
-                off = (n == nW ? NPLL : NPLL + 1) * G::PLANE;
-            }
-            bq[q] = off + (lane >> 2);
-        }
-    }
-
     int aff_b = -1;
     if (has_work) {
         issue(it);
@@ -686,37 +657,6 @@ __device__ __forceinline__ void wgrad_lean_body(const WArgs& wa, const int n_gro
         WTRACE(wt, 1);
         const Pre pre = prep(nxt);
         WTRACE(wt, 2);
-        if constexpr (Q4W) {
-            float af[2][NMQ], bf[2][NQW];
-#pragma unroll
-            for (int pg = 0; pg < 16; ++pg) {              // 16 pixels per group: tile row pg >> 1, columns 16 (pg & 1) ..
-                if (has_next) {                            // the next tile's loads, spread over the pixel groups
-#pragma unroll
-                    for (int p = 0; p < NPART; ++p)
-                        if (p * 16 / NPART == pg) issue_part(pre, p);
-                }
-                // operands of group pg + 1 are read while the 21 MFMAs of group pg issue (one register set ahead; the fences keep the
-                // scheduler from hoisting every group's reads to the top: 84 accumulators leave no room for that)
-                if (pg == 0) {
-#pragma unroll
-                    for (int m = 0; m < NMQ; ++m) af[0][m] = s_g[a4 + m * 4 * CSG];
-#pragma unroll
-                    for (int q = 0; q < NQW; ++q) bf[0][q] = s_in[bq[q]];
-                }
-                if (pg + 1 < 16) {
-#pragma unroll
-                    for (int m = 0; m < NMQ; ++m) af[(pg + 1) & 1][m] = s_g[a4 + m * 4 * CSG + ((pg + 1) >> 1) * TW + ((pg + 1) & 1) * 16];
-#pragma unroll
-                    for (int q = 0; q < NQW; ++q) bf[(pg + 1) & 1][q] = s_in[bq[q] + ((pg + 1) >> 1) * G::RS + ((pg + 1) & 1) * 16];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < NQW; ++q)
-#pragma unroll
-                    for (int m = 0; m < NMQ; ++m) acc4[m][q] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[pg & 1][m], bf[pg & 1][q], acc4[m][q], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
             if (has_next) {                                // the next tile's loads, spread over the K steps
@@ -731,7 +671,6 @@ __device__ __forceinline__ void wgrad_lean_body(const WArgs& wa, const int n_gro
 #pragma unroll
             for (int n = 0; n < NTW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[n], acc[n], 0, 0, 0);
         }
-        }
         WTRACE(wt, 3);
         lds_barrier();                                     // everyone done reading tile t
         WTRACE(wt, 5);
@@ -744,25 +683,6 @@ __device__ __forceinline__ void wgrad_lean_body(const WArgs& wa, const int n_gro
     }
     WTRACE(7, 2);
 
-    if constexpr (Q4W) {
-        // the 16 pixel-slot partials of every (cout, column) live in lanes 4 b + j: four xor steps in a fixed order, then lanes 0..3 hold
-        // column 4 q + j of the wave's quads -- the waves' columns are disjoint, so each writes its part of the block's slab directly
-        float* slab = wa.slab + (size_t)vb * Cout * wa.ncols;
-#pragma unroll
-        for (int m = 0; m < NMQ; ++m)
-#pragma unroll
-            for (int q = 0; q < NQW; ++q)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = acc4[m][q][i];
-                    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-                    const int row = 4 * m + i, col = 4 * (NQW * wave + q) + lane;
-                    if (lane < 4 && row < Cout && col < wa.ncols) slab[(size_t)row * wa.ncols + col] = v;
-                }
-        __syncthreads();                                   // (the hosted reductions below use the block's LDS as scratch)
-        side_run_hosted(side, smem, vb, vgrid);
-        return;
-    }
     // cross-wave reduction through LDS (fixed order => deterministic), then ONE slab per block
     __syncthreads();
     float* s_red = smem;
@@ -786,23 +706,13 @@ template <int KS, int IN, int GM2>
 __global__ __launch_bounds__(256, (KS == 3 ? 3 : 4)) void wgrad_lean_kernel(const WArgs wa, const int n_grows, const SidePack side) {
     wgrad_lean_body<KS, IN, GM2>(wa, n_grows, side, (int)blockIdx.x, (int)gridDim.x);
 }
-template <int IN>
-__global__ __launch_bounds__(256, 2) void wgrad_lean4_kernel(const WArgs wa, const int n_grows, const SidePack side) {
-    wgrad_lean_body<3, IN, 0, true>(wa, n_grows, side, (int)blockIdx.x, (int)gridDim.x);
-}
-// BNERV_WGRAD4=1: the 12-channel 3x3 weight gradients on 4x4x1 (opt-in, read per call).  Measured on MI355X: the form's 84
-// accumulator registers allow two blocks per CU instead of three, and its per-block ending (336 xor-shuffles and 336 scattered 4-byte stores per
-// wave) does not amortise: 720p pairs 88-99 us against 65-84 us, 360p 37 against 26, 180p 22 against 12; C1 step 1.686 against 1.497 ms.
-static bool wgrad4_on() { const char* e = getenv("BNERV_WGRAD4"); return e && e[0] == '1'; }
-
 // ---- paired launch: the data gradient of a 12-channel 3x3 conv (conv4_body.h) and a weight gradient that does not depend on it, in
 // ONE grid -- blocks [0, n_conv) run the conv, the rest the weight gradient (small layers), or the two roles interleaved with equal
 // block counts and the same tile walk (large layers: n_conv < 0, see launch_pair).  Inside a TAT block's backward the pairs are
 // (dW1 | dconv1), (dW0 | dconv0), (dW_block | dconv_block): each pair reads the same incoming gradient, and neither half fills the
 // chip through its prologue and tail (at 180x320 each is one tile per block: two latency-bound launches become one).
-// (the 4x4x1 weight gradient keeps 84 accumulator registers: its variant is built for two blocks per CU, 256 registers per lane)
-template <int EP, int WIN, bool Q4W>
-__global__ __launch_bounds__(256, (Q4W ? 2 : 3)) void conv_wgrad_pair_kernel(const bnerv_conv::KArgs ka, const WArgs wa, const int n_grows, const int n_conv, const SidePack side, const int pat) {
+template <int EP, int WIN>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_pair_kernel(const bnerv_conv::KArgs ka, const WArgs wa, const int n_grows, const int n_conv, const SidePack side, const int pat) {
     if (n_conv < 0) {
         // interleaved roles (n_conv = -(blocks per role)): XCD-local slots alternate conv / weight gradient, and block k of either role
         // walks the same tile list on the same XCD -- what one reads of the shared gradient (and of the conv's aux = the weight
@@ -814,7 +724,7 @@ __global__ __launch_bounds__(256, (Q4W ? 2 : 3)) void conv_wgrad_pair_kernel(con
             none.n_jobs = 0; none.n_slices = 0;
             bnerv_q4::conv_q4_body<BNERV_IN_PLAIN, EP>(ka, none, vb, nr);
         } else {
-            wgrad_lean_body<3, WIN, 0, Q4W>(wa, n_grows, side, vb, nr);
+            wgrad_lean_body<3, WIN, 0>(wa, n_grows, side, vb, nr);
         }
         return;
     }
@@ -823,7 +733,7 @@ __global__ __launch_bounds__(256, (Q4W ? 2 : 3)) void conv_wgrad_pair_kernel(con
         none.n_jobs = 0; none.n_slices = 0;
         bnerv_q4::conv_q4_body<BNERV_IN_PLAIN, EP>(ka, none, (int)blockIdx.x, n_conv);
     } else {
-        wgrad_lean_body<3, WIN, 0, Q4W>(wa, n_grows, side, (int)blockIdx.x - n_conv, (int)gridDim.x - n_conv);
+        wgrad_lean_body<3, WIN, 0>(wa, n_grows, side, (int)blockIdx.x - n_conv, (int)gridDim.x - n_conv);
     }
 }
 
@@ -840,14 +750,10 @@ static bool wlean_ok(const WArgs& wa) {
     return (size_t)d.B * cmax * d.H * d.W * 4 + (size_t)(d.W + 4) * 4 < WLEAN_MAX_BYTES;
 }
 
-static bool wgrad4_on();
-static bool wlean4(const bnerv_wgrad_desc& d) {            // the layers the 4x4x1 form of the lean kernel takes (two blocks per CU)
-    return d.k == 3 && d.Cout <= 12 && (d.g_mode == BNERV_IN_PLAIN || (d.g_mode == BNERV_IN_UNSHUFFLE && d.g_s == 1)) && wgrad4_on();
-}
 static int wlean_blocks(const bnerv_wgrad_desc& d) {
     const int total_tiles = d.B * cdiv(d.H, TH) * cdiv(d.W, TW);
     const int want = total_tiles < 1 ? 1 : total_tiles;   // fill the machine first: small layers are latency-bound
-    const int target = 256 * (d.k == 3 ? (wlean4(d) ? 2 : 3) : 4);
+    const int target = 256 * (d.k == 3 ? 3 : 4);
     return want < target ? want : target;
 }
 
@@ -869,13 +775,6 @@ int launch_wlean(hipStream_t st, const WArgs& wa) {
     const size_t lds = wlean_lds_bytes<KS>(n_grows);
     SidePack side;
     bnerv_side_take(wa.d.ctx, &side, 2 * wlean_blocks(wa.d));
-    if constexpr (KS == 3 && GM2 == 0) {
-        if (wlean4(wa.d)) {                                // 12-channel layers: the 4x4x1 form (two blocks per CU: wlean_blocks)
-            hipLaunchKernelGGL((wgrad_lean4_kernel<IN>), dim3(wlean_blocks(wa.d)), dim3(256), lds, st, wa, n_grows, side);
-            BNERV_LAUNCH_CHECK("wgrad_lean4");
-            return BNERV_OK;
-        }
-    }
     hipLaunchKernelGGL((wgrad_lean_kernel<KS, IN, GM2>), dim3(wlean_blocks(wa.d)), dim3(256), lds, st, wa, n_grows, side);
     BNERV_LAUNCH_CHECK("wgrad_lean");
     return BNERV_OK;
@@ -1518,8 +1417,7 @@ int launch_pair(hipStream_t st, bnerv_conv::KArgs& ka, const WArgs& wa, int* n_w
     if (lw > lds) lds = lw;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pair_kernel<EP, WIN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pair_kernel<EP, WIN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pair_kernel<EP, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     int n_conv = ka.total_items < 768 ? ka.total_items : 768;          // 3 conv blocks per CU when the layer is large
@@ -1533,17 +1431,14 @@ int launch_pair(hipStream_t st, bnerv_conv::KArgs& ka, const WArgs& wa, int* n_w
     // roles), 1.664 (6), 1.68 (3, 4, 7); 376 / 368 per role as 384, 512 per role (not all resident) 1.783.
     static const int mix3 = [] { const char* e = getenv("BNERV_PAIR_MIX"); return e ? atoi(e) : 384; }();
     static const int pat = [] { const char* e = getenv("BNERV_PAIR_PAT"); return e ? atoi(e) : 5; }();
-    const bool q4w = wlean4(wa.d);
-    const int mix = q4w && mix3 > 0 ? 256 : mix3;                       // (4x4x1 weight gradient: two blocks per CU, one of each role)
-    if (q4w && n_conv > 512) n_conv = 512;
+    const int mix = mix3;
     if (mix > 0 && ka.total_items >= 2 * mix && n_w >= mix) {          // large layer: mix blocks per role, all resident, roles interleaved
         n_w = mix; n_conv = -mix; grid = 2 * mix;
         if (n_w_out) *n_w_out = n_w;
     }
     SidePack side;
     bnerv_side_take(wa.d.ctx, &side, 2 * n_w);
-    if (q4w) hipLaunchKernelGGL((conv_wgrad_pair_kernel<EP, WIN, true>), dim3(grid), dim3(256), lds, st, ka, wa, n_grows, n_conv, side, pat);
-    else hipLaunchKernelGGL((conv_wgrad_pair_kernel<EP, WIN, false>), dim3(grid), dim3(256), lds, st, ka, wa, n_grows, n_conv, side, pat);
+    hipLaunchKernelGGL((conv_wgrad_pair_kernel<EP, WIN>), dim3(grid), dim3(256), lds, st, ka, wa, n_grows, n_conv, side, pat);
     BNERV_LAUNCH_CHECK("conv_wgrad_pair");
     return BNERV_OK;
 }

@@ -286,90 +286,6 @@ def _dense_grouped_bwd(acts, xc, wc, ys, auxs, dys, need_x, has_b, same_x, B):
     return dxs, dws, dbs
 
 
-class _TimeHead(torch.autograd.Function):
-    """PositionEncoding -> stem | stem_t -> every TAT modulation MLP as ONE forward launch (include/bnerv.h bnerv_time_head_fwd); the
-    backward is the unchanged grouped dense backward of the four layers depths."""
-
-    @staticmethod
-    def forward(ctx, pos, bases, n_mlp, *params):
-        lib = L.load()
-        dev = pos.device
-        B, Lv = pos.shape[0], bases.numel()
-        p2 = [L.f32c(t).reshape(t.shape[0], -1) if t.dim() > 1 else L.f32c(t) for t in params]
-        sw0, sb0, sw1, sb1, tw0, tb0, tw1, tb1 = p2[:8]
-        mw = p2[8:]
-        SH, SO, TH, TO = sw0.shape[0], sw1.shape[0], tw0.shape[0], tw1.shape[0]
-        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
-        pe, sy0, saux0, sy1, saux1 = f(B, 2 * Lv), f(B, SH), f(B, SH), f(B, SO), f(B, SO)
-        ty0, taux0, ty1, taux1 = f(B, TH), f(B, TH), f(B, TO), f(B, TO)
-        hs = [f(B, TO) for _ in range(n_mlp)]
-        outs = [f(B, mw[4 * i + 2].shape[0]) for i in range(n_mlp)]
-        d = L.TimeHeadDesc(L.ptr(pos), L.ptr(bases), L.ptr(pe), L.ptr(sw0), L.ptr(sb0), L.ptr(sw1), L.ptr(sb1), L.ptr(sy0), L.ptr(saux0), L.ptr(sy1), L.ptr(saux1),
-                           L.ptr(tw0), L.ptr(tb0), L.ptr(tw1), L.ptr(tb1), L.ptr(ty0), L.ptr(taux0), L.ptr(ty1), L.ptr(taux1), B, Lv, SH, SO, TH, TO, n_mlp,
-                           int(os.environ.get("BNERV_TH_DEBUG", "0")))
-        ml = (L.TimeHeadMlp * max(n_mlp, 1))()
-        for i in range(n_mlp):
-            w1, b1, w2, b2 = mw[4 * i:4 * i + 4]
-            ml[i].w1, ml[i].b1, ml[i].w2, ml[i].b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
-            ml[i].hs, ml[i].out, ml[i].C = hs[i].data_ptr(), outs[i].data_ptr(), w2.shape[0]
-        L.check(lib.bnerv_time_head_fwd(L.stream(), C.byref(d), ml), "bnerv_time_head_fwd")
-        ctx.n_mlp, ctx.B = n_mlp, B
-        ctx.pshapes = [tuple(t.shape) for t in params]
-        ctx.save_for_backward(pe, sy0, saux0, sy1, saux1, ty0, taux0, ty1, taux1, *hs, *outs, *p2)
-        return (sy1, ty1, *outs)
-
-    @staticmethod
-    def backward(ctx, d_sy1, d_ty1, *d_outs):
-        if _lazy_depth > 0:
-            _flush_deferred()               # the modulation gradients are deferred slab reductions of the TAT blocks
-        n, B = ctx.n_mlp, ctx.B
-        sv = ctx.saved_tensors
-        pe, sy0, saux0, sy1, saux1, ty0, taux0, ty1, taux1 = sv[:9]
-        hs, outs, p2 = sv[9:9 + n], sv[9 + n:9 + 2 * n], sv[9 + 2 * n:]
-        sw0, sb0, sw1, sb1, tw0, tb0, tw1, tb1 = p2[:8]
-        mw = p2[8:]
-        none, relu, sin = L.ACT_NONE, L.ACT_RELU, L.ACT_SIN
-        g = [None] * len(p2)
-        d_zt = d_ty1
-        if n:
-            w1s, w2s = [mw[4 * i] for i in range(n)], [mw[4 * i + 2] for i in range(n)]
-            dx4, dw4, db4 = _dense_grouped_bwd([none] * n, hs, w2s, outs, [None] * n, d_outs, [True] * n, [True] * n, False, B)
-            dx3, dw3, db3 = _dense_grouped_bwd([relu] * n, [ty1] * n, w1s, hs, [None] * n, dx4, [True] * n, [True] * n, True, B)
-            tot = next(t for t in dx3 if t is not None)
-            d_zt = tot if d_ty1 is None else tot + L.f32c(d_ty1).reshape(tot.shape)
-            for i in range(n):
-                g[8 + 4 * i], g[8 + 4 * i + 1], g[8 + 4 * i + 2], g[8 + 4 * i + 3] = dw3[i], db3[i], dw4[i], db4[i]
-        dx2, dw2, db2 = _dense_grouped_bwd([sin, sin], [sy0, ty0], [sw1, tw1], [sy1, ty1], [saux1, taux1], [d_sy1, d_zt], [True, True], [True, True], False, B)
-        dx1, dw1, db1 = _dense_grouped_bwd([sin, sin], [pe, pe], [sw0, tw0], [sy0, ty0], [saux0, taux0], dx2, [False, False], [True, True], True, B)
-        g[0], g[1], g[2], g[3] = dw1[0], db1[0], dw2[0], db2[0]
-        g[4], g[5], g[6], g[7] = dw1[1], db1[1], dw2[1], db2[1]
-        g = [None if t is None else t.reshape(sh) for t, sh in zip(g, ctx.pshapes)]
-        return (None, None, None, *g)
-
-
-TIME_HEAD_MAX_B = 4
-
-
-def time_head(pos, bases, stem, stem_t, mlps):
-    """pos [B] fp64, bases fp32 [L]; stem / stem_t = (w0, b0, w1, b1) of the two 2-layer sin MLPs; mlps = [(w1, b1, w2, b2), ...] of the TAT
-    modulation branches (relu inside).  Returns (stem_out [B, SO], z_t [B, TO], [out_i [B, C_i]]).  None when the shapes are not the
-    one-launch kernel's (the caller runs the five grouped launches)."""
-    B, Lv = pos.shape[0], bases.numel()
-    # OPT-IN (BNERV_TIME_HEAD=1).  Measured on MI355X (DESIGN section 11): 14.4 us against 13.0 us for the five launches replayed on their
-    # own, and 1.508 against 1.494 ms per C1 step -- every stem block re-reads the 164 KB first stem matrix (44 MB through L2 instead of
-    # 164 KB) and the chain's four dependent memory round trips are as long inside one launch as across launch boundaries.
-    if os.environ.get("BNERV_TIME_HEAD", "0") != "1" or pos.dtype != torch.float64 or not pos.is_cuda:
-        return None
-    SH, TH, TO = stem[0].shape[0], stem_t[0].shape[0], stem_t[2].shape[0]
-    if B > TIME_HEAD_MAX_B or 2 * Lv > 256 or SH > 512 or TH > 64 or TO > 32 or len(mlps) > L.MAX_DENSE_GROUPS:
-        return None
-    if any(t is None for t in (*stem, *stem_t)) or any(t is None for m in mlps for t in m):
-        return None
-    flat = [t for m in mlps for t in m]
-    out = _TimeHead.apply(pos.contiguous(), bases.to(device=pos.device, dtype=torch.float32).contiguous(), len(mlps), *stem, *stem_t, *flat)
-    return out[0], out[1], list(out[2:])
-
-
 DENSE_GEMM_MIN_B = 16
 
 
@@ -480,17 +396,6 @@ def _tat_forward(y0, s0, t0, s1, t1, w0, b0, w1, b1, train=True):
     out = torch.empty_like(y0)
     hs = torch.empty_like(y0) if train else None
     gp = torch.empty_like(y0) if train else None          # decode / eval (no_grad): neither h nor gelu' is read again, so they are not written
-    # the whole block as ONE launch (12-channel stages: include/bnerv.h bnerv_tat_block_fwd, csrc/tatf.hip).  OPT-IN, BNERV_TATF=1: on MI355X
-    # the one-launch form measured 118-121 us per 720p block against 89 us for the two launches, so the default is two
-    rc = 1
-    if os.environ.get("BNERV_TATF", "0") == "1":
-        td = L.TatDesc(L.ptr(y0), L.ptr(w0), L.ptr(b0), L.ptr(w1), L.ptr(b1), L.ptr(s0), L.ptr(t0), L.ptr(s1), L.ptr(t1), L.ptr(hs), L.ptr(gp), L.ptr(out),
-                       B, Cc, H, W, L.ctx().handle)
-        rc = L.load().bnerv_tat_block_fwd(L.stream(), C.byref(td))
-    if rc == 0:
-        return hs, gp, out
-    if rc != 1:
-        L.check(rc, "bnerv_tat_block_fwd")
     h = hs if train else torch.empty_like(y0)
     _conv(y0, w0, b0, h, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=s0, shift=t0, out2=gp)
     _conv(h, w1, b1, out, B=B, Cin=Cc, Cout=Cc, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_RES, scale=s1, shift=t1, aux0=y0)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BNERV_ABI_VERSION 6
+#define BNERV_ABI_VERSION 7
 
 #define BNERV_OK 0
 #define BNERV_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -87,27 +87,6 @@ typedef struct {
 
 int bnerv_dense_grouped_fwd(void* stream, const bnerv_dense_fwd_desc* groups, int n_groups, int B);
 int bnerv_dense_grouped_bwd(void* stream, const bnerv_dense_bwd_desc* groups, int n_groups, int B);
-
-/* The time-embedding head of NeRV_Boost.forward as ONE launch (ABI 6; csrc/dense.hip).  Replaces, for B <= 4 frames per GPU:
- *   pe = PositionEncoding(pos)                               model_nerv.py:47, model_blocks.py:120-126   (fp64 position rounded to fp32 first)
- *   stem   : sy0 = sin(sw0 pe + sb0) [SH];  sy1 = sin(sw1 sy0 + sb1) [SO]      model_nerv.py:48-50, NeRV_MLP model_blocks.py:66-71
- *   stem_t : ty0 = sin(tw0 pe + tb0) [TH];  ty1 = sin(tw1 ty0 + tb1) [TO] = z_t
- *   every TAT modulation MLP i:  hs_i = relu(w1_i z_t + b1_i) [TO];  out_i = w2_i hs_i + b2_i [C_i]          SFTLayer, model_blocks.py:92-105
- * i.e. bnerv_pe_fwd_f32_from_f64 + four bnerv_dense_grouped_fwd launches; every tensor those calls leave behind (outputs and the
- * cosines saux* / taux* of the sin layers) is written, so the backward is the unchanged bnerv_dense_grouped_bwd sequence.
- * Returns 1 when the shapes are not this kernel's (B > 4, 2L > 256, SH > 512, TH > 64, TO > 32, more than BNERV_MAX_DENSE_GROUPS MLPs). */
-typedef struct { const float* w1; const float* b1; const float* w2; const float* b2; float* hs; float* out; int C; int _pad; } bnerv_time_head_mlp;
-typedef struct {
-    const double* pos;     /* [B] */
-    const float* bases;    /* [L] */
-    float* pe;             /* [B, 2L] */
-    const float* sw0; const float* sb0; const float* sw1; const float* sb1;      /* stem: [SH, 2L], [SH], [SO, SH], [SO] */
-    float* sy0; float* saux0; float* sy1; float* saux1;                          /* [B, SH] x 2, [B, SO] x 2 */
-    const float* tw0; const float* tb0; const float* tw1; const float* tb1;      /* stem_t: [TH, 2L], [TH], [TO, TH], [TO] */
-    float* ty0; float* taux0; float* ty1; float* taux1;                          /* [B, TH] x 2, [B, TO] x 2 */
-    int B, L, SH, SO, TH, TO, n_mlp, _pad;
-} bnerv_time_head_desc;
-int bnerv_time_head_fwd(void* stream, const bnerv_time_head_desc* d, const bnerv_time_head_mlp* mlps /* [n_mlp] */);
 
 /* Stand-alone TAT affine  y = x*(scale[b,c]+1) + shift[b,c]  (SFTLayer.forward, model_blocks.py:101-105) and its backward:
  *   dx = g*(scale+1);  part[chunk][0][b,c] = sum_chunk g*x;  part[chunk][1][b,c] = sum_chunk g
@@ -234,32 +213,6 @@ int bnerv_conv_partial_rows(const bnerv_conv_desc* d);
  * With partial == NULL the layer runs unsplit. */
 size_t bnerv_conv_splitk_ws_bytes(const bnerv_conv_desc* d);
 int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* d);
-
-/* The TAT residual block forward as ONE launch (ABI 6; csrc/tatf.hip).  Replaces ResBlock_SFT.forward (model_blocks.py:74-89):
- *     out = x0 + conv1( sft1( gelu( conv0( sft0(x0) ) ) ) ),   sft_i(a) = a*(1+scale_i[b,c]) + shift_i[b,c]   (SFTLayer, model_blocks.py:92-105)
- * both convolutions 3x3, stride 1, zero padding 1 (applied AFTER each affine), C -> C channels with bias; GELU exact (model_blocks.py:81).
- * Train form (h and gp given): also writes h = gelu(v) and gp = gelu'(v), v = conv0(sft0(x0)) + b0 -- exactly what the two-call form
- * (bnerv_conv_igemm with BNERV_IN_AFFINE / BNERV_EP_BIAS_GELU, then BNERV_IN_AFFINE / BNERV_EP_BIAS_RES) leaves behind, so the backward
- * (bnerv_conv_wgrad_pair x 2) is unchanged.  Decode form (h == gp == NULL): only `out` is written.
- * Returns 1 when the block is not this kernel's (C outside 9..12, W % 4 != 0, unaligned tensors, a handful of tiles): the caller then
- * issues the two bnerv_conv_igemm calls.  The intermediate tile stays in LDS (one-pixel halo recomputed per 16x32 tile). */
-typedef struct {
-    const float* x0;       /* [B, C, H, W] */
-    const float* w0;       /* [C, C, 3, 3] conv0 */
-    const float* b0;       /* [C] or NULL */
-    const float* w1;       /* [C, C, 3, 3] conv1 */
-    const float* b1;       /* [C] or NULL */
-    const float* scale0;   /* [B, C] */
-    const float* shift0;   /* [B, C] */
-    const float* scale1;   /* [B, C] */
-    const float* shift1;   /* [B, C] */
-    float* h;              /* [B, C, H, W] gelu(v)   (NULL with gp: decode) */
-    float* gp;             /* [B, C, H, W] gelu'(v) */
-    float* out;            /* [B, C, H, W] */
-    int B, C, H, W;
-    bnerv_ctx* ctx;        /* stream context (may be NULL; nothing is hosted by this launch) */
-} bnerv_tat_desc;
-int bnerv_tat_block_fwd(void* stream, const bnerv_tat_desc* d);
 
 /* Weight + bias gradient (autograd's backward of F.conv2d wrt weight/bias at the same call sites):
  *   dw[co][ci][t] = sum_{b,p} g[b][co][p] * a[b][ci][p + t - pad],  db[co] = sum_{b,p} g[b][co][p]

@@ -69,6 +69,7 @@ def _install_crashtrace():
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "experimental: exercises a kernel form that is not in the default library")
+    config.addinivalue_line("markers", "isolated: run the test body in a child pytest process (a native crash becomes an ordinary failure)")
     # conftest is imported AFTER pytest's fd-level capture replaced descriptor 2: the terminal's stderr is the descriptor the capture
     # manager saved (private attribute, hence the guarded lookup; without it the crumbs still reach the trail file)
     global _REAL_STDERR
@@ -116,6 +117,46 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+ISOLATED_CHILD = "BNERV_ISOLATED_CHILD"
+
+
+def run_isolated(nodeid, timeout=900, marker="gpu"):
+    """Run ONE test in a child pytest process and turn whatever happens to the child into an ordinary outcome of the calling test:
+    exit 0 -> passed (or skipped, if the child skipped), anything else -- an assertion, a timeout, a native crash (SIGABRT / SIGSEGV
+    inside a kernel launch, RCCL, a graph capture) -- -> pytest.fail with the tail of the child's output, which ends with the crash
+    tracer's native frames and its "died in" line.  The suite's main process survives and every other test keeps its evidence
+    (round 4 lost 183 results to one abort).  Used through @pytest.mark.isolated, see pytest_pyfunc_call below."""
+    import subprocess
+    env = dict(os.environ)
+    env[ISOLATED_CHILD] = "1"
+    env["BNERV_TEST_TRAIL"] = BREADCRUMB + ".child"
+    cmd = [sys.executable, "-m", "pytest", nodeid, "-x", "-q", "-p", "no:cacheprovider", "-m", marker]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+        out, rc = r.stdout.decode("utf-8", "replace"), r.returncode
+    except subprocess.TimeoutExpired as e:
+        out, rc = (e.stdout or b"").decode("utf-8", "replace"), "timeout"
+    if rc == 0:
+        tail = out[-600:]
+        if " skipped" in tail and " passed" not in tail:
+            pytest.skip(f"isolated child skipped {nodeid}")
+        return out
+    how = f"killed by signal {-rc}" if isinstance(rc, int) and rc < 0 else f"exit status {rc}"
+    keep = [ln for ln in out.splitlines() if not ln.startswith("  File ") and not ln.startswith("Extension modules:")]
+    pytest.fail(f"isolated child for {nodeid}: {how}\n" + "\n".join(keep[-70:])[-6000:], pytrace=False)
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_pyfunc_call(pyfuncitem):
+    """@pytest.mark.isolated: the test body runs in a child process (run_isolated); inside that child it runs normally."""
+    if pyfuncitem.get_closest_marker("isolated") is None or os.environ.get(ISOLATED_CHILD) == "1":
+        return None
+    if "gpu" in pyfuncitem.keywords and not torch.cuda.is_available():
+        return None
+    run_isolated(pyfuncitem.nodeid, marker="gpu" if "gpu" in pyfuncitem.keywords else "not gpu")
+    return True
 
 
 def load_golden(name):

@@ -68,51 +68,6 @@ def test_tiny_models_against_reference_goldens(name, cfg):
             assert err <= 5e-3 * max(gn, float(ref.abs().max())) + 1e-6, (k, err, gn)
 
 
-@pytest.mark.parametrize("B", [1, 2, 4])
-def test_time_head_one_launch_equals_the_five_launch_form(B, monkeypatch):
-    """NeRV_Boost's time-embedding head (PE -> stem | stem_t -> every TAT modulation MLP) as ONE launch (ops.time_head,
-    include/bnerv.h bnerv_time_head_fwd) against the five grouped launches it replaces: image, every returned stage and every parameter
-    gradient of the tiny model (the fused forward writes the same saved tensors; the backward is the same grouped dense backward), and the
-    quantities themselves against float64: PE with its large arguments, sin layers, relu MLPs."""
-    from boosting_nerv_amd import hnerv_utils as hu, ops
-    args = configs.tiny_nerv()
-    torch.manual_seed(1)
-    model = _build("tiny_nerv", args).to(DEV)
-    norm_idx = torch.tensor([(i + 1) / 7 for i in range(B)], dtype=torch.float64, device=DEV)
-    frame = torch.rand(B, 3, 180, 320, generator=torch.Generator().manual_seed(3)).to(DEV)
-    res = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("BNERV_TIME_HEAD", flag)
-        model.zero_grad(set_to_none=True)
-        img, lst, _ = model(norm_idx, norm_idx=norm_idx)
-        hu.loss_fn(img, frame, "L1_freq").backward()
-        res[flag] = (img.detach().clone(), [t.detach().clone() for t in lst], {k: p.grad.detach().clone() for k, p in model.named_parameters()})
-    a, b = res["1"], res["0"]
-    torch.testing.assert_close(a[0], b[0], rtol=1e-4, atol=2e-6)
-    for x, y in zip(a[1], b[1]):
-        torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-6)
-    for k in a[2]:
-        ga, gb = a[2][k], b[2][k]
-        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-9, (k, float((ga - gb).abs().max()), float(gb.abs().max()))
-    # the head's own outputs against float64 (stock ops), straight through ops.time_head
-    sfts = []
-    for layer in model.layers:
-        sfts += layer.sft_layers()
-    monkeypatch.setenv("BNERV_TIME_HEAD", "1")
-    from boosting_nerv_amd.model_blocks import time_head_forward
-    with torch.no_grad():
-        out, zt, mods = time_head_forward(model.pe_t, norm_idx, model.stem, model.stem_t, sfts)
-        pe = torch.cat([torch.sin(norm_idx.float()[:, None] * model.pe_t.pe_bases.to(DEV)), torch.cos(norm_idx.float()[:, None] * model.pe_t.pe_bases.to(DEV))], 1).double()
-        f = lambda m, x: torch.sin(x @ m.weight.double().flatten(1).T + m.bias.double())
-        ref_out = f(model.stem[2], f(model.stem[0], pe))
-        ref_zt = f(model.stem_t[2], f(model.stem_t[0], pe))
-        torch.testing.assert_close(out.flatten(1).double(), ref_out, rtol=1e-4, atol=2e-5)       # (sin of O(1) sums of 160 / 256 products in fp32)
-        torch.testing.assert_close(zt.flatten(1).double(), ref_zt, rtol=1e-4, atol=2e-5)
-        l0 = sfts[0]
-        h = torch.relu(ref_zt @ l0.SFT_scale_conv0.weight.double().flatten(1).T + l0.SFT_scale_conv0.bias.double())
-        torch.testing.assert_close(mods[0][0].flatten(1).double(), h @ l0.SFT_scale_conv1.weight.double().flatten(1).T + l0.SFT_scale_conv1.bias.double(), rtol=1e-4, atol=2e-5)
-
-
 def test_c1_full_size_against_reference_golden():
     """BASELINE config C1/C2 (NeRV-boost 1.5M, 720x1280): seeded init identical to the reference, forward / loss / gradient
     norms against the reference's own run."""
@@ -279,6 +234,7 @@ def test_big_models_full_size_against_reference_golden(name, cfg):
     assert all(torch.isfinite(p).all().item() for p in model.parameters())
 
 
+@pytest.mark.isolated
 @pytest.mark.parametrize("name,cfg", [("c3", configs.c3), ("c4", configs.c4)])
 def test_big_models_captured_recipe_steps_against_oracle(name, cfg):
     """The recipe's train step (Fusion10_freq, fused Adan, cosine schedule) of C3 / C4 at 1080x1920 as the CAPTURED hipGraph, against
@@ -339,6 +295,7 @@ def test_big_models_captured_recipe_steps_against_oracle(name, cfg):
         assert abs(psnr_h - float(psnr_c.mean())) <= 0.02, (name, s, psnr_h, float(psnr_c.mean()))
 
 
+@pytest.mark.isolated
 def test_c5_full_size_against_reference_golden():
     """BASELINE configs[4] at its own size: ONE compression train step's hooks (train_nerv_compression.py:354-367) on the C3 model built
     with --quant at 1080x1920 against the reference's CPU run (oracle/make_goldens.py gen_full_c5): quantiser scales after init_data,
@@ -645,6 +602,7 @@ def test_short_schedule_end_psnr_matches_oracle():
     assert abs(got - ref_psnr) <= 0.02, (got, ref_psnr)
 
 
+@pytest.mark.isolated
 def test_long_unsynchronised_run_keeps_the_schedule():
     """The per-step scalars (lr, Adan bias corrections) reach the GPU through a ring of pinned slots.  With the GPU held back
     (a long sleep kernel) the host enqueues far more steps than the ring has slots: every step must still see its OWN
@@ -685,6 +643,7 @@ def test_smoke_entry():
     g.smoke()
 
 
+@pytest.mark.isolated
 def test_dp_step_path_on_one_rank_group():
     """The multi-GPU step executed on a 1-rank NCCL(=RCCL) group, in both forms -- ONE graph with the all-reduce captured inside,
     and graph A [fwd,loss,bwd,bucket gather] -> eager all-reduce -> graph B [scatter, Adan] -- and with the bucket in one or two
@@ -956,7 +915,8 @@ def test_train_cli_end_to_end(tmp_path, monkeypatch):
 
 
 def test_bench_two_ranks_share_one_gpu(tmp_path):
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), with BNERV_BENCH_SHARE_GPU=1 so that
+    """Plain `python bench.py --gpus 2` (the script re-launches itself through torch.distributed.run, one rank per process; the
+    driver's explicit torch.distributed.run form is what test_bench_two_ranks_over_rccl uses), with BNERV_BENCH_SHARE_GPU=1 so that
     both ranks use this box's single GPU over gloo: the N > 1 code path of the script runs end to end and prints ONE JSON line with
     the contract's keys (the numbers of such a run mean nothing)."""
     import json
@@ -965,8 +925,10 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BNERV_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29671",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "5"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    # plain `python bench.py --gpus 2`: the script launches its own ranks (torch.distributed.run, free local port)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "5"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -1071,6 +1033,7 @@ def test_inpainting_cli_end_to_end(tmp_path, monkeypatch):
     assert train_psnrs[-1] > train_psnrs[0]
 
 
+@pytest.mark.isolated
 def test_captured_step_is_bitwise_reproducible_at_full_size():
     """tools/kdeterminism.py: two runs of 200 captured C1 steps (720x1280) from the same parameters and frame order give the same loss
     and the same bits in every parameter tensor at every step.  (Guards the tile pipelines' LDS hand-overs: the 4x4x1 kernel's

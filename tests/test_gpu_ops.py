@@ -166,86 +166,6 @@ def test_tat_block(ops, shape):
         close(a, r, msg=f"tat d{n}")
 
 
-@pytest.mark.parametrize("shape", [(1, 12, 48, 96), (2, 12, 37, 68), (1, 12, 16, 32), (2, 9, 21, 36), (1, 11, 180, 320), (3, 12, 5, 8), (1, 10, 33, 132)])
-def test_tat_block_fused_forward(ops, shape, monkeypatch):
-    """The one-launch TAT block forward (include/bnerv.h bnerv_tat_block_fwd, csrc/tatf.hip: 16 x 32 tiles, intermediate tile in LDS with a
-    recomputed one-pixel ring) against the oracle AND against the two-launch form it replaces: out, and the saved h = gelu(v), gp = gelu'(v)
-    the backward reads; then the whole autograd block (fused forward + paired backward).  Shapes: tiles that touch every image border at
-    once (one tile), ragged bottom / right tiles (H % 16, W % 32 != 0), images smaller than a tile, B > 1 (per-sample modulation: the weights
-    are re-scaled when the block's tile list crosses a sample), 9 / 10 / 11 channels (zero-padded quads), and the decode form (no h, gp)."""
-    from boosting_nerv_amd import _lib as L
-    import ctypes as C
-    monkeypatch.setenv("BNERV_TATF_MIN_TILES", "1")
-    monkeypatch.setenv("BNERV_TATF", "1")                  # (opt-in form: see csrc/tatf.hip, DESIGN section 11)
-    B, Cc, H, W = shape
-    x0, mods, w0, b0, w1, b1, g = _tat_inputs(B, Cc, H, W, seed=21)
-    s0, t0, s1, t1 = mods
-    with torch.no_grad():
-        v = F.conv2d(x0 * (s0 + 1) + t0, w0, b0, padding=1)
-        h_ref = F.gelu(v)
-        gp_ref = 0.5 * (1 + torch.erf(v / math.sqrt(2))) + v * torch.exp(-0.5 * v * v) / math.sqrt(2 * math.pi)
-        out_ref = x0 + F.conv2d(h_ref * (s1 + 1) + t1, w1, b1, padding=1)
-    xg, w0g, b0g, w1g, b1g = (t.detach().to(DEV).contiguous() for t in (x0, w0, b0, w1, b1))
-    m = [t.detach().to(DEV).reshape(B, Cc).contiguous() for t in mods]
-    for train in (True, False):
-        h = torch.full_like(xg, float("nan")) if train else None
-        gp = torch.full_like(xg, float("nan")) if train else None
-        out = torch.full_like(xg, float("nan"))
-        td = L.TatDesc(L.ptr(xg), L.ptr(w0g), L.ptr(b0g), L.ptr(w1g), L.ptr(b1g), L.ptr(m[0]), L.ptr(m[1]), L.ptr(m[2]), L.ptr(m[3]), L.ptr(h), L.ptr(gp), L.ptr(out),
-                       B, Cc, H, W, L.ctx().handle)
-        rc = L.load().bnerv_tat_block_fwd(L.stream(), C.byref(td))
-        assert rc == 0, (rc, L.load().bnerv_last_error())
-        close(out, out_ref, msg="fused tat fwd out")
-        if train:
-            close(h, h_ref, msg="fused tat fwd h")
-            close(gp, gp_ref, msg="fused tat fwd gelu'")
-    # the two-launch form on the same inputs: same quantities, fp32 summation order aside
-    monkeypatch.setenv("BNERV_TATF", "0")
-    h2, gp2, out2 = ops._tat_forward(xg, m[0], m[1], m[2], m[3], w0g, b0g, w1g, b1g, True)
-    monkeypatch.setenv("BNERV_TATF", "1")
-    h1, gp1, out1 = ops._tat_forward(xg, m[0], m[1], m[2], m[3], w0g, b0g, w1g, b1g, True)
-    close(out1, out2, msg="fused vs two-launch fwd out")
-    close(h1, h2, msg="fused vs two-launch fwd h")
-    close(gp1, gp2, msg="fused vs two-launch fwd gelu'")
-    # autograd block through the fused forward
-    ref = _tat_ref(x0, mods, w0, b0, w1, b1)
-    cot = torch.randn(ref.shape, generator=g)
-    leaves = [x0] + mods + [w0, b0, w1, b1]
-    rg = torch.autograd.grad(ref, leaves, cot)
-    gl = [gpu(t) for t in leaves]
-    outb = ops.tat_block(*gl)
-    close(outb, ref, msg="tat (fused) fwd")
-    for n, a, r in zip(["x0", "s0", "t0", "s1", "t1", "w0", "b0", "w1", "b1"], torch.autograd.grad(outb, gl, cot.to(DEV)), rg):
-        close(a, r, msg=f"tat (fused) d{n}")
-
-
-def test_tat_block_fused_at_full_size_is_reproducible(ops, monkeypatch):
-    """The one-launch form (opt-in, BNERV_TATF=1) at the BASELINE size: bitwise reproducible run to run, equal to stock ops."""
-    from boosting_nerv_amd import _lib as L
-    import ctypes as C
-    monkeypatch.setenv("BNERV_TATF", "1")
-    B, Cc, H, W = 1, 12, 720, 1280
-    g = torch.Generator().manual_seed(5)
-    xg = torch.randn(B, Cc, H, W, generator=g).to(DEV)
-    w0g, w1g = (torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc)).to(DEV), (torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc)).to(DEV)
-    b0g, b1g = (torch.randn(Cc, generator=g) * 0.1).to(DEV), (torch.randn(Cc, generator=g) * 0.1).to(DEV)
-    m = [(torch.randn(B, Cc, generator=g) * 0.2).to(DEV) for _ in range(4)]
-    outs = []
-    for _ in range(2):
-        h, gp, out = torch.empty_like(xg), torch.empty_like(xg), torch.empty_like(xg)
-        td = L.TatDesc(L.ptr(xg), L.ptr(w0g), L.ptr(b0g), L.ptr(w1g), L.ptr(b1g), L.ptr(m[0]), L.ptr(m[1]), L.ptr(m[2]), L.ptr(m[3]), L.ptr(h), L.ptr(gp), L.ptr(out),
-                       B, Cc, H, W, L.ctx().handle)
-        assert L.load().bnerv_tat_block_fwd(L.stream(), C.byref(td)) == 0
-        outs.append((h, gp, out))
-    assert all(torch.equal(a, b) for a, b in zip(*outs))
-    with torch.no_grad():
-        s0, t0, s1, t1 = (t.reshape(B, Cc, 1, 1) for t in m)
-        hr = F.gelu(F.conv2d(xg * (s0 + 1) + t0, w0g, b0g, padding=1))          # (stock ops on the GPU as a second opinion at full size)
-        outr = xg + F.conv2d(hr * (s1 + 1) + t1, w1g, b1g, padding=1)
-    close(outs[0][2], outr.cpu(), msg="fused tat fwd 720p out")
-    close(outs[0][0], hr.cpu(), msg="fused tat fwd 720p h")
-
-
 @pytest.mark.parametrize("case", [(1, 12, 12, 16, 64, 3, 1), (2, 12, 12, 9, 33, 3, 2), (1, 30, 15, 9, 16, 3, 5), (1, 20, 33, 6, 9, 1, 2), (1, 9, 7, 5, 6, 3, 3),
                                   (1, 20, 20, 24, 36, 3, 3), (1, 40, 38, 16, 32, 3, 2)])
 def test_snerv_block(ops, case):

@@ -24,7 +24,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, name), f"{name} declared in include/bnerv.h but not exported by libbnerv_hip.so"
         assert name in _lib.SYMBOLS, f"{name} has no ctypes binding in boosting_nerv_amd/_lib.py"
     assert set(_lib.SYMBOLS) <= declared
-    assert lib.bnerv_abi_version() == _lib.ABI_VERSION == 6 and lib.bnerv_build_arch() == b"gfx950"
+    assert lib.bnerv_abi_version() == _lib.ABI_VERSION == 7 and lib.bnerv_build_arch() == b"gfx950"
 
 
 def test_abi_argument_validation_without_gpu():
@@ -525,3 +525,19 @@ def test_adan_captured_launch_needs_the_capture_bracket():
     opt.begin_capture()
     assert opt._cap_open[0][1] is not t1                           # a second capture never shares the first one's table
     opt.finish_capture()
+
+
+def test_isolated_child_crash_is_an_ordinary_failure():
+    """conftest.run_isolated (what @pytest.mark.isolated runs a test through): a child that dies with SIGABRT must come back as a
+    normal pytest failure whose message carries the crash tracer's "died in" line; a passing child passes; a skipping child skips.
+    This is the guard that keeps one native crash from erasing the whole GPU suite's evidence (round 4)."""
+    import conftest
+    from _pytest.outcomes import Failed, Skipped
+    with pytest.raises(Failed) as ei:
+        conftest.run_isolated("tests/isolation_probe.py::test_probe_aborts", marker="not gpu")
+    msg = str(ei.value)
+    assert "killed by signal 6" in msg, msg[-800:]
+    assert "[bnerv-crashtrace] died in: [bnerv-trail] START tests/isolation_probe.py::test_probe_aborts" in msg, msg[-800:]
+    assert "passed" in conftest.run_isolated("tests/isolation_probe.py::test_probe_passes", marker="not gpu")
+    with pytest.raises(Skipped):
+        conftest.run_isolated("tests/isolation_probe.py::test_probe_skips", marker="not gpu")

@@ -26,8 +26,6 @@ for _ in range(reps):
     elif which == "pair_dk1":     # block conv backward: weight gradient (plain) | conv^T
         ops._wgrad_conv_pair(dict(x=x, g=g, dw=dw, db=db, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=1, **kw),
                              dict(x=g, w=w, bias=None, out=out, in_mode=L.IN_PLAIN, ep_mode=L.EP_PLAIN, transposed=1, **kw))
-    elif which == "tat_fused":    # the whole TAT block forward as one launch (csrc/tatf.hip)
-        ops._tat_forward(x, sc, sh, sc, sh, w, b, w, b, True)
     elif which == "conv38_k2s":     # wide layer, TAT conv0 forward: the wide split kernel (or lean2 with BNERV_SPLIT_WIDE=off)
         ops._conv(x, w, b, out, B=B, Cin=C, Cout=C, H=H, W=W, k=3, in_mode=L.IN_AFFINE, ep_mode=L.EP_BIAS_GELU, scale=sc, shift=sh, out2=g)
     elif which == "conv_k2s":       # the TAT conv0 forward the train step launches: affine -> conv -> bias -> gelu, gelu'

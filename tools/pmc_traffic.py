@@ -23,8 +23,6 @@ CFG = {
                       kernel="wA|dK2s: conv0 backward pair (weight gradient, affine prologue | conv^T -> dsin + sums) 12->12 @720x1280"),
     "pair_dk1": dict(mode="pair_dk1", pat="pair_kernel", row="pair_dk1", shape=[12, 720, 1280], alg=3 * P12 + 2 * WB12, sources=SRCP,
                      kernel="wP|dK1: block conv backward pair (weight gradient | conv^T) 12->12 @720x1280"),
-    "tat_fused": dict(mode="tat_fused", pat="tat_fused", row="tat_fwd", shape=[12, 720, 1280], alg=4 * P12 + 2 * WB12, sources=["tatf.hip", "conv_common.h", "common.h"],
-                      kernel="fused TAT block forward (affine -> conv0 -> gelu, gelu' -> affine -> conv1 -> + x0) 12->12 @720x1280"),
     "c4": dict(mode="conv_k2s_1080", pat="conv_", row="k2s", shape=[12, 1080, 1920], alg=3 * 12 * 1080 * 1920 * 4 + WB12, sources=SRC4,
                kernel="K2s: TAT conv0 forward (affine -> 3x3 -> bias -> gelu, gelu') 12->12 @1080x1920"),
     "wide": dict(mode="conv38_k2s", pat="conv_bfw_kernel", row="k2s", shape=[38, 1080, 1920], alg=945561600, sources=["convbf.hip", "split16.h", "conv_common.h", "common.h"],
