@@ -62,6 +62,10 @@ void bnerv_side_take(bnerv_ctx* ctx, SidePack* sp, int max_slices) {
     sp->n_jobs = 0;
     sp->n_slices = 0;
     if (!ctx) return;
+    // hosts are launches with an idle tail (several rounds of tiles per block); a one-tile-per-block launch (the <= 180x320 stages: every
+    // caller passes max_slices = 2 x its grid) would pay the hosted slices on top of its only round
+    static const int min_grid = [] { const char* e = getenv("BNERV_SIDE_MIN_GRID"); return e ? atoi(e) : 0; }();
+    if (max_slices < 2 * min_grid) return;
     std::vector<SideJob>& q = ctx->queue;
     int n = 0;
     while (n < (int)q.size() && n < SIDE_MAX_JOBS && sp->n_slices + q[n].slices <= max_slices) {

@@ -1466,7 +1466,12 @@ int bnerv_convbf_pair_try(hipStream_t st, const bnerv_conv_desc& d, int vec, con
     if (slots < 1) return 1;
     const int nr = 8 * wg * slots;
     // both roles must fill the chip on their own: the conv has at least two items per block, the weight gradient's own plan at least twice the slots
-    if (ngroups * d.B * ka.tiles_x * ka.tiles_y < 2 * nr || nat_slots < 2 * slots) return 1;
+    // both roles must fill the chip on their own: about one item per resident block or more (7/8 of the blocks busy).  Round 5: the
+    // threshold was two items per block, which sent C1's 12 -> 48 up-conv backward at 180x320 (230 tiles for 256 blocks per role) to the
+    // low-resolution pair -- 46.6 us there against 25.3 us here (profiles/r05_timeline_c1.md); at 90x160 (60 tiles) the low-resolution
+    // pair stays faster (17.0 against 20.1 us).  BNERV_PAIR_BFW_FILL=<eighths> overrides (16 = the old rule, 0 = always).
+    static const int fill = [] { const char* e = getenv("BNERV_PAIR_BFW_FILL"); return e ? atoi(e) : 7; }();
+    if (ngroups * d.B * ka.tiles_x * ka.tiles_y * 8 < fill * nr || nat_slots * 8 < fill * slots) return 1;
     int rc = 1;
 #define BNERV_BP(CI, CE, NT, WI, MT, G2) if (d.in_mode == CI && d.ep_mode == CE && ntb == NT && w.in_mode == WI && w_mtw == MT && gm2 == G2) \
         rc = launch_bfw_pair<CI, CE, NT, WI, MT, G2>(st, ka, wa, slots, ngn, ngm, nr);

@@ -54,7 +54,9 @@ bool bnerv_convs_shape_ok(const bnerv_conv_desc& d, int vec) {
     { const char* e = getenv("BNERV_SMALL"); if (e && e[0] == '0') return false; }      // A/B switch, read per call (tests reach the other families with it)
     // small images; an up-conv (several cout groups per tile) pays up to 180x320, where the persistent split kernel still runs one tile per block
     const bool uns = d.in_mode == BNERV_IN_UNSHUFFLE;          // the data gradient of a PixelShuffle(2) up-conv: its input is the shuffled gradient
-    const size_t max_px = ((d.out_s == 2 && d.Cout >= 32) || uns) ? 65536 : 16384;
+    static const size_t px_up = [] { const char* e = getenv("BNERV_SMALL_MAXPX_UP"); return e ? (size_t)atol(e) : (size_t)65536; }();     // (A/B switches)
+    static const size_t px_uns = [] { const char* e = getenv("BNERV_SMALL_MAXPX_UNS"); return e ? (size_t)atol(e) : (size_t)65536; }();
+    const size_t max_px = uns ? px_uns : (d.out_s == 2 && d.Cout >= 32) ? px_up : 16384;
     if (!(vec && d.k == 3 && d.Cin <= (uns ? 64 : 32) && (size_t)d.H * d.W <= max_px && d.B <= 65535 && cdiv(d.Cout, 16) <= 65535)) return false;
     if (uns) return d.in_s == 2 && (d.Cin & 3) == 0 && d.ep_mode == BNERV_EP_PLAIN && d.out_s == 1 && (size_t)d.B * d.Cin * d.H * d.W * 4 < LEAN_MAX_BYTES;
     if (d.in_s != 1) return false;
