@@ -737,6 +737,12 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_pair_kernel(const bnerv_con
     }
 }
 
+#include "pairf_body.h"      // the shared-tile form of the same pair (round 5)
+template <int EP, int WIN>
+__global__ __launch_bounds__(256, 2) void pair_fused_kernel(const bnerv_conv::KArgs ka, const WArgs wa, const SidePack side) {
+    pair_fused_body<EP, WIN>(ka, wa, side, (int)blockIdx.x, (int)gridDim.x);
+}
+
 constexpr size_t WLEAN_MAX_BYTES = 0x7ff00000;
 
 static bool wlean_ok(const WArgs& wa) {
@@ -1330,6 +1336,9 @@ int launch_modes(hipStream_t st, const WArgs& wa, const Plan& p) {
 
 #if defined(BNERV_TRACE) || defined(BNERV_TRACE_BW)
 extern "C" int bnerv_debug_trace_read_w(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_w), sizeof(g_trace_w)); }
+#ifdef BNERV_TRACE
+extern "C" int bnerv_debug_trace_read_pairf(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bnerv_q4::g_trace4), sizeof(bnerv_q4::g_trace4)); }   // this translation unit's copy (pairf_body.h stamps)
+#endif
 #endif
 extern "C" size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int k) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (k != 1 && k != 3)) return 0;
@@ -1411,6 +1420,35 @@ namespace {
 template <int EP, int WIN>
 int launch_pair(hipStream_t st, bnerv_conv::KArgs& ka, const WArgs& wa, int* n_w_out) {
     bnerv_q4::q4_prepare(ka);
+    {
+        // shared-tile form (pairf_body.h): one block runs both roles on its tile from ONE staged copy of the gradient.  Default: the pairs
+        // with a reducing epilogue (TAT convs: DGELU_SAVED / DSIN) from 1024 tiles on (two tiles per block at 512 blocks).  Measured on
+        // MI355X, C1 (profiles/r05_pair_fused.md): 720p DSIN pair 81.0 against 83.5 us, DGELU_SAVED 76.5 against 74.5, PLAIN 68.5 against
+        // 66.7 (kept on the interleaved pair); at 360x640 (900 tiles) the interleaved pair's three blocks per CU win (27 against 29 us).
+        // HBM traffic of the DSIN pair: see the same file.  BNERV_PAIR_FUSED=<tiles>: every pair from that many tiles on; 0: off.
+        const char* fe = getenv("BNERV_PAIR_FUSED");         // (read per call: the parity tests switch forms inside one process)
+        const int fused_env = fe ? atoi(fe) : -1;
+        const bool red_ep = EP == BNERV_EP_DGELU_SAVED || EP == BNERV_EP_DSIN;
+        const int fused_min = fused_env >= 0 ? fused_env : (red_ep ? 1024 : 0);
+        const bnerv_conv_desc& c = ka.d;
+        const bnerv_wgrad_desc& w = wa.d;
+        if (fused_min > 0 && ka.total_items >= fused_min && ka.total_items >= 8 && c.x == w.g && c.Cin == w.Cout && c.Cout == w.Cin && c.B == w.B &&
+            w.g_s == 1 && (w.g_mode == BNERV_IN_PLAIN || w.g_mode == BNERV_IN_UNSHUFFLE)) {
+            const size_t ldsf = pair_fused_lds_bytes();
+            static bool attrf = false;
+            if (!attrf) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_fused_kernel<EP, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+                attrf = true;
+            }
+            int grid = ka.total_items < 512 ? (ka.total_items & ~7) : 512;
+            if (n_w_out) *n_w_out = grid;
+            SidePack side;
+            bnerv_side_take(w.ctx, &side, 2 * grid);
+            hipLaunchKernelGGL((pair_fused_kernel<EP, WIN>), dim3(grid), dim3(256), ldsf, st, ka, wa, side);
+            BNERV_LAUNCH_CHECK("pair_fused");
+            return BNERV_OK;
+        }
+    }
     const int n_grows = wa.d.Cout <= 12 ? 12 : 16;
     size_t lds = bnerv_q4::q4_lds_bytes();
     const size_t lw = wlean_lds_bytes<3>(n_grows);

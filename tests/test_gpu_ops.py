@@ -166,6 +166,33 @@ def test_tat_block(ops, shape):
         close(a, r, msg=f"tat d{n}")
 
 
+@pytest.mark.parametrize("shape", [(1, 12, 48, 96), (2, 12, 37, 68), (3, 12, 16, 32), (2, 9, 21, 36), (1, 11, 180, 320), (1, 10, 33, 132), (1, 12, 360, 640)])
+def test_tat_block_backward_on_the_shared_tile_pair(ops, shape, monkeypatch):
+    """The shared-tile backward pair (csrc/pairf_body.h: data gradient + weight gradient of one 12-channel 3x3 layer from ONE staged
+    copy of the incoming gradient; default only from 1024 tiles on) forced on for every size (BNERV_PAIR_FUSED=8): the whole TAT block
+    against the oracle (stock ops on the CPU, reference semantics model_blocks.py:74-89) -- its conv1 pair is the DGELU_SAVED form, its
+    conv0 pair the DSIN form -- and against the interleaved pair it replaces (same quantities, fp32 summation order aside).  Shapes: one
+    tile touching every border, ragged bottom / right tiles, B > 1 (the per-sample flush of the per-lane channel sums and the per-sample
+    affine), 9 / 10 / 11 channels, several tiles per block (360x640: 900 tiles on 512 blocks)."""
+    x0, mods, w0, b0, w1, b1, g = _tat_inputs(*shape, seed=31)
+    ref = _tat_ref(x0, mods, w0, b0, w1, b1)
+    cot = torch.randn(ref.shape, generator=g)
+    leaves = [x0] + mods + [w0, b0, w1, b1]
+    rg = torch.autograd.grad(ref, leaves, cot)
+    names = ["x0", "s0", "t0", "s1", "t1", "w0", "b0", "w1", "b1"]
+    got = {}
+    for form, env in (("fused", "8"), ("interleaved", "0")):
+        monkeypatch.setenv("BNERV_PAIR_FUSED", env)
+        gl = [gpu(t) for t in leaves]
+        out = ops.tat_block(*gl)
+        close(out, ref, msg=f"tat fwd ({form})")
+        got[form] = torch.autograd.grad(out, gl, cot.to(DEV))
+        for n, a, r in zip(names, got[form], rg):
+            close(a, r, msg=f"tat d{n} ({form})")
+    for n, a, b in zip(names, got["fused"], got["interleaved"]):
+        close(a, b, msg=f"tat d{n}: shared-tile pair vs interleaved pair")
+
+
 @pytest.mark.parametrize("case", [(1, 12, 12, 16, 64, 3, 1), (2, 12, 12, 9, 33, 3, 2), (1, 30, 15, 9, 16, 3, 5), (1, 20, 33, 6, 9, 1, 2), (1, 9, 7, 5, 6, 3, 3),
                                   (1, 20, 20, 24, 36, 3, 3), (1, 40, 38, 16, 32, 3, 2)])
 def test_snerv_block(ops, case):

@@ -10,6 +10,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 B, C, H, W = (1, 38, 1080, 1920) if "38" in which else ((1, 12, 1080, 1920) if which.endswith("_1080") else (1, 12, 720, 1280))
 if which.endswith("_1080"):        # C4's final stage: the 12-channel kernels at 1080x1920
     which = which[:-5]
+if which.startswith("pair38"):    # C3's final stage: the backward pair of a 38-channel TAT conv (two launches: wide weight gradient, wide data gradient)
+    which = "pair" + which[6:]
 x, g = torch.randn(B, C, H, W, device=dev), torch.randn(B, C, H, W, device=dev)
 w, b = torch.randn(C, C, 3, 3, device=dev) / 10, torch.randn(C, device=dev)
 sc, sh = torch.randn(B, C, device=dev) * 0.1, torch.randn(B, C, device=dev) * 0.1

@@ -1,6 +1,6 @@
 """HBM traffic + issue mix of one hot kernel of the step from the PMC counters, stamped with the kernel sources it was measured on.
     python tools/pmc_traffic.py <which> [round-tag]      (through gpurun, repo root)   -> gpurun_out/<tag>_traffic_<which>.json + <tag>_pmc_<which>.md
-        which: k2s | pair_dk3s | pair_dk2s | pair_dk1 | tat_fused   (12 -> 12 @720x1280, C1)
+        which: k2s | pair_dk3s | pair_dk2s | pair_dk1   (12 -> 12 @720x1280, C1)
                c4 (K2s 12 -> 12 @1080x1920) | wide (K2s 38 -> 38 @1080x1920)
 Method (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (with --kernel-trace only),
 chip-wide sums per dispatch averaged over the dispatches of tools/kone.py; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at
@@ -9,22 +9,25 @@ matches the tree."""
 import csv, glob, hashlib, json, os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 which = sys.argv[1] if len(sys.argv) > 1 else "k2s"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
 P12 = 12 * 720 * 1280 * 4
 WB12 = 12 * 12 * 9 * 4
 SRC4 = ["conv.hip", "conv4.hip", "conv4_body.h", "conv_common.h", "common.h"]
-SRCP = ["wgrad.hip", "conv4_body.h", "conv4.hip", "conv_common.h", "common.h", "sidejob.h"]
+SRCP = ["wgrad.hip", "pairf_body.h", "conv4_body.h", "conv4.hip", "conv_common.h", "common.h", "sidejob.h"]
 CFG = {
     "k2s": dict(mode="conv_k2s", pat="conv_", row="k2s", shape=[12, 720, 1280], alg=3 * P12 + WB12, sources=SRC4,
                 kernel="K2s: TAT conv0 forward (affine -> 3x3 -> bias -> gelu, gelu') 12->12 @720x1280"),
-    "pair_dk3s": dict(mode="pair_dk3s", pat="pair_kernel", row="pair_dk3s", shape=[12, 720, 1280], alg=4 * P12 + 2 * WB12, sources=SRCP,
+    "pair_dk3s": dict(mode="pair_dk3s", pat="pair_", row="pair_dk3s", shape=[12, 720, 1280], alg=4 * P12 + 2 * WB12, sources=SRCP,
                       kernel="wA|dK3s: conv1 backward pair (weight gradient, affine prologue | conv^T -> dgelu(saved) + sums) 12->12 @720x1280"),
-    "pair_dk2s": dict(mode="pair_dk2s", pat="pair_kernel", row="pair_dk2s", shape=[12, 720, 1280], alg=5 * P12 + 2 * WB12, sources=SRCP,
+    "pair_dk2s": dict(mode="pair_dk2s", pat="pair_", row="pair_dk2s", shape=[12, 720, 1280], alg=5 * P12 + 2 * WB12, sources=SRCP,
                       kernel="wA|dK2s: conv0 backward pair (weight gradient, affine prologue | conv^T -> dsin + sums) 12->12 @720x1280"),
-    "pair_dk1": dict(mode="pair_dk1", pat="pair_kernel", row="pair_dk1", shape=[12, 720, 1280], alg=3 * P12 + 2 * WB12, sources=SRCP,
+    "pair_dk1": dict(mode="pair_dk1", pat="pair_", row="pair_dk1", shape=[12, 720, 1280], alg=3 * P12 + 2 * WB12, sources=SRCP,
                      kernel="wP|dK1: block conv backward pair (weight gradient | conv^T) 12->12 @720x1280"),
     "c4": dict(mode="conv_k2s_1080", pat="conv_", row="k2s", shape=[12, 1080, 1920], alg=3 * 12 * 1080 * 1920 * 4 + WB12, sources=SRC4,
                kernel="K2s: TAT conv0 forward (affine -> 3x3 -> bias -> gelu, gelu') 12->12 @1080x1920"),
+    "wide_pair": dict(mode="pair38_dk2s", pat="bfw_kernel", multi=True, row="pair_dk2s", shape=[38, 1080, 1920], alg=5 * 38 * 1080 * 1920 * 4 + 2 * 38 * 38 * 9 * 4,
+                      sources=["convbf.hip", "wgrad.hip", "wgrad_bfw_body.h", "split16.h", "conv_common.h", "common.h"],
+                      kernel="wA|dK2s 38->38 @1080x1920: conv0 backward as its two launches (wgrad_bfw_kernel + conv_bfw_kernel, DSIN epilogue), counters summed over the two"),
     "wide": dict(mode="conv38_k2s", pat="conv_bfw_kernel", row="k2s", shape=[38, 1080, 1920], alg=945561600, sources=["convbf.hip", "split16.h", "conv_common.h", "common.h"],
                  kernel="K2s 38->38 @1080x1920 on the wide split kernel"),
 }
@@ -41,11 +44,16 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SA
                    cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
         rows = [r for r in csv.DictReader(open(f)) if cfg["pat"] in r["Kernel_Name"] and "wprep" not in r["Kernel_Name"]]
+        kernels = sorted({r["Kernel_Name"] for r in rows}) if cfg.get("multi") else [None]
         for name in ctr.split():
-            v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == name]
-            if v:
-                vals[name] = sum(v) / len(v)
-                log.append(f"   {name:28s} {vals[name]:16.0f}  (n={len(v)})  {rows[0]['Kernel_Name'][:70]}")
+            tot = 0.0
+            for kn in kernels:                                   # multi: the pair is several launches -- per-kernel averages, summed
+                v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == name and (kn is None or r["Kernel_Name"] == kn)]
+                if v:
+                    tot += sum(v) / len(v)
+                    log.append(f"   {name:28s} {sum(v) / len(v):16.0f}  (n={len(v)})  {(kn or rows[0]['Kernel_Name'])[:70]}")
+            if tot:
+                vals[name] = tot
 h = hashlib.sha256()
 for f in sorted(cfg["sources"]):
     h.update(open(os.path.join(R, "boosting_nerv_amd", "csrc", f), "rb").read())
