@@ -57,7 +57,7 @@ __device__ __forceinline__ int g_base(int b, int co, int C, int H, int W, int s)
     return ((b * (C / ss) + cf) * (H * s) + i) * (W * s) + j;
 }
 
-__global__ __launch_bounds__(256) void wgrad_tiny_kernel(const WTArgs a) {
+__device__ __forceinline__ void wgrad_tiny_body(const WTArgs& a, const int bx, const int by) {     // (bx, by): the block's cout tile / column group
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = a.H, W = a.W, HW = H * W, RS = W + 2, PL = (H + 2) * RS;
     const int HWp = (HW + 3) & ~3, HWs = row_stride4(HW);
@@ -66,11 +66,11 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(const WTArgs a) {
     int* s_px = reinterpret_cast<int*>(s_g + 16 * HWs);  // [HWp]: pixel -> offset in a padded plane (of its interior origin)
     int* s_go = s_px + HWp;                              // [HWp]: pixel -> offset in the shuffled gradient plane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    const int co_base = blockIdx.x * 16, nW = a.Cin * 9;
+    const int co_base = bx * 16, nW = a.Cin * 9;
     int coloff[WT_NTW];
 #pragma unroll
     for (int t = 0; t < WT_NTW; ++t) {
-        const int col = (blockIdx.y * WT_NTG + wave + 4 * t) * 16 + li;
+        const int col = (by * WT_NTG + wave + 4 * t) * 16 + li;
         const int ci = col / 9, tap = col - ci * 9, dy = tap / 3, dx = tap - dy * 3;
         coloff[t] = col < nW ? ci * PL + dy * RS + dx : 0;                       // (columns beyond the matrix: any valid address, never stored)
     }
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(const WTArgs a) {
                 for (int t = 0; t < WT_NTW; ++t) bv[t] = bn[t];
             }
         }
-        if (blockIdx.y == 0) {                               // bias gradient: the row sums of g (wave w: rows 4w .. 4w + 3)
+        if (by == 0) {                               // bias gradient: the row sums of g (wave w: rows 4w .. 4w + 3)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float sm = 0.f;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(const WTArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < WT_NTW; ++t) {
-        const int col = (blockIdx.y * WT_NTG + wave + 4 * t) * 16 + li;
+        const int col = (by * WT_NTG + wave + 4 * t) * 16 + li;
         if (col >= nW) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -143,14 +143,15 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(const WTArgs a) {
             if (co < a.Cout) a.dw[(size_t)co * nW + col] = acc[t][e];
         }
     }
-    if (blockIdx.y == 0 && lane < 4 && a.db && co_base + wave * 4 + lane < a.Cout) a.db[co_base + wave * 4 + lane] = dbs;
+    if (by == 0 && lane < 4 && a.db && co_base + wave * 4 + lane < a.Cout) a.db[co_base + wave * 4 + lane] = dbs;
 }
+__global__ __launch_bounds__(256) void wgrad_tiny_kernel(const WTArgs a) { wgrad_tiny_body(a, (int)blockIdx.x, (int)blockIdx.y); }
 
 struct DTArgs { const float* g; const float* w; float* slab; int B, Cin, Cout, H, W, s; };   // conv-space: Cin = channels of g, Cout = channels of dx
 
 // NTN: N tiles (16 output channels each) the block computes; wave w owns the M tiles w, w + 4, w + 8, w + 12 (<= 256 pixels)
 template <int NTN>
-__global__ __launch_bounds__(256) void dgrad_tiny_kernel(const DTArgs a) {
+__device__ __forceinline__ void dgrad_tiny_body(const DTArgs& a, const int bx) {                     // bx: the block's slice of 8 gradient channels
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = a.H, W = a.W, HW = H * W, RS = W + 2, PL = (H + 2) * RS, NW = a.Cout * 9;
     const int MT = (HW + 15) >> 4;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void dgrad_tiny_kernel(const DTArgs a) {
     int* s_px = reinterpret_cast<int*>(s_w + ((DT_CS * NW + 3) & ~3));      // [MT * 16]
     int* s_go = s_px + MT * 16;                          // [MT * 16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    const int c0 = blockIdx.x * DT_CS;
+    const int c0 = bx * DT_CS;
     for (int i = tid; i < MT * 16; i += 256) {
         const int y = i / W, x = i - y * W;
         s_px[i] = i < HW ? y * RS + x : 0;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void dgrad_tiny_kernel(const DTArgs a) {
             for (int u = 0; u < 8; ++u) { const int p = gp0 + 32 * u; if (p < HW) s_g[gc * PL + RS + 1 + s_px[p]] = v[u]; }
         }
         __syncthreads();
-        float* out = a.slab + ((size_t)blockIdx.x * a.B + b) * a.Cout * HW;
+        float* out = a.slab + ((size_t)bx * a.B + b) * a.Cout * HW;
         for (int mt = wave; mt < MT; mt += 4) {
             f32x4 acc[NTN];
 #pragma unroll
@@ -218,6 +219,18 @@ __global__ __launch_bounds__(256) void dgrad_tiny_kernel(const DTArgs a) {
             }
         }
     }
+}
+template <int NTN>
+__global__ __launch_bounds__(256) void dgrad_tiny_kernel(const DTArgs a) { dgrad_tiny_body<NTN>(a, (int)blockIdx.x); }
+
+// The stem stage's backward as ONE launch: the weight gradient's blocks first, the data gradient's K slices behind them.  The two read the
+// same gradient and do not depend on each other; each is a 13 / 8 us launch of 47..141 / 94 blocks on 256 CUs whatever its arithmetic
+// (staging latency, one K loop, one store phase), and the data gradient's slab reduction rides on the deferred-reduction queue.
+template <int NTN>
+__global__ __launch_bounds__(256) void stem_pair_kernel(const WTArgs wa, const DTArgs da, const int wx, const int n_w) {
+    const int b = (int)blockIdx.x;
+    if (b < n_w) wgrad_tiny_body(wa, b % wx, b / wx);
+    else dgrad_tiny_body<NTN>(da, b - n_w);
 }
 
 bool stem_switch() {                                      // BNERV_STEM=0: the tiled kernels (A/B switch, read per call)
@@ -274,3 +287,39 @@ int bnerv_stem_dgrad_try(hipStream_t st, const bnerv_conv_desc& d) {
     BNERV_LAUNCH_CHECK("dgrad_tiny");
     return bnerv_reduce_slabs(st, d.partial, nblk, d.B * d.Cout * d.H * d.W, d.out);
 }
+
+// ---- both at once (bnerv_conv_wgrad_pair, form 0).  1: not this pair; BNERV_OK: dw / db written, dx's slabs in c.partial and *n_slabs > 0
+// slabs of c.B * c.Cout * c.H * c.W floats for the caller to reduce into c.out (deferred or at once).
+int bnerv_stem_pair_try(hipStream_t st, const bnerv_conv_desc& c, const bnerv_wgrad_desc& d, int* n_slabs) {
+    { const char* e = getenv("BNERV_PAIR_STEM"); if (e && e[0] == '0') return 1; }      // A/B switch, read per call
+    if (!stem_switch() || !stem_dgrad_shape(c) || !c.partial) return 1;
+    if (d.k != 3 || d.in_mode != BNERV_IN_PLAIN || d.g_mode == BNERV_IN_TANHGRAD) return 1;
+    if ((size_t)d.H * d.W > TINY_MAX_PX || !tiny_s_ok(d.g_s, d.Cout)) return 1;
+    const int PL = (d.H + 2) * (d.W + 2);
+    if ((size_t)d.Cin * PL > WT_MAX_XFLOATS || d.Cout < 64) return 1;
+    if ((size_t)d.B * (d.Cin > d.Cout ? d.Cin : d.Cout) * d.H * d.W >= (size_t)1 << 30) return 1;
+    const int cs = c.in_mode == BNERV_IN_UNSHUFFLE ? c.in_s : 1;
+    if (!(c.x == d.g && c.Cin == d.Cout && c.Cout == d.Cin && c.B == d.B && c.H == d.H && c.W == d.W && cs == d.g_s)) return 1;   // one layer, one gradient
+    const int HW = d.H * d.W, HWp = (HW + 3) & ~3;
+    const size_t lds_w = ((size_t)((d.Cin * PL + 3) & ~3) + 16 * (size_t)row_stride4(HW) + 2 * HWp) * sizeof(float);
+    const int NW = c.Cout * 9, MT = cdiv(HW, 16);
+    const size_t lds_d = ((size_t)((DT_CS * PL + 3) & ~3) + (size_t)((DT_CS * NW + 3) & ~3) + 2 * MT * 16) * sizeof(float);
+    const size_t lds = lds_w > lds_d ? lds_w : lds_d;
+    static size_t attr2 = 0, attr6 = 0;
+    const bool small = c.Cout <= 32;
+    size_t& attr = small ? attr2 : attr6;
+    if (lds > attr) {
+        if (small) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pair_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pair_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    WTArgs wa{d.x, d.g, d.dw, d.db, d.B, d.Cin, d.Cout, d.H, d.W, d.g_s};
+    DTArgs da{c.x, c.w, c.partial, c.B, c.Cin, c.Cout, c.H, c.W, cs};
+    const int wx = cdiv(d.Cout, 16), wy = cdiv(cdiv(d.Cin * 9, 16), WT_NTG), n_w = wx * wy, n_d = cdiv(c.Cin, DT_CS);
+    if (small) hipLaunchKernelGGL(stem_pair_kernel<2>, dim3(n_w + n_d), dim3(256), lds, st, wa, da, wx, n_w);
+    else hipLaunchKernelGGL(stem_pair_kernel<6>, dim3(n_w + n_d), dim3(256), lds, st, wa, da, wx, n_w);
+    BNERV_LAUNCH_CHECK("stem_pair");
+    *n_slabs = n_d;
+    return BNERV_OK;
+}
+

@@ -30,6 +30,7 @@ static __device__ unsigned long long g_trace_w[1024 * 4 * 8 * 8];
 int bnerv_convbf_pair_try(hipStream_t st, const bnerv_conv_desc& d, int vec, const bnerv_wb::WArgs& wa, int w_mtw, int ngn, int ngm, int nat_slots, int* n_slabs);   // convbf.hip
 bool bnerv_convs_shape_ok(const bnerv_conv_desc& d, int vec);     // convs.hip
 int bnerv_stem_wgrad_try(hipStream_t st, const bnerv_wgrad_desc& d);   // stem.hip (images of <= 256 pixels): 1 = not that layer
+int bnerv_stem_pair_try(hipStream_t st, const bnerv_conv_desc& c, const bnerv_wgrad_desc& d, int* n_slabs);   // stem.hip: the stem stage's (dW | d input) as one launch
 #include <stdlib.h>
 #include <type_traits>
 #include <string.h>
@@ -1609,6 +1610,17 @@ extern "C" int bnerv_conv_wgrad_pair(void* stream, const bnerv_conv_desc* cdp, c
     // the conv half: a 3x3 stride-1 data gradient (plain input, or the unshuffle(2) prologue of an up-conv's), epilogue PLAIN / DGELU_SAVED / DSIN
     if (c.in_mode == BNERV_IN_UNSHUFFLE && c.in_s == 1) c.in_mode = BNERV_IN_PLAIN;
     if (!(c.k == 3 && c.out_s == 1 && c.x && c.w && c.out && c.B > 0)) return 1;
+    // form 0: the stem stage (an image of <= 256 pixels: stem.hip) -- dW / db are written directly, the data gradient's K-slice slabs
+    // (c.partial, bnerv_conv_splitk_ws_bytes) are summed by a deferred reduction on the same context
+    if (c.ep_mode == BNERV_EP_PLAIN && c.partial && w.k == 3 && w.x && w.g && w.dw && w.ctx && w.ctx == c.ctx) {
+        int ns = 0;
+        const int rs = bnerv_stem_pair_try(reinterpret_cast<hipStream_t>(stream), c, w, &ns);
+        if (rs < 0) return rs;
+        if (rs == BNERV_OK) {
+            bnerv_side_push(c.ctx, reinterpret_cast<hipStream_t>(stream), c.partial, ns, c.B * c.Cout * c.H * c.W, 0, c.out, nullptr);
+            return BNERV_OK;
+        }
+    }
     if (!((c.in_mode == BNERV_IN_PLAIN && c.in_s == 1) || (c.in_mode == BNERV_IN_UNSHUFFLE && c.in_s == 2))) return 1;
     if (!(c.ep_mode == BNERV_EP_DGELU_SAVED || c.ep_mode == BNERV_EP_DSIN || c.ep_mode == BNERV_EP_PLAIN)) return 1;
     if (c.ep_mode != BNERV_EP_PLAIN && !(c.aux0 && c.aux1 && c.scale && c.partial)) return 1;

@@ -84,17 +84,20 @@ def _wgrad_conv_pair(wg, cv):
         rows = lib.bnerv_conv_partial_rows(C.byref(cd))
         part = torch.empty(rows, cv["B"], 2, cv["Cout"], dtype=torch.float32, device=cx.device)
         cd.partial = part.data_ptr()
+    skw = None
+    if not red and cv["ep_mode"] == L.EP_PLAIN:            # a split-K layer (the stem stage's long-K data gradient): its slab workspace
+        nb = lib.bnerv_conv_splitk_ws_bytes(C.byref(cd))
+        if nb:
+            skw = _ws(nb, cx.device)
+            cd.partial = skw.data_ptr()
     rc = lib.bnerv_conv_wgrad_pair(L.stream(), C.byref(cd), C.byref(wd))
     if rc == 1:                                            # not a pair the launch takes: the two usual calls, weight gradient first
         L.check(lib.bnerv_conv_wgrad(L.stream(), C.byref(wd)), "bnerv_conv_wgrad")
-        if not red and cv["ep_mode"] == L.EP_PLAIN:
-            nb = lib.bnerv_conv_splitk_ws_bytes(C.byref(cd))
-            if nb:
-                skw = _ws(nb, cx.device)
-                cd.partial = skw.data_ptr()
         L.check(lib.bnerv_conv_igemm(L.stream(), C.byref(cd)), "bnerv_conv_igemm")
     else:
         L.check(rc, "bnerv_conv_wgrad_pair")
+        if skw is not None:
+            L.ctx().keep.append(skw)                       # (the stem pair sums its slabs in a deferred reduction: alive until the flush)
     L.ctx().keep.append(ws)
     if red:
         st = torch.empty(cv["B"], 2, cv["Cout"], dtype=torch.float32, device=cx.device)
