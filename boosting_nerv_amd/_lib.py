@@ -39,6 +39,16 @@ class ConvDesc(C.Structure):
                 ("transposed", C.c_int), ("wCo", C.c_int), ("wCi", C.c_int), ("ctx", _fp)]
 
 
+class TimeBranchMlp(C.Structure):
+    _fields_ = [("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("hs", _fp), ("out", _fp), ("C", C.c_int), ("_pad", C.c_int)]
+
+
+class TimeBranchDesc(C.Structure):
+    _fields_ = [("pos", _fp), ("bases", _fp), ("pe", _fp), ("sw0", _fp), ("sb0", _fp), ("sy0", _fp), ("saux0", _fp),
+                ("tw0", _fp), ("tb0", _fp), ("tw1", _fp), ("tb1", _fp), ("ty0", _fp), ("taux0", _fp), ("ty1", _fp), ("taux1", _fp),
+                ("B", C.c_int), ("L", C.c_int), ("SH", C.c_int), ("TH", C.c_int), ("TO", C.c_int), ("n_mlp", C.c_int)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("x", _fp), ("g", _fp), ("gaux", _fp), ("scale", _fp), ("shift", _fp), ("dw", _fp), ("db", _fp),
                 ("ws", _fp), ("ws_bytes", C.c_size_t),
@@ -103,6 +113,7 @@ SYMBOLS = {
     "bnerv_pe_fwd_f64": (_I, [_V, _V, _V, _V, _I, _I]),
     "bnerv_pe_fwd_f32_from_f64": (_I, [_V, _V, _V, _V, _I, _I]),
     "bnerv_dense_grouped_fwd": (_I, [_V, C.POINTER(DenseFwdDesc), _I, _I]),
+    "bnerv_time_branch_fwd": (_I, [_V, C.POINTER(TimeBranchDesc), C.POINTER(TimeBranchMlp)]),
     "bnerv_dense_grouped_bwd": (_I, [_V, C.POINTER(DenseBwdDesc), _I, _I]),
     "bnerv_sft_affine_fwd": (_I, [_V, _V, _V, _V, _V, _I, _I, _I]),
     "bnerv_sft_affine_bwd": (_I, [_V, _V, _V, _V, _V, _V, _I, _I, _I]),
@@ -160,7 +171,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class BnervError(RuntimeError):

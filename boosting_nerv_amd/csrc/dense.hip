@@ -247,6 +247,185 @@ extern "C" int bnerv_pe_fwd_f64(void* stream, const double* pos, const float* ba
     return BNERV_OK;
 }
 
+// ---------------------------------------------------------------- the time-embedding branch as ONE launch (round 5)
+// NeRV_Boost.forward starts with a chain of five dependent tiny launches (model_nerv.py:47-51, model_blocks.py:66-71, :92-105):
+//     PE(t) -> [stem layer 0 | stem_t layer 0] -> [stem layer 1 | stem_t layer 1 = z_t] -> every TAT MLP layer 0 -> every TAT MLP layer 1,
+// ~4.8 us each (24 us of a 1.47 ms step) although only the stem's second layer (4.4 MB of weights) moves real data: the rest is GEMVs of a few
+// thousand MACs whose launches wait on one another.  This kernel runs everything except the stem's second layer:
+//   * stem blocks: PE, then a 16-row slice of stem layer 0 (sin; value and cosine written for the backward);
+//   * chain blocks (8): ALL the weights the block will need -- stem_t's two layers and its share of the TAT MLPs (both layers) -- are
+//     requested from memory at once, straight into LDS (one exposed memory latency instead of four: round 4's one-launch form reloaded at every
+//     level and was slower than the launches it replaced); PE meanwhile; then stem_t layer 0 -> layer 1 -> the block's MLPs
+//     from LDS.  Chain block 0 also writes PE and stem_t's outputs.
+// The stem's second layer follows as the ordinary grouped launch: 5 launches -> 2.  Every tensor the five-launch form left behind is written,
+// so the backward (bnerv_dense_grouped_bwd x 4) is unchanged.  A row here is 16 lanes x strided fma chains + 4 shuffle steps, in the grouped
+// kernel a wave-strided sum: same quantities, last-bit differences.
+struct TBMlp { const float* w1; const float* b1; const float* w2; const float* b2; float* hs; float* out; int C; int _pad; };
+struct TBArgs {
+    bnerv_time_branch_desc d;
+    TBMlp m[BNERV_MAX_DENSE_GROUPS];
+    int nb_stem, nb_chain, rows_per_block, mlps_per_block, cmax;      // cmax: the largest C_i, rounded up to 4
+};
+constexpr int TB_MAXB = 4, TB_MAXI = 256, TB_MAXH = 512, TB_MAXT = 64, TB_MAXO = 32, TB_MAXC = 128, TB_MAXM = 4;      // TB_MAXM: modulation MLPs per chain block
+constexpr int TB_NT = 1024;
+
+// pre[b * stride + r] = bias[r] + sum_i W[r * I + i] x[b][i]: 16 lanes per row, lane j takes elements j, j + 16, ... (W anywhere: LDS or global)
+template <int XS>
+__device__ __forceinline__ void tb_rows16(const float* __restrict__ W, const float* __restrict__ bias, const int I, const int R, const float (*x)[XS],
+                                          float* pre, const int stride, const int B) {
+    const int tid = threadIdx.x, g16 = tid >> 4, j = tid & 15;
+    for (int r = g16; r < ((R + TB_NT / 16 - 1) / (TB_NT / 16)) * (TB_NT / 16); r += TB_NT / 16) {      // (whole passes: the shuffles need every lane)
+        float v[TB_MAXB];
+#pragma unroll
+        for (int b = 0; b < TB_MAXB; ++b) v[b] = 0.f;
+        if (r < R) {
+            for (int i = j; i < I; i += 16) {
+                const float wv = W[(size_t)r * I + i];
+#pragma unroll
+                for (int b = 0; b < TB_MAXB; ++b)
+                    if (b < B) v[b] = fmaf(wv, x[b][i], v[b]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < TB_MAXB; ++b) {
+            if (b < B) {
+                float t = v[b];
+                t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
+                if (r < R && j == 0) pre[b * stride + r] = t + (bias ? bias[r] : 0.f);
+            }
+        }
+    }
+}
+
+// rows of SEVERAL small matrices at once, 8 lanes per row: row = mi * rows_pad + r of matrix mi (r >= rows[mi]: idle), inputs x[mi or 0][b][.]
+// in LDS, weights and biases in LDS.  Returns the pre-activation of (mi, r, b) in lane j == 0 of the row's group through `emit`.
+template <class RowsOf, class WOf, class BOf, class XOf, class Emit>
+__device__ __forceinline__ void tb_multi8(const int n_mat, const int rows_pad, const int I, const int B, RowsOf rows_of, WOf w_of, BOf b_of, XOf x_of, Emit emit) {
+    const int tid = threadIdx.x, g8 = tid >> 3, j = tid & 7;
+    const int total = n_mat * rows_pad, step = TB_NT / 8;
+    for (int row0 = 0; row0 < total; row0 += step) {        // (whole passes: the shuffles need every lane)
+        const int row = row0 + g8;
+        const int mi = row / rows_pad, r = row - mi * rows_pad;
+        const bool live = row < total && r < rows_of(mi);
+        float v[TB_MAXB];
+#pragma unroll
+        for (int b = 0; b < TB_MAXB; ++b) v[b] = 0.f;
+        if (live) {
+            const float* W = w_of(mi) + r * I;
+#pragma unroll 4
+            for (int i = j; i < I; i += 8) {
+                const float wv = W[i];
+#pragma unroll
+                for (int b = 0; b < TB_MAXB; ++b)
+                    if (b < B) v[b] = fmaf(wv, x_of(mi, b)[i], v[b]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < TB_MAXB; ++b) {
+            if (b < B) {
+                float t = v[b];
+                t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
+                if (live && j == 0) emit(mi, r, b, t + b_of(mi)[r]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(TB_NT) void time_branch_kernel(const TBArgs a) {
+    const bnerv_time_branch_desc& d = a.d;
+    extern __shared__ __attribute__((aligned(16))) float tb_smem[];
+    __shared__ __attribute__((aligned(16))) float s_pe[TB_MAXB][TB_MAXI];
+    __shared__ __attribute__((aligned(16))) float s_t0[TB_MAXB][TB_MAXT];
+    __shared__ __attribute__((aligned(16))) float s_zt[TB_MAXB][TB_MAXT];
+    __shared__ __attribute__((aligned(16))) float s_h[TB_MAXM][TB_MAXB][TB_MAXO];
+    __shared__ __attribute__((aligned(16))) float s_o[TB_MAXB][TB_MAXH];
+    __shared__ float s_bias[2 * TB_MAXT + TB_MAXM * (TB_MAXO + TB_MAXC)];
+    const int tid = threadIdx.x;
+    const int B = d.B, L = d.L, I = 2 * d.L, TO = d.TO;
+    const bool stem_role = (int)blockIdx.x < a.nb_stem;
+    const int cb = (int)blockIdx.x - a.nb_stem;              // chain block index
+    // ---- chain blocks: request EVERY weight and bias of the block's chain NOW (the PE below overlaps the flight): one exposed latency
+    float* w_t0 = tb_smem;                                   // [TH][I]
+    float* w_t1 = w_t0 + d.TH * I;                           // [TO][TH]
+    float* w_m = w_t1 + TO * d.TH;                           // per MLP of this block: [TO][TO] then [cmax][TO]
+    const int mstride = TO * TO + a.cmax * TO;
+    float* b_t0 = s_bias; float* b_t1 = s_bias + TB_MAXT; float* b_m = s_bias + 2 * TB_MAXT;     // per MLP: [TO] then [cmax]
+    const int bstride = TB_MAXO + TB_MAXC;
+    const int m0 = cb * a.mlps_per_block, nm = stem_role ? 0 : max(0, min(a.mlps_per_block, d.n_mlp - m0));
+    const int sr0 = (int)blockIdx.x * a.rows_per_block, snr = stem_role ? min(a.rows_per_block, d.SH - sr0) : 0;
+    if (stem_role) {
+        if (tid < snr) s_bias[tid] = d.sb0 ? d.sb0[sr0 + tid] : 0.f;        // (visible behind the barrier that follows the PE)
+    } else {
+        auto stage = [&](const float* __restrict__ src, float* dst, const int n) {          // n % 4 == 0, 16-byte aligned (launcher)
+            for (int i = tid * 4; i < n; i += TB_NT * 4) *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(src + i);
+        };
+        auto stage1 = [&](const float* __restrict__ src, float* dst, const int n) {
+            for (int i = tid; i < n; i += TB_NT) dst[i] = src ? src[i] : 0.f;
+        };
+        stage(d.tw0, w_t0, d.TH * I);
+        stage(d.tw1, w_t1, TO * d.TH);
+        stage1(d.tb0, b_t0, d.TH);
+        stage1(d.tb1, b_t1, TO);
+        for (int k = 0; k < nm; ++k) {
+            const TBMlp& mm = a.m[m0 + k];
+            stage(mm.w1, w_m + k * mstride, TO * TO);
+            stage(mm.w2, w_m + k * mstride + TO * TO, mm.C * TO);
+            stage1(mm.b1, b_m + k * bstride, TO);
+            stage1(mm.b2, b_m + k * bstride + TB_MAXO, mm.C);
+        }
+    }
+    // ---- positional encoding (model_blocks.py:120-126): ONE IEEE fp32 multiply, accurate sinf / cosf; fp64 positions rounded to fp32 first
+    for (int e = tid; e < B * L; e += TB_NT) {
+        const int n = e / L, l = e - n * L;
+        const float v = __fmul_rn((float)d.pos[n], d.bases[l]);
+        const float sv = sinf(v), cv = cosf(v);
+        s_pe[n][l] = sv; s_pe[n][L + l] = cv;
+        if (cb == 0) { d.pe[(size_t)n * I + l] = sv; d.pe[(size_t)n * I + L + l] = cv; }
+    }
+    __syncthreads();
+    if (stem_role) {
+        // this block's rows of stem layer 0 (weights straight from memory: each row is read by exactly one block)
+        tb_rows16<TB_MAXI>(d.sw0 + (size_t)sr0 * I, nullptr, I, snr, s_pe, &s_o[0][0], TB_MAXH, B);
+        __syncthreads();
+        for (int e = tid; e < B * snr; e += TB_NT) {
+            const int b = e / snr, r = e - b * snr;
+            float sv, cv;
+            sincosf(s_o[b][r] + s_bias[r], &sv, &cv);
+            d.sy0[(size_t)b * d.SH + sr0 + r] = sv;
+            d.saux0[(size_t)b * d.SH + sr0 + r] = cv;
+        }
+        return;
+    }
+    // ---- chain: stem_t layer 0, layer 1 (z_t), then this block's modulation MLPs -- both layers of all of them at once -- from LDS
+    tb_rows16<TB_MAXI>(w_t0, b_t0, I, d.TH, s_pe, &s_t0[0][0], TB_MAXT, B);
+    __syncthreads();
+    for (int e = tid; e < B * d.TH; e += TB_NT) {
+        const int b = e / d.TH, r = e - b * d.TH;
+        float sv, cv;
+        sincosf(s_t0[b][r], &sv, &cv);
+        s_t0[b][r] = sv;
+        if (cb == 0) { d.ty0[(size_t)b * d.TH + r] = sv; d.taux0[(size_t)b * d.TH + r] = cv; }
+    }
+    __syncthreads();
+    tb_rows16<TB_MAXT>(w_t1, b_t1, d.TH, TO, s_t0, &s_zt[0][0], TB_MAXT, B);
+    __syncthreads();
+    for (int e = tid; e < B * TO; e += TB_NT) {
+        const int b = e / TO, r = e - b * TO;
+        float sv, cv;
+        sincosf(s_zt[b][r], &sv, &cv);
+        s_zt[b][r] = sv;
+        if (cb == 0) { d.ty1[(size_t)b * TO + r] = sv; d.taux1[(size_t)b * TO + r] = cv; }
+    }
+    __syncthreads();
+    tb_multi8(nm, TO, TO, B, [&](int) { return TO; }, [&](int k) { return w_m + k * mstride; }, [&](int k) { return b_m + k * bstride; },
+              [&](int, int b) { return &s_zt[b][0]; },
+              [&](int k, int r, int b, float v) { const float y = fmaxf(v, 0.f); s_h[k][b][r] = y; a.m[m0 + k].hs[(size_t)b * TO + r] = y; });
+    __syncthreads();
+    tb_multi8(nm, a.cmax, TO, B, [&](int k) { return a.m[m0 + k].C; }, [&](int k) { return w_m + k * mstride + TO * TO; }, [&](int k) { return b_m + k * bstride + TB_MAXO; },
+              [&](int k, int b) { return &s_h[k][b][0]; },
+              [&](int k, int r, int b, float v) { a.m[m0 + k].out[(size_t)b * a.m[m0 + k].C + r] = v; });
+}
+
 // Descriptor tables travel BY VALUE in the kernel-argument segment (<= 4 KB: BNERV_MAX_DENSE_GROUPS * 88 B), so a captured
 // hipGraph replays them without touching host memory.
 extern "C" int bnerv_dense_grouped_fwd(void* stream, const bnerv_dense_fwd_desc* groups, int n_groups, int B) {
@@ -312,5 +491,40 @@ extern "C" int bnerv_reduce_slabs(void* stream, const float* slabs, int n_slabs,
     else
         hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(cdiv(count, 4)), dim3(1024), 0, (hipStream_t)stream, slabs, n_slabs, count, out);
     BNERV_LAUNCH_CHECK("reduce_slabs");
+    return BNERV_OK;
+}
+
+// 1: not this launch's branch (the caller issues the grouped launches); BNERV_OK; negative BNERV_E_*.
+extern "C" int bnerv_time_branch_fwd(void* stream, const bnerv_time_branch_desc* dp, const bnerv_time_branch_mlp* mlps) {
+    BNERV_REQUIRE(dp && (mlps || dp->n_mlp == 0), "time_branch_fwd: null descriptor");
+    const bnerv_time_branch_desc& d = *dp;
+    BNERV_REQUIRE(d.pos && d.bases && d.pe && d.sw0 && d.sy0 && d.saux0 && d.tw0 && d.tw1 && d.ty0 && d.taux0 && d.ty1 && d.taux1, "time_branch_fwd: null tensor");
+    BNERV_REQUIRE(d.B > 0 && d.L > 0 && d.SH > 0 && d.TH > 0 && d.TO > 0 && d.n_mlp >= 0, "time_branch_fwd: bad shape");
+    if (d.B > TB_MAXB || 2 * d.L > TB_MAXI || d.SH > 4096 || d.TH > TB_MAXT || d.TO > TB_MAXO || d.n_mlp > BNERV_MAX_DENSE_GROUPS) return 1;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    if ((2 * d.L) % 4 || d.TH % 4 || d.TO % 4 || !al16(d.tw0) || !al16(d.tw1)) return 1;                 // 16-byte staging of the chain's weights
+    TBArgs a;
+    a.d = d;
+    a.cmax = 4;
+    for (int i = 0; i < d.n_mlp; ++i) {
+        BNERV_REQUIRE(mlps[i].w1 && mlps[i].w2 && mlps[i].hs && mlps[i].out && mlps[i].C > 0, "time_branch_fwd: bad modulation MLP %d", i);
+        if (((mlps[i].C + 3) & ~3) > a.cmax) a.cmax = (mlps[i].C + 3) & ~3;
+        if (mlps[i].C > TB_MAXC || !al16(mlps[i].w1) || !al16(mlps[i].w2)) return 1;
+        a.m[i].w1 = mlps[i].w1; a.m[i].b1 = mlps[i].b1; a.m[i].w2 = mlps[i].w2; a.m[i].b2 = mlps[i].b2; a.m[i].hs = mlps[i].hs; a.m[i].out = mlps[i].out;
+        a.m[i].C = mlps[i].C; a.m[i]._pad = 0;
+    }
+    a.rows_per_block = 16;
+    a.nb_stem = cdiv(d.SH, a.rows_per_block);
+    a.mlps_per_block = d.n_mlp > 32 ? TB_MAXM : 2;           // 16 chain blocks for C1's 32 MLPs; at most 10 x 4
+    a.nb_chain = d.n_mlp > 0 ? cdiv(d.n_mlp, a.mlps_per_block) : 1;
+    const size_t lds = ((size_t)d.TH * 2 * d.L + (size_t)d.TO * d.TH + (size_t)a.mlps_per_block * ((size_t)d.TO * d.TO + (size_t)a.cmax * d.TO)) * sizeof(float);
+    if (lds > 100 * 1024) return 1;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&time_branch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(time_branch_kernel, dim3(a.nb_stem + a.nb_chain), dim3(TB_NT), lds, (hipStream_t)stream, a);
+    BNERV_LAUNCH_CHECK("time_branch");
     return BNERV_OK;
 }

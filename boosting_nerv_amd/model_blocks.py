@@ -142,6 +142,32 @@ def mlp_pair_forward(mlps, xs):
     return [h.view(B, -1, 1, 1) for h in hs]
 
 
+def time_branch_forward(pe_t, pos, stem, stem_t, sft_layers):
+    """NeRV_Boost's time-embedding branch -- pe_t(pos), the stem and stem_t MLPs on it, and the (scale, shift) modulations of every SFTLayer
+    in ``sft_layers`` from stem_t's output (model_nerv.py:47-51, model_blocks.py:92-105) -- as TWO launches (ops.time_branch) instead of five.
+    Returns (stem_out [B, C, 1, 1], t_embed [B, ch_t, 1, 1], [(scale_i, shift_i)]) or None when the branch is not the kernel's (other
+    activations, more than 4 frames per step, no positional encoding, quantised containers): the caller takes the layer-by-layer path."""
+    if "pe" not in pe_t.pe_embed or len(stem) != 4 or len(stem_t) != 4 or not sft_layers:
+        return None
+    if any(_act_name(m[i]) != "sin" for m in (stem, stem_t) for i in (1, 3)) or any(_act_name(l.act) != "relu" for l in sft_layers):
+        return None
+    if pe_t._dev_bases is None or pe_t._dev_bases.device != pos.device:
+        pe_t._dev_bases = pe_t.pe_bases.to(pos.device)
+    mlps = []
+    for l in sft_layers:
+        for c0, c1 in ((l.SFT_scale_conv0, l.SFT_scale_conv1), (l.SFT_shift_conv0, l.SFT_shift_conv1)):
+            mlps.append((c0.effective_weight(), c0.effective_bias(), c1.effective_weight(), c1.effective_bias()))
+    res = ops.time_branch(pos, pe_t._dev_bases,
+                          (stem[0].effective_weight(), stem[0].effective_bias(), stem[2].effective_weight(), stem[2].effective_bias()),
+                          (stem_t[0].effective_weight(), stem_t[0].effective_bias(), stem_t[2].effective_weight(), stem_t[2].effective_bias()), mlps)
+    if res is None:
+        return None
+    out, zt, mo = res
+    B = out.shape[0]
+    mods = [(mo[2 * i].view(B, -1, 1, 1), mo[2 * i + 1].view(B, -1, 1, 1)) for i in range(len(sft_layers))]
+    return out.view(B, -1, 1, 1), zt.view(B, -1, 1, 1), mods
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # TAT: SFTLayer / ResBlock_SFT                                                  reference model_blocks.py:74-105
 # ----------------------------------------------------------------------------------------------------------------------

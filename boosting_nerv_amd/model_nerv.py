@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from .model_blocks import *  # noqa: F401,F403
 from .model_blocks import (CustomConv2d, NeRV_MLP, NeRVBlock, PositionEncoding, head_out, mlp_pair_forward,
-                           tat_modulations)
+                           tat_modulations, time_branch_forward)
 from .lib.quant_ops import CustomLinear
 
 
@@ -190,13 +190,21 @@ class NeRV_Boost(_CEMHooks, nn.Module):
 
     def forward(self, input, input_embed=None, norm_idx=None):
         dec_start = time.time()
-        t_embed = self.pe_t(input[:, None], round_to_f32=True)     # pe_t(input[:, None].float()) without the conversion launch
-        output, t_embed = mlp_pair_forward([self.stem, self.stem_t], [t_embed, t_embed])
+        sfts = []
+        for layer in self.layers:
+            sfts += layer.sft_layers()
+        head = time_branch_forward(self.pe_t, input, self.stem, self.stem_t, sfts) if input.dtype == torch.float64 else None
+        if head is not None:                               # PE -> stem | stem_t -> every TAT modulation: TWO launches (ops.time_branch)
+            output, t_embed, mods = head
+        else:
+            t_embed = self.pe_t(input[:, None], round_to_f32=True)     # pe_t(input[:, None].float()) without the conversion launch
+            output, t_embed = mlp_pair_forward([self.stem, self.stem_t], [t_embed, t_embed])
+            mods = None
         output = output.view(output.size(0), self.fc_dim, self.fc_h, self.fc_w)
         if self.dp_hook is not None and output.requires_grad:
             output.register_hook(self.dp_hook)             # fires when every decoder layer's backward has run (engine.TrainStep, two buckets)
         out_list = []
-        output = decoder_layers_forward(self.layers, output, t_embed, out_list)
+        output = decoder_layers_forward(self.layers, output, t_embed, out_list, mods=mods)
         img_out = head_out(self.head_layer, output, self.out_bias)
         if self.time_decode and torch.cuda.is_available():
             torch.cuda.synchronize()

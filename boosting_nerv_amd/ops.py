@@ -334,6 +334,96 @@ def dense_gemm(x, w, b, act="none"):
     return _DenseGemm.apply(x, w, b, _ACT[act])
 
 
+class _TimeBranch(torch.autograd.Function):
+    """PositionEncoding -> stem layer 0 | stem_t (both layers) -> every TAT modulation MLP as ONE launch (include/bnerv.h
+    bnerv_time_branch_fwd), then the stem's second layer as the ordinary grouped launch: 2 launches for the reference's chain of
+    model_nerv.py:47-51 / model_blocks.py:92-105 instead of 5.  The backward is the unchanged grouped dense backward of the four depths."""
+
+    @staticmethod
+    def forward(ctx, pos, bases, n_mlp, *params):
+        lib = L.load()
+        dev = pos.device
+        B, Lv = pos.shape[0], bases.numel()
+        p2 = [L.f32c(t).reshape(t.shape[0], -1) if t.dim() > 1 else L.f32c(t) for t in params]
+        sw0, sb0, sw1, sb1, tw0, tb0, tw1, tb1 = p2[:8]
+        mw = p2[8:]
+        SH, SO, TH, TO = sw0.shape[0], sw1.shape[0], tw0.shape[0], tw1.shape[0]
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        pe, sy0, saux0, sy1, saux1 = f(B, 2 * Lv), f(B, SH), f(B, SH), f(B, SO), f(B, SO)
+        ty0, taux0, ty1, taux1 = f(B, TH), f(B, TH), f(B, TO), f(B, TO)
+        hs = [f(B, TO) for _ in range(n_mlp)]
+        outs = [f(B, mw[4 * i + 2].shape[0]) for i in range(n_mlp)]
+        d = L.TimeBranchDesc(L.ptr(pos), L.ptr(bases), L.ptr(pe), L.ptr(sw0), L.ptr(sb0), L.ptr(sy0), L.ptr(saux0),
+                             L.ptr(tw0), L.ptr(tb0), L.ptr(tw1), L.ptr(tb1), L.ptr(ty0), L.ptr(taux0), L.ptr(ty1), L.ptr(taux1), B, Lv, SH, TH, TO, n_mlp)
+        ml = (L.TimeBranchMlp * max(n_mlp, 1))()
+        for i in range(n_mlp):
+            w1, b1, w2, b2 = mw[4 * i:4 * i + 4]
+            ml[i].w1, ml[i].b1, ml[i].w2, ml[i].b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+            ml[i].hs, ml[i].out, ml[i].C = hs[i].data_ptr(), outs[i].data_ptr(), w2.shape[0]
+        rc = lib.bnerv_time_branch_fwd(L.stream(), C.byref(d), ml)
+        if rc != 0:
+            L.check(rc if rc < 0 else -1, "bnerv_time_branch_fwd (shapes were checked by ops.time_branch)")
+        g = (L.DenseFwdDesc * 1)(L.DenseFwdDesc(L.ptr(sy0), L.ptr(sw1), L.ptr(sb1), L.ptr(sy1), L.ptr(saux1), SH, SO, L.ACT_SIN, 0))
+        L.check(lib.bnerv_dense_grouped_fwd(L.stream(), g, 1, B), "bnerv_dense_grouped_fwd")
+        ctx.n_mlp, ctx.B = n_mlp, B
+        ctx.pshapes = [tuple(t.shape) for t in params]
+        ctx.save_for_backward(pe, sy0, saux0, sy1, saux1, ty0, taux0, ty1, taux1, *hs, *outs, *p2)
+        return (sy1, ty1, *outs)
+
+    @staticmethod
+    def backward(ctx, d_sy1, d_ty1, *d_outs):
+        if _lazy_depth > 0:
+            _flush_deferred()               # the modulation gradients are deferred slab reductions of the TAT blocks
+        n, B = ctx.n_mlp, ctx.B
+        sv = ctx.saved_tensors
+        pe, sy0, saux0, sy1, saux1, ty0, taux0, ty1, taux1 = sv[:9]
+        hs, outs, p2 = sv[9:9 + n], sv[9 + n:9 + 2 * n], sv[9 + 2 * n:]
+        sw0, sb0, sw1, sb1, tw0, tb0, tw1, tb1 = p2[:8]
+        mw = p2[8:]
+        none, relu, sin = L.ACT_NONE, L.ACT_RELU, L.ACT_SIN
+        g = [None] * len(p2)
+        d_zt = d_ty1
+        if n:
+            w1s, w2s = [mw[4 * i] for i in range(n)], [mw[4 * i + 2] for i in range(n)]
+            dx4, dw4, db4 = _dense_grouped_bwd([none] * n, hs, w2s, outs, [None] * n, d_outs, [True] * n, [True] * n, False, B)
+            dx3, dw3, db3 = _dense_grouped_bwd([relu] * n, [ty1] * n, w1s, hs, [None] * n, dx4, [True] * n, [True] * n, True, B)
+            tot = next(t for t in dx3 if t is not None)
+            d_zt = tot if d_ty1 is None else tot + L.f32c(d_ty1).reshape(tot.shape)
+            for i in range(n):
+                g[8 + 4 * i], g[8 + 4 * i + 1], g[8 + 4 * i + 2], g[8 + 4 * i + 3] = dw3[i], db3[i], dw4[i], db4[i]
+        dx2, dw2, db2 = _dense_grouped_bwd([sin, sin], [sy0, ty0], [sw1, tw1], [sy1, ty1], [saux1, taux1], [d_sy1, d_zt], [True, True], [True, True], False, B)
+        dx1, dw1, db1 = _dense_grouped_bwd([sin, sin], [pe, pe], [sw0, tw0], [sy0, ty0], [saux0, taux0], dx2, [False, False], [True, True], True, B)
+        g[0], g[1], g[2], g[3] = dw1[0], db1[0], dw2[0], db2[0]
+        g[4], g[5], g[6], g[7] = dw1[1], db1[1], dw2[1], db2[1]
+        g = [None if t is None else t.reshape(sh) for t, sh in zip(g, ctx.pshapes)]
+        return (None, None, None, *g)
+
+
+def time_branch(pos, bases, stem, stem_t, mlps):
+    """pos [B] fp64, bases fp32 [L]; stem / stem_t = (w0, b0, w1, b1) of the two 2-layer sin MLPs; mlps = [(w1, b1, w2, b2), ...] of the TAT
+    modulation branches (relu inside).  Returns (stem_out [B, SO], z_t [B, TO], [out_i [B, C_i]]), or None when the shapes are not the
+    kernel's (the caller runs the five grouped launches).  BNERV_TIME_BRANCH=0 switches it off (A/B)."""
+    if os.environ.get("BNERV_TIME_BRANCH", "1") == "0" or pos.dtype != torch.float64 or not pos.is_cuda or pos.dim() != 1:
+        return None
+    B, Lv = pos.shape[0], bases.numel()
+    if any(t is None for t in (*stem, *stem_t)) or any(t is None for m in mlps for t in m):
+        return None
+    fl = lambda t: t.reshape(t.shape[0], -1).shape
+    SH, TH, TO = stem[0].shape[0], stem_t[0].shape[0], stem_t[2].shape[0]
+    if B > 4 or 2 * Lv > 256 or (2 * Lv) % 4 or TH > 64 or TH % 4 or TO > 32 or TO % 4 or len(mlps) > L.MAX_DENSE_GROUPS:
+        return None
+    # every layer must have the width the kernel indexes with (an SFTLayer built with factor != 1 has a narrower hidden layer)
+    if fl(stem[0])[1] != 2 * Lv or fl(stem_t[0])[1] != 2 * Lv or fl(stem[2])[1] != SH or fl(stem_t[2])[1] != TH:
+        return None
+    if any(fl(m[0]) != (TO, TO) or fl(m[2])[1] != TO or fl(m[2])[0] > 128 for m in mlps):
+        return None
+    if any(t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 for t in (stem_t[0], stem_t[2], *[m[0] for m in mlps], *[m[2] for m in mlps])):
+        return None
+    flat = [t for m in mlps for t in m]
+    out = _TimeBranch.apply(pos.contiguous(), bases.to(device=pos.device, dtype=torch.float32).contiguous(), len(mlps), *stem, *stem_t, *flat)
+    return out[0], out[1], list(out[2:])
+
+
 def dense_grouped(xs, ws, bs, acts):
     """Evaluate n independent dense layers y_i = act_i(W_i x_i + b_i).
     xs[i]: [B, I_i(,1,1)], ws[i]: [O_i, I_i(,1,1)], bs[i]: [O_i] or None, acts[i] in {'none','relu','sin'}.

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BNERV_ABI_VERSION 7
+#define BNERV_ABI_VERSION 8
 
 #define BNERV_OK 0
 #define BNERV_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -87,6 +87,28 @@ typedef struct {
 
 int bnerv_dense_grouped_fwd(void* stream, const bnerv_dense_fwd_desc* groups, int n_groups, int B);
 int bnerv_dense_grouped_bwd(void* stream, const bnerv_dense_bwd_desc* groups, int n_groups, int B);
+
+/* The time-embedding branch of NeRV_Boost.forward except the stem's second layer, as ONE launch (ABI 8; csrc/dense.hip):
+ *   pe = PositionEncoding(pos)                               model_nerv.py:47, model_blocks.py:120-126   (fp64 position rounded to fp32 first)
+ *   stem layer 0 : sy0 = sin(sw0 pe + sb0) [SH]                                model_nerv.py:48-50, NeRV_MLP model_blocks.py:66-71
+ *   stem_t       : ty0 = sin(tw0 pe + tb0) [TH];  ty1 = sin(tw1 ty0 + tb1) [TO] = z_t
+ *   every TAT modulation MLP i:  hs_i = relu(w1_i z_t + b1_i) [TO];  out_i = w2_i hs_i + b2_i [C_i]          SFTLayer, model_blocks.py:92-105
+ * (the stem's second layer follows as an ordinary bnerv_dense_grouped_fwd launch).  Every tensor the five-launch form leaves behind --
+ * outputs and the cosines saux0 / taux* of the sin layers -- is written, so the backward is the unchanged bnerv_dense_grouped_bwd sequence.
+ * Requires w1_i [TO, TO] and w2_i [C_i, TO] row-major, sw0 / tw0 [*, 2L].  Returns 1 when the shapes are not this kernel's (B > 4, 2L > 256,
+ * TH > 64, TO > 32, C_i > 128, more than BNERV_MAX_DENSE_GROUPS MLPs, unaligned weights): the caller issues the grouped launches. */
+typedef struct { const float* w1; const float* b1; const float* w2; const float* b2; float* hs; float* out; int C; int _pad; } bnerv_time_branch_mlp;
+typedef struct {
+    const double* pos;     /* [B] */
+    const float* bases;    /* [L] */
+    float* pe;             /* [B, 2L] */
+    const float* sw0; const float* sb0;                                          /* stem layer 0: [SH, 2L], [SH] */
+    float* sy0; float* saux0;                                                    /* [B, SH] x 2 */
+    const float* tw0; const float* tb0; const float* tw1; const float* tb1;      /* stem_t: [TH, 2L], [TH], [TO, TH], [TO] */
+    float* ty0; float* taux0; float* ty1; float* taux1;                          /* [B, TH] x 2, [B, TO] x 2 */
+    int B, L, SH, TH, TO, n_mlp;
+} bnerv_time_branch_desc;
+int bnerv_time_branch_fwd(void* stream, const bnerv_time_branch_desc* d, const bnerv_time_branch_mlp* mlps /* [n_mlp] */);
 
 /* Stand-alone TAT affine  y = x*(scale[b,c]+1) + shift[b,c]  (SFTLayer.forward, model_blocks.py:101-105) and its backward:
  *   dx = g*(scale+1);  part[chunk][0][b,c] = sum_chunk g*x;  part[chunk][1][b,c] = sum_chunk g

@@ -68,6 +68,57 @@ def test_tiny_models_against_reference_goldens(name, cfg):
             assert err <= 5e-3 * max(gn, float(ref.abs().max())) + 1e-6, (k, err, gn)
 
 
+@pytest.mark.parametrize("B", [1, 2, 4])
+def test_time_branch_two_launches_equal_the_five_launch_form(B, monkeypatch):
+    """NeRV_Boost's time-embedding branch (PE -> stem | stem_t -> every TAT modulation MLP, model_nerv.py:47-51, model_blocks.py:92-105)
+    as the one-launch kernel + the stem's second layer (ops.time_branch, include/bnerv.h bnerv_time_branch_fwd) against the five grouped
+    launches it replaces: image, every returned stage and every parameter gradient of the tiny model (the kernel writes the same saved
+    tensors; the backward is the same grouped dense backward), and the quantities themselves against float64: PE with its large arguments,
+    sin layers, relu MLPs."""
+    from boosting_nerv_amd import hnerv_utils as hu
+    args = configs.tiny_nerv()
+    torch.manual_seed(1)
+    model = _build("tiny_nerv", args).to(DEV)
+    norm_idx = torch.tensor([(i + 1) / 7 for i in range(B)], dtype=torch.float64, device=DEV)
+    frame = torch.rand(B, 3, 180, 320, generator=torch.Generator().manual_seed(3)).to(DEV)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BNERV_TIME_BRANCH", flag)
+        model.zero_grad(set_to_none=True)
+        img, lst, _ = model(norm_idx, norm_idx=norm_idx)
+        hu.loss_fn(img, frame, "L1_freq").backward()
+        res[flag] = (img.detach().clone(), [t.detach().clone() for t in lst], {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    a, b = res["1"], res["0"]
+    torch.testing.assert_close(a[0], b[0], rtol=1e-4, atol=2e-6)
+    for x, y in zip(a[1], b[1]):
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-6)
+    for k in a[2]:
+        ga, gb = a[2][k], b[2][k]
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-9, (k, float((ga - gb).abs().max()), float(gb.abs().max()))
+    # the branch's own outputs against float64 (stock ops)
+    sfts = []
+    for layer in model.layers:
+        sfts += layer.sft_layers()
+    monkeypatch.setenv("BNERV_TIME_BRANCH", "1")
+    from boosting_nerv_amd.model_blocks import time_branch_forward
+    with torch.no_grad():
+        got = time_branch_forward(model.pe_t, norm_idx, model.stem, model.stem_t, sfts)
+        assert got is not None, "the tiny NeRV_Boost's branch must be the kernel's"
+        out, zt, mods = got
+        pe = torch.cat([torch.sin(norm_idx.float()[:, None] * model.pe_t.pe_bases.to(DEV)), torch.cos(norm_idx.float()[:, None] * model.pe_t.pe_bases.to(DEV))], 1).double()
+        f = lambda m, x: torch.sin(x @ m.weight.double().flatten(1).T + m.bias.double())
+        ref_out = f(model.stem[2], f(model.stem[0], pe))
+        ref_zt = f(model.stem_t[2], f(model.stem_t[0], pe))
+        torch.testing.assert_close(out.flatten(1).double(), ref_out, rtol=1e-4, atol=2e-5)       # (sin of O(1) sums of 160 / 256 products in fp32)
+        torch.testing.assert_close(zt.flatten(1).double(), ref_zt, rtol=1e-4, atol=2e-5)
+        for li in (0, len(sfts) - 1):
+            l0 = sfts[li]
+            h = torch.relu(ref_zt @ l0.SFT_scale_conv0.weight.double().flatten(1).T + l0.SFT_scale_conv0.bias.double())
+            torch.testing.assert_close(mods[li][0].flatten(1).double(), h @ l0.SFT_scale_conv1.weight.double().flatten(1).T + l0.SFT_scale_conv1.bias.double(), rtol=1e-4, atol=2e-5)
+            h = torch.relu(ref_zt @ l0.SFT_shift_conv0.weight.double().flatten(1).T + l0.SFT_shift_conv0.bias.double())
+            torch.testing.assert_close(mods[li][1].flatten(1).double(), h @ l0.SFT_shift_conv1.weight.double().flatten(1).T + l0.SFT_shift_conv1.bias.double(), rtol=1e-4, atol=2e-5)
+
+
 def test_c1_full_size_against_reference_golden():
     """BASELINE config C1/C2 (NeRV-boost 1.5M, 720x1280): seeded init identical to the reference, forward / loss / gradient
     norms against the reference's own run."""

@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-export BNERV_TEST_TRAIL=$PWD/gpurun_out/r05n_trail.txt
-timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -p no:cacheprovider > gpurun_out/r05n_ops.log 2>&1; echo "ops rc=$?"; grep -v "bnerv-trail" gpurun_out/r05n_ops.log | tail -3 | cut -c1-300
-timeout 600 python -m pytest tests/test_gpu_models.py -x -q -m gpu -p no:cacheprovider -k "tiny_models or c1_full or trajectory or reproducible or big_models_full" > gpurun_out/r05n_models.log 2>&1; echo "models rc=$?"; grep -v "bnerv-trail" gpurun_out/r05n_models.log | tail -3 | cut -c1-300
-TIMELINE=1 tools/ab_steps.sh r05n c1 "BNERV_PAIR_STEM=0" "BNERV_PAIR_STEM=1"
+export BNERV_TEST_TRAIL=$PWD/gpurun_out/r05p_trail.txt
+timeout 900 python -m pytest tests/test_gpu_models.py -x -q -m gpu -p no:cacheprovider -k "time_branch or tiny_models or c1_full or trajectory or reproducible or decode" > gpurun_out/r05p_models.log 2>&1; echo "models rc=$?"; grep -v "bnerv-trail" gpurun_out/r05p_models.log | tail -25 | cut -c1-300
+TIMELINE=1 tools/ab_steps.sh r05p c1 "BNERV_TIME_BRANCH=0" "BNERV_TIME_BRANCH=1"
