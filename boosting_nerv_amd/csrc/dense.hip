@@ -150,17 +150,27 @@ __device__ __forceinline__ void dense_bwd_x_body(const BwdArgs& a, const int bx,
     }
 }
 
-struct BwdGrid { int wx, wy, wz, xx, xy, xz; };
+// Block -> (group, row block, column chunk) through per-group prefix sums: every group gets exactly the blocks ITS shape needs.  (Until round 5
+// the grid was (largest O / 4) x groups x (largest I / chunk): fine for the equal-sized groups of a forward launch's backward, but a launch that
+// mixes the stem's 4320-row layer with 32 modulation layers of 12..32 rows started 37 884 blocks of which 1 400 had work: 34 us.)
+struct BwdGrid { int nw, wpre[BNERV_MAX_DENSE_GROUPS + 1], xpre[BNERV_MAX_DENSE_GROUPS + 1]; int n_groups, B; };
 __global__ __launch_bounds__(256) void dense_bwd_kernel(const BwdArgs a, const BwdGrid q) {
-    const int nw = q.wx * q.wy * q.wz;
     int t = blockIdx.x;
-    if (t < nw) {                                          // block-uniform
-        const int bx = t % q.wx; t /= q.wx;
-        dense_bwd_w_body(a, bx, t % q.wy, t / q.wy);
+    const int* pre = t < q.nw ? q.wpre : q.xpre;          // block-uniform
+    const bool wphase = t < q.nw;
+    if (!wphase) t -= q.nw;
+    // group of block t: the number of prefix entries pre[1 .. n_groups - 1] that are <= t -- one compare per lane and a ballot (a scalar walk
+    // over up to 40 entries is 40 dependent scalar loads on the critical path of every block of the last group)
+    const int ln = threadIdx.x & 63;
+    const bool ge = ln + 1 < q.n_groups && t >= pre[ln + 1];
+    const int gi = __popcll(__ballot(ge));
+    t -= pre[gi];
+    if (wphase) {
+        const int wx = (a.g[gi].O + 3) >> 2;               // row blocks of this group; t = bz * wx + bx
+        dense_bwd_w_body(a, t % wx, gi, t / wx);
     } else {
-        t -= nw;
-        const int bx = t % q.xx; t /= q.xx;
-        dense_bwd_x_body(a, bx, t % q.xy, t / q.xy);
+        const int xx = (a.g[gi].O + BNERV_DENSE_DX_CHUNK - 1) / BNERV_DENSE_DX_CHUNK;      // t = b * xx + chunk
+        dense_bwd_x_body(a, t % xx, t / xx, gi);
     }
 }
 
@@ -461,9 +471,17 @@ extern "C" int bnerv_dense_grouped_bwd(void* stream, const bnerv_dense_bwd_desc*
         any_dx |= g.dx_part != nullptr;
     }
     hipStream_t st = (hipStream_t)stream;
-    BwdGrid q{cdiv(maxO, 4), n_groups, cdiv(maxI, DW_CHUNK), 0, 0, 0};
-    if (any_dx) { q.xx = cdiv(maxO, BNERV_DENSE_DX_CHUNK); q.xy = B; q.xz = n_groups; }
-    hipLaunchKernelGGL(dense_bwd_kernel, dim3(q.wx * q.wy * q.wz + q.xx * q.xy * q.xz), dim3(256), 0, st, a, q);
+    BwdGrid q;
+    q.n_groups = n_groups; q.B = B;
+    int nw = 0, nx = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        q.wpre[i] = nw; q.xpre[i] = nx;
+        nw += cdiv(groups[i].O, 4) * cdiv(groups[i].I, DW_CHUNK);
+        if (groups[i].dx_part) nx += cdiv(groups[i].O, BNERV_DENSE_DX_CHUNK) * B;
+    }
+    q.wpre[n_groups] = nw; q.xpre[n_groups] = nx; q.nw = nw;
+    (void)maxO; (void)maxI; (void)any_dx;
+    hipLaunchKernelGGL(dense_bwd_kernel, dim3(nw + nx), dim3(256), 0, st, a, q);
     BNERV_LAUNCH_CHECK("dense_bwd");
     return BNERV_OK;
 }

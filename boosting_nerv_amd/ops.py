@@ -233,9 +233,11 @@ class _DenseGrouped(torch.autograd.Function):
         return (None, None) + tuple(dxs) + tuple(dws) + tuple(dbs)
 
 
-def _dense_grouped_bwd(acts, xc, wc, ys, auxs, dys, need_x, has_b, same_x, B):
+def _dense_grouped_bwd(acts, xc, wc, ys, auxs, dys, need_x, has_b, same_x, B, defer_reduce=False):
     """Backward of n grouped dense layers y_i = act_i(W_i x_i + b_i) (bnerv_dense_grouped_bwd): returns ([dx_i or None], [dW_i [O, I]], [db_i or
-    None]).  same_x: every layer read the SAME input tensor -- its gradient is the sum over the layers, returned in the first needed slot."""
+    None]).  same_x: every layer read the SAME input tensor -- its gradient is the sum over the layers, returned in the first needed slot.
+    defer_reduce: input gradients that need a slab reduction (shared inputs, layers wider than one dx chunk) are QUEUED on the stream context
+    (deferred slab reductions, _reduce_slabs(defer=True)) instead of launched: the caller flushes once for several of them."""
     n = len(xc)
     lib = L.load()
     dev = ys[0].device
@@ -272,7 +274,7 @@ def _dense_grouped_bwd(acts, xc, wc, ys, auxs, dys, need_x, has_b, same_x, B):
     dxs = [None] * n
     if shared:
         tot = torch.empty(B, I0, dtype=torch.float32, device=dev)
-        _reduce_slabs(shared_buf, n, B * I0, tot)
+        _reduce_slabs(shared_buf, n, B * I0, tot, defer=defer_reduce)
         first = next(i for i in range(n) if need_x[i])
         dxs[first] = tot               # the same tensor was passed n times: its whole gradient goes to one slot
     else:
@@ -284,7 +286,7 @@ def _dense_grouped_bwd(acts, xc, wc, ys, auxs, dys, need_x, has_b, same_x, B):
             else:
                 I = wc[i].shape[1]
                 tot = torch.empty(B, I, dtype=torch.float32, device=dev)
-                _reduce_slabs(dxps[i], nchunks[i], B * I, tot)
+                _reduce_slabs(dxps[i], nchunks[i], B * I, tot, defer=defer_reduce)
                 dxs[i] = tot
     return dxs, dws, dbs
 
@@ -368,10 +370,17 @@ class _TimeBranch(torch.autograd.Function):
         ctx.n_mlp, ctx.B = n_mlp, B
         ctx.pshapes = [tuple(t.shape) for t in params]
         ctx.save_for_backward(pe, sy0, saux0, sy1, saux1, ty0, taux0, ty1, taux1, *hs, *outs, *p2)
+        # z_t has no consumer besides the modulation MLPs when they are all evaluated here: autograd would otherwise materialise a zero
+        # gradient for it (a fill launch) and the backward would add it (another launch)
+        ctx.set_materialize_grads(False)
         return (sy1, ty1, *outs)
 
     @staticmethod
     def backward(ctx, d_sy1, d_ty1, *d_outs):
+        """Five launches instead of the layer-by-layer backward's six (and one reduction launch instead of two): the branches' levels are
+        grouped by what is READY, not by which forward launch they came from --
+            [every modulation MLP's layer 1 | the stem's layer 1]  ->  [every MLP's layer 0]  ->  ONE flush of both pending input-gradient
+            reductions (z_t's over the 32 MLPs, the stem's 68 chunks)  ->  [stem_t layer 1 | stem layer 0]  ->  [stem_t layer 0]."""
         if _lazy_depth > 0:
             _flush_deferred()               # the modulation gradients are deferred slab reductions of the TAT blocks
         n, B = ctx.n_mlp, ctx.B
@@ -382,19 +391,26 @@ class _TimeBranch(torch.autograd.Function):
         mw = p2[8:]
         none, relu, sin = L.ACT_NONE, L.ACT_RELU, L.ACT_SIN
         g = [None] * len(p2)
-        d_zt = d_ty1
-        if n:
-            w1s, w2s = [mw[4 * i] for i in range(n)], [mw[4 * i + 2] for i in range(n)]
-            dx4, dw4, db4 = _dense_grouped_bwd([none] * n, hs, w2s, outs, [None] * n, d_outs, [True] * n, [True] * n, False, B)
-            dx3, dw3, db3 = _dense_grouped_bwd([relu] * n, [ty1] * n, w1s, hs, [None] * n, dx4, [True] * n, [True] * n, True, B)
-            tot = next(t for t in dx3 if t is not None)
-            d_zt = tot if d_ty1 is None else tot + L.f32c(d_ty1).reshape(tot.shape)
-            for i in range(n):
-                g[8 + 4 * i], g[8 + 4 * i + 1], g[8 + 4 * i + 2], g[8 + 4 * i + 3] = dw3[i], db3[i], dw4[i], db4[i]
-        dx2, dw2, db2 = _dense_grouped_bwd([sin, sin], [sy0, ty0], [sw1, tw1], [sy1, ty1], [saux1, taux1], [d_sy1, d_zt], [True, True], [True, True], False, B)
-        dx1, dw1, db1 = _dense_grouped_bwd([sin, sin], [pe, pe], [sw0, tw0], [sy0, ty0], [saux0, taux0], dx2, [False, False], [True, True], True, B)
-        g[0], g[1], g[2], g[3] = dw1[0], db1[0], dw2[0], db2[0]
-        g[4], g[5], g[6], g[7] = dw1[1], db1[1], dw2[1], db2[1]
+        w1s, w2s = [mw[4 * i] for i in range(n)], [mw[4 * i + 2] for i in range(n)]
+        if n + 1 > L.MAX_DENSE_GROUPS or n == 0:
+            raise L.BnervError("time branch backward: group count outside the grouped kernel's table")
+        # level 1: layer 1 of every modulation MLP + the stem's layer 1 (its input gradient: 68 chunks, reduced below)
+        dxa, dwa, dba = _dense_grouped_bwd([none] * n + [sin], list(hs) + [sy0], w2s + [sw1], list(outs) + [sy1], [None] * n + [saux1],
+                                           list(d_outs) + [d_sy1], [True] * (n + 1), [True] * (n + 1), False, B, defer_reduce=True)
+        dx4, d_sy0 = dxa[:n], dxa[n]
+        # level 2: layer 0 of every MLP (all read z_t: one shared gradient, summed over the MLPs below)
+        dx3, dw3, db3 = _dense_grouped_bwd([relu] * n, [ty1] * n, w1s, hs, [None] * n, dx4, [True] * n, [True] * n, True, B, defer_reduce=True)
+        _flush_deferred()                   # both reductions (and whatever else was still queued) in ONE launch
+        tot = next(t for t in dx3 if t is not None)
+        d_zt = tot if d_ty1 is None else tot + L.f32c(d_ty1).reshape(tot.shape)
+        for i in range(n):
+            g[8 + 4 * i], g[8 + 4 * i + 1], g[8 + 4 * i + 2], g[8 + 4 * i + 3] = dw3[i], db3[i], dwa[i], dba[i]
+        # level 3: stem_t's layer 1 and the stem's layer 0 (the positional encoding has no gradient)
+        dxb, dwb, dbb = _dense_grouped_bwd([sin, sin], [ty0, pe], [tw1, sw0], [ty1, sy0], [taux1, saux0], [d_zt, d_sy0], [True, False], [True, True], False, B)
+        # level 4: stem_t's layer 0
+        _, dwc, dbc = _dense_grouped_bwd([sin], [pe], [tw0], [ty0], [taux0], [dxb[0]], [False], [True], False, B)
+        g[0], g[1], g[2], g[3] = dwb[1], dbb[1], dwa[n], dba[n]
+        g[4], g[5], g[6], g[7] = dwc[0], dbc[0], dwb[0], dbb[0]
         g = [None if t is None else t.reshape(sh) for t, sh in zip(g, ctx.pshapes)]
         return (None, None, None, *g)
 
