@@ -125,6 +125,7 @@ SYMBOLS = {
     "bnerv_ctx_wplan_record": (_I, [_V]),
     "bnerv_ctx_wplan_freeze": (_I, [_V]),
     "bnerv_ctx_wplan_run": (_I, [_V, _V]),
+    "bnerv_ctx_wplan_run_fetch": (_I, [_V, _V, _V, _V, _V, _I, _Z, _V, _V]),
     "bnerv_ctx_wplan_end": (_I, [_V]),
     "bnerv_ctx_wplan_entries": (_I, [_V]),
     "bnerv_reduce_slabs_deferred": (_I, [_V, _V, _V, _I, _I, _V]),

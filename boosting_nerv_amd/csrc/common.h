@@ -149,3 +149,21 @@ __device__ __forceinline__ int xcd_remap(int orig, int n) {
     const int xcd = orig & 7, q = n >> 3, r = n & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
+
+// The step's frame fetch (csrc/optim.hip bnerv_fetch_frame; train_nerv_all.py:328-332 when the clip lives in HBM): frame (int)sel[0] of the clip and
+// its normalised index copied to the step's static buffers.  A device function because the weight-fragment plan's launch (convbf.hip) can carry it
+// as a second block range: two independent launches at the head of every captured step become one.
+__device__ __forceinline__ void fetch_frame_body(const float* __restrict__ clip, const double* __restrict__ norms, const float* __restrict__ sel,
+                                                 const int n_frames, const size_t frame_elems, float* __restrict__ dst, double* __restrict__ dst_norm,
+                                                 const int bx, const int nbx) {
+    int k = (int)sel[0];
+    k = k < 0 ? 0 : (k >= n_frames ? n_frames - 1 : k);
+    const f32x4* src = reinterpret_cast<const f32x4*>(clip + (size_t)k * frame_elems);
+    f32x4* out = reinterpret_cast<f32x4*>(dst);
+    const size_t n4 = frame_elems / 4;
+    for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n4; i += (size_t)nbx * 256) out[i] = src[i];
+    if (bx == 0 && threadIdx.x == 0) {
+        for (size_t i = n4 * 4; i < frame_elems; ++i) dst[i] = clip[(size_t)k * frame_elems + i];
+        if (norms && dst_norm) dst_norm[0] = norms[k];
+    }
+}

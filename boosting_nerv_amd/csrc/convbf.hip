@@ -653,6 +653,21 @@ __global__ __launch_bounds__(256) void bf_wprep_plan_kernel(const WPlanEntry* __
     else wprep_slot<2>(e.w, arena + e.slot0, e.wCi, e.transposed, e.Cin, e.Cout, e.nck, e.ntb, f);
 }
 
+// the same launch with the step's frame fetch as a second block range (bnerv_ctx_wplan_run_fetch)
+struct FetchArgs { const float* clip; const double* norms; const float* sel; int n_frames; size_t frame_elems; float* dst; double* dst_norm; };
+__global__ __launch_bounds__(256) void bf_wprep_plan_fetch_kernel(const WPlanEntry* __restrict__ table, const int* __restrict__ blockmap, u32x4* __restrict__ arena,
+                                                                  const int n_plan, const FetchArgs fa) {
+    if ((int)blockIdx.x >= n_plan) {                       // block-uniform
+        fetch_frame_body(fa.clip, fa.norms, fa.sel, fa.n_frames, fa.frame_elems, fa.dst, fa.dst_norm, (int)blockIdx.x - n_plan, (int)gridDim.x - n_plan);
+        return;
+    }
+    const WPlanEntry e = table[blockmap[blockIdx.x]];
+    const int f = ((int)blockIdx.x - e.block0) * 256 + threadIdx.x;
+    if (f >= e.nfrag) return;
+    if (e.ns == 3) wprep_slot<3>(e.w, arena + e.slot0, e.wCi, e.transposed, e.Cin, e.Cout, e.nck, e.ntb, f);
+    else wprep_slot<2>(e.w, arena + e.slot0, e.wCi, e.transposed, e.Cin, e.Cout, e.nck, e.ntb, f);
+}
+
 static bool wplan_same(const WPlanEntry& a, const bnerv_conv_desc& d, int nck, int ntb, int ns) {
     return a.w == d.w && a.wCo == d.wCo && a.wCi == d.wCi && a.transposed == d.transposed && a.Cin == d.Cin && a.Cout == d.Cout && a.nck == nck &&
            a.ntb == ntb && a.ns == ns;
@@ -1393,6 +1408,26 @@ extern "C" int bnerv_ctx_wplan_run(bnerv_ctx* ctx, void* stream) {
     if (!p || p->state != 2 || p->blocks == 0) return BNERV_OK;       // nothing planned: every call prepares its own fragments
     hipLaunchKernelGGL(bf_wprep_plan_kernel, dim3(p->blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p->table, p->blockmap, p->arena);
     BNERV_LAUNCH_CHECK("bf_wprep_plan");
+    p->live = true;
+    return BNERV_OK;
+}
+// bnerv_ctx_wplan_run + bnerv_fetch_frame as ONE launch (the two are independent and open every captured step that trains a resident clip).
+// Returns 1 when there is no frozen plan with work: the caller issues bnerv_fetch_frame (and nothing else) as before.
+extern "C" int bnerv_ctx_wplan_run_fetch(bnerv_ctx* ctx, void* stream, const float* clip, const double* norms, const float* sel_dev, int n_frames, size_t frame_elems,
+                                         float* dst_img, double* dst_norm) {
+    BNERV_REQUIRE(ctx != nullptr, "ctx_wplan_run_fetch: null context");
+    BNERV_REQUIRE(clip && sel_dev && dst_img && n_frames > 0 && frame_elems > 0, "ctx_wplan_run_fetch: bad fetch args");
+    BNERV_REQUIRE((reinterpret_cast<uintptr_t>(clip) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst_img) & 15) == 0 && (frame_elems % 4 == 0 || n_frames == 1),
+                  "ctx_wplan_run_fetch: 16-byte aligned frames required");
+    BfWPlan* p = ctx->wplan;
+    if (!p || p->state != 2 || p->blocks == 0) return 1;
+    const size_t n4 = frame_elems / 4;
+    int fb = (int)((n4 + 255) / 256);
+    if (fb > 2048) fb = 2048;
+    if (fb < 1) fb = 1;
+    const FetchArgs fa{clip, norms, sel_dev, n_frames, frame_elems, dst_img, dst_norm};
+    hipLaunchKernelGGL(bf_wprep_plan_fetch_kernel, dim3(p->blocks + fb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p->table, p->blockmap, p->arena, p->blocks, fa);
+    BNERV_LAUNCH_CHECK("bf_wprep_plan_fetch");
     p->live = true;
     return BNERV_OK;
 }

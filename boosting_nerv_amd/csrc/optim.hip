@@ -100,16 +100,7 @@ __global__ __launch_bounds__(256) void adan_table_kernel(const bnerv_adan_entry*
 
 __global__ __launch_bounds__(256) void fetch_frame_kernel(const float* __restrict__ clip, const double* __restrict__ norms, const float* __restrict__ sel,
                                                           const int n_frames, const size_t frame_elems, float* __restrict__ dst, double* __restrict__ dst_norm) {
-    int k = (int)sel[0];
-    k = k < 0 ? 0 : (k >= n_frames ? n_frames - 1 : k);
-    const f32x4* src = reinterpret_cast<const f32x4*>(clip + (size_t)k * frame_elems);
-    f32x4* out = reinterpret_cast<f32x4*>(dst);
-    const size_t n4 = frame_elems / 4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = src[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        for (size_t i = n4 * 4; i < frame_elems; ++i) dst[i] = clip[(size_t)k * frame_elems + i];
-        if (norms && dst_norm) dst_norm[0] = norms[k];
-    }
+    fetch_frame_body(clip, norms, sel, n_frames, frame_elems, dst, dst_norm, (int)blockIdx.x, (int)gridDim.x);
 }
 
 struct BucketArgs { bnerv_bucket_chunk c; float* bucket; float scale; int to_bucket; int bstart[BNERV_ADAN_MAX_TENSORS * 2 + 1]; };

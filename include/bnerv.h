@@ -166,6 +166,10 @@ int bnerv_ctx_reserve(bnerv_ctx* ctx, size_t bytes);
 int bnerv_ctx_wplan_record(bnerv_ctx* ctx);
 int bnerv_ctx_wplan_freeze(bnerv_ctx* ctx);
 int bnerv_ctx_wplan_run(bnerv_ctx* ctx, void* stream);
+/* bnerv_ctx_wplan_run and bnerv_fetch_frame (below) as ONE launch (ABI 8): both open a captured step on a resident clip and neither depends on the
+ * other.  Returns 1 when the context has no frozen plan with work -- the caller then calls bnerv_fetch_frame alone. */
+int bnerv_ctx_wplan_run_fetch(bnerv_ctx* ctx, void* stream, const float* clip, const double* norms, const float* sel_dev, int n_frames, size_t frame_elems,
+                              float* dst_img, double* dst_norm);
 int bnerv_ctx_wplan_end(bnerv_ctx* ctx);
 int bnerv_ctx_wplan_entries(const bnerv_ctx* ctx);     /* entries of the frozen plan (0: none) */
 int bnerv_reduce_slabs_deferred(bnerv_ctx* ctx, void* stream, const float* slabs, int n_slabs, int count, float* out);
