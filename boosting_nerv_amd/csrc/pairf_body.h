@@ -32,7 +32,10 @@ __device__ __forceinline__ void pair_fused_body(const bnerv_conv::KArgs& ka, con
     using GW = Geo<3>;                                     // x tile (the weight gradient's B operand): plane stride 420
     using bnerv_conv::LItem;
     constexpr unsigned kOOB = 0x80000000u;                 // the out-of-range marker offset of the raw buffer views (conv_common.h)
-    constexpr int NSLOT = Q4_NCH * GQ::ROWS * GQ::SEGS;   // 1200 16-byte slots per 12-plane halo tile
+    // 16-byte slots of a 12-plane halo tile, 101 per plane (100 + one idle): a plane stride of 404 floats == 20 (mod 32) makes the weight
+    // gradient's A reads (16 planes x 2 k-lanes per half wave) 2-way bank conflicts; the natural 400 == 16 (mod 32) made them 8-way
+    constexpr int PSLOT = GQ::ROWS * GQ::SEGS + 1, GPL = PSLOT * 4;
+    constexpr int NSLOT = Q4_NCH * PSLOT;                  // 1212
     constexpr int NPRE = (NSLOT + 255) / 256;              // 5
     constexpr int S_IN = NPRE * 256 * 4;                   // floats per g buffer
     constexpr int S_W = Q4_NCH * Q4_QPAD * 4;
@@ -40,7 +43,7 @@ __device__ __forceinline__ void pair_fused_body(const bnerv_conv::KArgs& ka, con
     constexpr bool WAFF = (WIN == BNERV_IN_AFFINE);
     constexpr int NTW = 7, NPLL = 12;
     constexpr int NXS = NPRE;
-    static_assert(GQ::PLANE == GQ::PLANE_RAW && S_IN >= Q4_NCH * GQ::PLANE && GW::ROWS == GQ::ROWS && GW::SEGS == GQ::SEGS, "slot geometry");
+    static_assert(GQ::PLANE == GQ::PLANE_RAW && S_IN >= Q4_NCH * GPL && GW::ROWS == GQ::ROWS && GW::SEGS == GQ::SEGS, "slot geometry");
     static_assert(EP == BNERV_EP_PLAIN || RED, "epilogues of the backward pairs");
     const bnerv_conv_desc& d = ka.d;                       // the data gradient as a convolution: d.x = g, d.Cin = couts of the layer, d.Cout = its input channels
     const bnerv_wgrad_desc& w = wa.d;
@@ -49,7 +52,7 @@ __device__ __forceinline__ void pair_fused_body(const bnerv_conv::KArgs& ka, con
     float* s_w = smem + 2 * S_IN;                          // [co-as-ci][quad][4] compact weight quads of the data gradient
     float* s_red = s_w + S_W;                              // [4 waves][2][16] per-channel sums of the waves at a flush (DGELU_SAVED / DSIN)
     float* s_x = s_red + 256;                              // (NPLL + 2) planes of GW::PLANE + dump area of the idle slots
-    float* s_affw = s_x + (NPLL + 2) * GW::PLANE + (NXS * 256 - NSLOT) * 4;   // [2][16] affine prologue of the weight gradient's input
+    float* s_affw = s_x + (NPLL + 2) * GW::PLANE + 64 * 4;                     // [2][16] affine prologue of the weight gradient's input (behind the dump area)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,10 +90,10 @@ __device__ __forceinline__ void pair_fused_body(const bnerv_conv::KArgs& ka, con
     for (int i = tid; i < 2 * GW::PLANE; i += 256) s_x[NPLL * GW::PLANE + i] = i < GW::PLANE ? 1.0f : 0.0f;
 
     // ---- per-slot constants: slot = (channel, halo row, 4-px segment); thread t owns slots t, t + 256, ... of BOTH tiles
-    auto slot_geom = [&](int k, int& c, int& r, int& sg) {
+    auto slot_geom = [&](int k, int& c, int& r, int& sg) {     // (r == ROWS: the plane's idle 101st slot)
         const int sidx = tid + k * 256;
-        c = sidx / (GQ::ROWS * GQ::SEGS);
-        const int rem = sidx - c * (GQ::ROWS * GQ::SEGS);
+        c = sidx / PSLOT;
+        const int rem = sidx - c * PSLOT;
         r = rem / GQ::SEGS;
         sg = rem - r * GQ::SEGS;
     };
@@ -106,11 +109,11 @@ __device__ __forceinline__ void pair_fused_body(const bnerv_conv::KArgs& ka, con
     for (int k = 0; k < NPRE; ++k) {
         int c, r, sg;
         slot_geom(k, c, r, sg);
-        const bool real = tid + k * 256 < NSLOT;
+        const bool real = tid + k * 256 < NSLOT && r < GQ::ROWS;
         const unsigned off = (unsigned)(((c * H + r) * W + 4 * sg) * 4);
         voffg[k] = (real && c < Cg) ? off : kOOB;          // out of range: the DMA writes zeros
         voffx[k] = (real && c < Cx) ? off : kOOB;
-        loffx[k] = real ? (c * GW::PLANE + r * GW::RS + 4 * sg) * 4 : ((NPLL + 2) * GW::PLANE + (tid + k * 256 - NSLOT) * 4) * 4;
+        loffx[k] = real ? (c * GW::PLANE + r * GW::RS + 4 * sg) * 4 : ((NPLL + 2) * GW::PLANE + (tid & 63) * 4) * 4;      // idle slots: a 64-slot dump area
     }
     const unsigned shift = (unsigned)((GQ::PAD * W + GQ::XOFF) * 4);         // both views start PAD rows + XOFF columns early: offsets >= 0
     const unsigned g_bytes = (unsigned)((size_t)d.B * Cg * H * W * 4) + shift;
@@ -242,7 +245,7 @@ __device__ __forceinline__ void pair_fused_body(const bnerv_conv::KArgs& ka, con
     }
     // A operand from the g halo tile: plane li, the CENTRE of pixel (row, column) = halo (row + PAD, column + XOFF); rows 12..15 read the
     // slots behind plane 11 / the other buffer: they only reach output rows that are dropped
-    const int abase = li * GQ::PLANE + (2 * wave + GQ::PAD) * GQ::RS + GQ::XOFF + kq;
+    const int abase = li * GPL + (2 * wave + GQ::PAD) * GQ::RS + GQ::XOFF + kq;
 
     f32x4 accw[NTW];
 #pragma unroll
@@ -333,7 +336,7 @@ __device__ __forceinline__ void pair_fused_body(const bnerv_conv::KArgs& ka, con
                         const int nci = ky == 2 ? ci + 1 : ci, nky = ky == 2 ? 0 : ky + 1;
                         if (nci < Q4_NCH) {
 #pragma unroll
-                            for (int kx = 0; kx < 3; ++kx) a_nxt[kx] = a_base[nci * GQ::PLANE + nky * GQ::RS + kx];
+                            for (int kx = 0; kx < 3; ++kx) a_nxt[kx] = a_base[nci * GPL + nky * GQ::RS + kx];
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -492,7 +495,7 @@ __device__ __forceinline__ void pair_fused_body(const bnerv_conv::KArgs& ka, con
 inline size_t pair_fused_lds_bytes() {
     using GQ = bnerv_conv::Geo<3>;
     using GW = Geo<3>;
-    constexpr int NSLOT = bnerv_q4::Q4_NCH * GQ::ROWS * GQ::SEGS;
+    constexpr int NSLOT = bnerv_q4::Q4_NCH * (GQ::ROWS * GQ::SEGS + 1);
     constexpr int NPRE = (NSLOT + 255) / 256;
-    return ((size_t)2 * NPRE * 256 * 4 + (size_t)bnerv_q4::Q4_NCH * bnerv_q4::Q4_QPAD * 4 + 256 + (size_t)(12 + 2) * GW::PLANE + (size_t)(NPRE * 256 - NSLOT) * 4 + 32 + 64) * sizeof(float);
+    return ((size_t)2 * NPRE * 256 * 4 + (size_t)bnerv_q4::Q4_NCH * bnerv_q4::Q4_QPAD * 4 + 256 + (size_t)(12 + 2) * GW::PLANE + 64 * 4 + 32 + 64) * sizeof(float);
 }
