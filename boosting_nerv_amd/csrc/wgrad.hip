@@ -1595,6 +1595,98 @@ static int small_pair_try(hipStream_t st, const bnerv_conv_desc& c, WArgs& wa, i
 }
 }  // namespace
 
+// ---- the 1x1 output head's backward as ONE streaming pass (head_layer 1x1 C -> K <= 4 + OutImg tanh, model_nerv.py:41, :56-57, model_blocks.py:57-63):
+//     dy[k][p] = g[k][p] * 0.5 (1 - (2 img[k][p] - 1)^2);   dx[c][p] = sum_k W[k][c] dy[k][p];   dW[k][c] = sum_p dy[k][p] x[c][p];   db[k] = sum_p dy[k][p]
+// The two halves were a streaming data-gradient kernel (13 us at 720p) and the 1x1 lean weight gradient (15.8 us): each read g and img, one
+// wrote dx, the other read x -- 132 MB for 110 MB of distinct tensors and two launches for a pass that is 75 fma per pixel.  Here a thread takes
+// 4 consecutive pixels per step of a grid-stride loop, keeps its K (C + 1) partial sums in registers and the block writes ONE slab [K][C + 1]
+// (the weight gradient's slab layout: the deferred slab reduction finishes it as for every other layer).
+constexpr int HB_KMAX = 4, HB_CMAX = 16;
+struct HeadBwdArgs { const float* g; const float* img; const float* x; const float* w; float* dx; float* slab; int B, K, C, transposed; size_t HW; int nq; };
+template <int K, int C>
+__global__ __launch_bounds__(256) void head1x1_bwd_kernel(const HeadBwdArgs a) {
+    __shared__ float s_w[HB_KMAX * HB_CMAX];
+    __shared__ float s_red[4][HB_KMAX * (HB_CMAX + 1)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < K * C) {                                     // W(k, c): the conv descriptor's transposed weights are stored [k][c], direct ones [c][k]
+        const int k = tid / C, c = tid - k * C;
+        s_w[k * HB_CMAX + c] = a.transposed ? a.w[k * C + c] : a.w[c * K + k];
+    }
+    if (lane < K * (C + 1)) s_red[wave][(lane / (C + 1)) * (HB_CMAX + 1) + lane % (C + 1)] = 0.f;      // this wave's running sums (only its lane 0 adds to them)
+    __syncthreads();
+    const int total = a.B * a.nq;                          // pixel quads of all samples
+    const int rounds = (total + (int)gridDim.x * 256 - 1) / ((int)gridDim.x * 256);       // block-uniform: the wave sums need every lane
+#pragma unroll 1
+    for (int it = 0; it < rounds; ++it) {
+        const int q = (it * (int)gridDim.x + (int)blockIdx.x) * 256 + tid;
+        const bool live = q < total;
+        const int b = live ? q / a.nq : 0, qq = live ? q - b * a.nq : 0;
+        f32x4 dy[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const size_t o = ((size_t)b * K + k) * a.HW + (size_t)qq * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.g + o), im = *reinterpret_cast<const f32x4*>(a.img + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float t = 2.0f * im[e] - 1.0f; dy[k][e] = live ? v[e] * 0.5f * (1.0f - t * t) : 0.f; }
+        }
+        f32x4 xv[C];                                       // every load of the thread in flight before the first use
+#pragma unroll
+        for (int c = 0; c < C; ++c) xv[c] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)b * C + c) * a.HW + (size_t)qq * 4);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float sm = wave_sum((dy[k][0] + dy[k][1]) + (dy[k][2] + dy[k][3]));
+            if (lane == 0) s_red[wave][k * (HB_CMAX + 1) + C] += sm;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float wv = s_w[k * HB_CMAX + c];
+                float pw = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { r[e] = fmaf(dy[k][e], wv, r[e]); pw = fmaf(dy[k][e], xv[c][e], pw); }
+                pw = wave_sum(pw);
+                if (lane == 0) s_red[wave][k * (HB_CMAX + 1) + c] += pw;
+            }
+            if (a.dx && live) *reinterpret_cast<f32x4*>(a.dx + ((size_t)b * C + c) * a.HW + (size_t)qq * 4) = r;
+            __builtin_amdgcn_sched_barrier(0);             // (one channel's three wave sums at a time: interleaving all 36 costs 256 registers)
+        }
+    }
+    __syncthreads();
+    if (tid < K * (C + 1)) {                               // the four waves in a fixed order
+        const int k = tid / (C + 1), c = tid - k * (C + 1);
+        const int i = k * (HB_CMAX + 1) + c;
+        a.slab[(size_t)blockIdx.x * K * (C + 1) + tid] = (s_red[0][i] + s_red[1][i]) + (s_red[2][i] + s_red[3][i]);
+    }
+}
+
+// 1: not the head's pair; BNERV_OK: launched, *n_slabs slabs of K x (C + 1) floats in w.ws
+static int head_pair_try(hipStream_t st, const bnerv_conv_desc& c, const bnerv_wgrad_desc& w, int* n_slabs) {
+    { const char* e = getenv("BNERV_PAIR_HEAD"); if (e && e[0] == '0') return 1; }      // A/B switch, read per call
+    if (!(c.k == 1 && w.k == 1 && c.in_mode == BNERV_IN_TANHGRAD && c.ep_mode == BNERV_EP_PLAIN && c.out_s == 1 && w.g_mode == BNERV_IN_TANHGRAD && w.in_mode == BNERV_IN_PLAIN)) return 1;
+    if (!(c.x && c.aux0 && c.w && c.out && w.x && w.g && w.gaux && w.dw && w.ws && w.defer_finish && w.ctx && w.ctx == c.ctx)) return 1;
+    if (!(c.x == w.g && c.aux0 == w.gaux && c.Cin == w.Cout && c.Cout == w.Cin && c.B == w.B && c.H == w.H && c.W == w.W)) return 1;     // one head, one gradient
+    const int K = c.Cin, C = c.Cout;
+    if (K != 3 || C != 12 || ((size_t)c.H * c.W) % 4 != 0) return 1;            // (instantiated for the reference's heads: 12 -> 3; HNeRV's heads are 3x3)
+    if (c.transposed ? !(c.wCo == K && c.wCi == C) : !(c.wCo == C && c.wCi == K)) return 1;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!(al(c.x) && al(c.aux0) && al(c.out) && al(w.x))) return 1;
+    const size_t HW = (size_t)c.H * c.W;
+    const int nq = (int)(HW / 4);
+    // one quad per thread up to 1024 blocks (every load of a thread is in flight at once: the pass is one memory round trip per wave; a
+    // first version with four quads per thread on 225 blocks ran 36.8 us -- four serialised round trips on less than one wave per SIMD)
+    int blocks = cdiv(c.B * nq, 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    if ((size_t)blocks * K * (C + 1) * sizeof(float) > w.ws_bytes) return 1;
+    HeadBwdArgs a{c.x, c.aux0, w.x, c.w, c.out, reinterpret_cast<float*>(w.ws), c.B, K, C, c.transposed, HW, nq};
+    hipLaunchKernelGGL((head1x1_bwd_kernel<3, 12>), dim3(blocks), dim3(256), 0, st, a);
+    BNERV_LAUNCH_CHECK("head1x1_bwd");
+    *n_slabs = blocks;
+    return BNERV_OK;
+}
+
 // Returns BNERV_OK when both were launched together, 1 when the pair is not one this launch takes (the caller then issues
 // bnerv_conv_wgrad and bnerv_conv_igemm separately, in that order), a negative BNERV_E_* on error.
 extern "C" int bnerv_conv_wgrad_pair(void* stream, const bnerv_conv_desc* cdp, const bnerv_wgrad_desc* wdp) {
@@ -1609,6 +1701,13 @@ extern "C" int bnerv_conv_wgrad_pair(void* stream, const bnerv_conv_desc* cdp, c
     const bnerv_wgrad_desc& w = wa.d;
     // the conv half: a 3x3 stride-1 data gradient (plain input, or the unshuffle(2) prologue of an up-conv's), epilogue PLAIN / DGELU_SAVED / DSIN
     if (c.in_mode == BNERV_IN_UNSHUFFLE && c.in_s == 1) c.in_mode = BNERV_IN_PLAIN;
+    if (c.k == 1) {                                        // form H: the 1x1 output head (tanh-grad prologue), one streaming pass
+        int ns = 0;
+        const int rh = head_pair_try(reinterpret_cast<hipStream_t>(stream), c, w, &ns);
+        if (rh != BNERV_OK) return rh;
+        bnerv_side_push(w.ctx, reinterpret_cast<hipStream_t>(stream), w.ws, ns, w.Cout * (w.Cin + 1), w.Cin + 1, w.dw, w.db);
+        return BNERV_OK;
+    }
     if (!(c.k == 3 && c.out_s == 1 && c.x && c.w && c.out && c.B > 0)) return 1;
     // form 0: the stem stage (an image of <= 256 pixels: stem.hip) -- dW / db are written directly, the data gradient's K-slice slabs
     // (c.partial, bnerv_conv_splitk_ws_bytes) are summed by a deferred reduction on the same context

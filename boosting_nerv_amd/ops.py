@@ -668,11 +668,14 @@ class _HeadTanh(torch.autograd.Function):
         Cout, k = w.shape[0], w.shape[-1]
         dw = torch.empty_like(w)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_b else None
-        _wgrad(x, g, dw, db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_TANHGRAD, gaux=img, defer=True)
         dx = None
         if ctx.needs_input_grad[0]:
+            # (dW | dx) of the head: one streaming pass where the library pairs them (1x1, tanh-grad prologue), the two launches otherwise
             dx = torch.empty_like(x)
-            _conv(g, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_TANHGRAD, ep_mode=L.EP_PLAIN, transposed=1, aux0=img)
+            _wgrad_conv_pair(dict(x=x, g=g, dw=dw, db=db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_TANHGRAD, gaux=img),
+                             dict(x=g, w=w, bias=None, out=dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_TANHGRAD, ep_mode=L.EP_PLAIN, transposed=1, aux0=img))
+        else:
+            _wgrad(x, g, dw, db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_TANHGRAD, gaux=img, defer=True)
         _flush_deferred(block_end=True)
         return dx, dw, db
 
