@@ -23,6 +23,8 @@ CFG = {
                       kernel="wA|dK2s: conv0 backward pair (weight gradient, affine prologue | conv^T -> dsin + sums) 12->12 @720x1280"),
     "pair_dk1": dict(mode="pair_dk1", pat="pair_", row="pair_dk1", shape=[12, 720, 1280], alg=3 * P12 + 2 * WB12, sources=SRCP,
                      kernel="wP|dK1: block conv backward pair (weight gradient | conv^T) 12->12 @720x1280"),
+    "pair_c4": dict(mode="pair_dk2s_1080", pat="pair_", row="pair_dk2s", shape=[12, 1080, 1920], alg=5 * 12 * 1080 * 1920 * 4 + 2 * WB12, sources=SRCP,
+                    kernel="wA|dK2s: conv0 backward pair (weight gradient, affine prologue | conv^T -> dsin + sums) 12->12 @1080x1920 (C4's last stage)"),
     "c4": dict(mode="conv_k2s_1080", pat="conv_", row="k2s", shape=[12, 1080, 1920], alg=3 * 12 * 1080 * 1920 * 4 + WB12, sources=SRC4,
                kernel="K2s: TAT conv0 forward (affine -> 3x3 -> bias -> gelu, gelu') 12->12 @1080x1920"),
     "wide_pair": dict(mode="pair38_dk2s", pat="bfw_kernel", multi=True, row="pair_dk2s", shape=[38, 1080, 1920], alg=5 * 38 * 1080 * 1920 * 4 + 2 * 38 * 38 * 9 * 4,

@@ -4,7 +4,7 @@
 # (tools/suite_repeat.sh, one lease each).   usage (through gpurun, repo root): tools/round5_evidence.sh [fast]
 set -u
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
-for k in pair_dk2s pair_dk3s pair_dk1 k2s c4 wide wide_pair; do python tools/pmc_traffic.py $k r05 > /dev/null 2>&1; done
+for k in pair_dk2s pair_dk3s pair_dk1 k2s c4 pair_c4 wide wide_pair; do python tools/pmc_traffic.py $k r05 > /dev/null 2>&1; done
 cp $O/r05_traffic_*.json $R/profiles/ 2>/dev/null          # the bench lines below read (and verify) them
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/r05_bench_c1.json 2> $O/r05_bench_c1.err
