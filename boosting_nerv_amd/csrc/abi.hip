@@ -24,15 +24,17 @@ extern "C" const char* bnerv_build_arch(void) { return "gfx950"; }
 namespace {
 __global__ __launch_bounds__(256) void side_flush_kernel(const SidePack sp) {
     __shared__ float red[256];
-    side_slice(sp, blockIdx.x, red);
+    side_slice<SidePack, true>(sp, blockIdx.x, red);
 }
 __global__ __launch_bounds__(256) void side_flush_many_kernel(const SideFlushPack sp) {
     __shared__ float red[256];
-    side_slice(sp, blockIdx.x, red);
+    side_slice<SideFlushPack, true>(sp, blockIdx.x, red);
 }
 
-SideJob make_job(const void* src, int n_slabs, int count, int ncols, float* out, float* out2) {
+SideJob make_job(const void* src, int n_slabs, int count, int ncols, float* out, float* out2, const float* fs = nullptr, const float* ft = nullptr) {
     SideJob j;
+    j.fs = fs;
+    j.ft = ft;
     j.src = reinterpret_cast<const float*>(src);
     j.out = out;
     j.out2 = out2;
@@ -48,8 +50,8 @@ SideJob make_job(const void* src, int n_slabs, int count, int ncols, float* out,
 }
 }  // namespace
 
-void bnerv_side_push(bnerv_ctx* ctx, hipStream_t st, const void* src, int n_slabs, int count, int ncols, float* out, float* out2) {
-    const SideJob j = make_job(src, n_slabs, count, ncols, out, out2);
+void bnerv_side_push(bnerv_ctx* ctx, hipStream_t st, const void* src, int n_slabs, int count, int ncols, float* out, float* out2, const float* fold_scale, const float* fold_shift) {
+    const SideJob j = make_job(src, n_slabs, count, ncols, out, out2, fold_scale, fold_shift);
     if (ctx) { ctx->queue.push_back(j); return; }
     SidePack sp;                                          // no context: run it now
     sp.j[0] = j;
@@ -67,14 +69,19 @@ void bnerv_side_take(bnerv_ctx* ctx, SidePack* sp, int max_slices) {
     static const int min_grid = [] { const char* e = getenv("BNERV_SIDE_MIN_GRID"); return e ? atoi(e) : 0; }();
     if (max_slices < 2 * min_grid) return;
     std::vector<SideJob>& q = ctx->queue;
+    // queued jobs in issue order; fold jobs (sidejob.h) stay behind for the flush kernels and are stepped over -- the jobs are independent of
+    // one another (distinct outputs), the order only keeps the oldest slabs moving first
     int n = 0;
-    while (n < (int)q.size() && n < SIDE_MAX_JOBS && sp->n_slices + q[n].slices <= max_slices) {
-        sp->j[n] = q[n];
-        sp->n_slices += q[n].slices;
+    size_t i = 0;
+    while (i < q.size() && n < SIDE_MAX_JOBS) {
+        if (q[i].fs) { ++i; continue; }
+        if (sp->n_slices + q[i].slices > max_slices) break;
+        sp->j[n] = q[i];
+        sp->n_slices += q[i].slices;
         ++n;
+        q.erase(q.begin() + (long)i);
     }
     sp->n_jobs = n;
-    q.erase(q.begin(), q.begin() + n);
 }
 
 int bnerv_side_pending(const bnerv_ctx* ctx) { return ctx ? (int)ctx->queue.size() : 0; }

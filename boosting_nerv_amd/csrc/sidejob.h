@@ -22,6 +22,11 @@ struct SideJob {
     int n_slabs, count, ncols;
     int epb;        // consecutive elements per slice (power of two <= 256); lanes = 256 / epb
     int slices;     // ceil(count / epb)
+    // FOLD job (fs != NULL; the shared-tile pair's fold form, pairf_body.h): the slabs hold rows of ncols + 8 columns -- (ncols - 1) raw
+    // products R, then 9 tap-masked gradient sums M -- and output element (co, n) is (1 + fs[n / 9]) R + ft[n / 9] M[n % 9] for a weight
+    // column, M[4] for the bias column: the affine prologue of the weight gradient's input applied after the sum instead of per element
+    const float* fs;
+    const float* ft;
 };
 
 struct SidePack {
@@ -49,14 +54,17 @@ void* bnerv_ctx_scratch(bnerv_ctx* ctx, size_t bytes, hipStream_t st);
 
 // host side (abi.hip).  The queue belongs to the caller's bnerv_ctx; ctx == NULL means "no queue": nothing to take, and a push
 // runs the reduction at once on `st`.
-void bnerv_side_push(bnerv_ctx* ctx, hipStream_t st, const void* src, int n_slabs, int count, int ncols, float* out, float* out2);
+void bnerv_side_push(bnerv_ctx* ctx, hipStream_t st, const void* src, int n_slabs, int count, int ncols, float* out, float* out2,
+                     const float* fold_scale = nullptr, const float* fold_shift = nullptr);
 void bnerv_side_take(bnerv_ctx* ctx, SidePack* sp, int max_slices);   // moves up to SIDE_MAX_JOBS queued jobs (while their slices fit
                                                          // max_slices) into *sp (n_jobs = 0 if none): a small grid must not host a big reduction
 int bnerv_side_flush(bnerv_ctx* ctx, hipStream_t st);    // standalone launch(es) for everything still queued
 int bnerv_side_pending(const bnerv_ctx* ctx);
 
 // one slice (256 threads, `red` = 256 floats of LDS the caller no longer needs; caller guarantees a barrier before)
-template <class Pack>
+// FOLD: the instantiation of the stand-alone flush kernels (abi.hip), which alone execute fold jobs (bnerv_side_take never hands one to a hosting
+// launch: the hosted copy of this routine inside the hot kernels keeps its register footprint)
+template <class Pack, bool FOLD = false>
 __device__ __forceinline__ void side_slice(const Pack& sp, int s, float* red) {
     int j = 0;
     while (j < sp.n_jobs - 1 && s >= sp.j[j].slices) { s -= sp.j[j].slices; ++j; }
@@ -65,29 +73,55 @@ __device__ __forceinline__ void side_slice(const Pack& sp, int s, float* red) {
     const int e = threadIdx.x % epb, lane = threadIdx.x / epb;
     const int i = s * epb + e;
     // 16 loads in flight per thread (one memory latency per 16 slabs), combined in a fixed tree
-    float acc = 0.f;
+    const bool fold = FOLD && job.fs != nullptr;
+    float acc = 0.f, acc2 = 0.f;
+    int fci = 0;
+    bool fbias = false;
     if (i < job.count) {
-        const float* p = job.src + i;
-        const size_t cnt = (size_t)job.count;
+        size_t cnt = (size_t)job.count;
+        size_t i0 = (size_t)i, i1 = 0;
+        if (fold) {
+            const int co = i / job.ncols, n = i - co * job.ncols, rowl = job.ncols + 8;
+            cnt = (size_t)(job.count / job.ncols) * rowl;
+            fbias = n == job.ncols - 1;
+            fci = fbias ? 0 : n / 9;
+            i1 = (size_t)co * rowl + (job.ncols - 1) + (fbias ? 4 : n - fci * 9);
+            i0 = fbias ? i1 : (size_t)co * rowl + n;
+        }
+        const float* p = job.src + i0;
+        const float* p2 = job.src + i1;
         for (int k0 = lane; k0 < job.n_slabs; k0 += 16 * lanes) {
-            float v[16];
+            float v[16], u2[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int k = k0 + u * lanes;
                 v[u] = k < job.n_slabs ? p[(size_t)k * cnt] : 0.f;
+                u2[u] = (fold && !fbias && k < job.n_slabs) ? p2[(size_t)k * cnt] : 0.f;
             }
 #pragma unroll
             for (int w = 8; w >= 1; w >>= 1)
 #pragma unroll
-                for (int u = 0; u < w; ++u) v[u] += v[u + w];
+                for (int u = 0; u < w; ++u) { v[u] += v[u + w]; u2[u] += u2[u + w]; }
             acc += v[0];
+            acc2 += u2[0];
         }
     }
     red[lane * epb + e] = acc;
     __syncthreads();
-    if (lane == 0 && i < job.count) {
-        float t = 0.f;
+    float t = 0.f;
+    if (lane == 0 && i < job.count)
         for (int l = 0; l < lanes; ++l) t += red[l * epb + e];
+    if (fold) {                                            // (block-uniform: a slice belongs to one job) the second column sum through the same area
+        __syncthreads();
+        red[lane * epb + e] = acc2;
+        __syncthreads();
+        if (lane == 0 && i < job.count && !fbias) {
+            float t2 = 0.f;
+            for (int l = 0; l < lanes; ++l) t2 += red[l * epb + e];
+            t = (1.0f + job.fs[fci]) * t + job.ft[fci] * t2;
+        }
+    }
+    if (lane == 0 && i < job.count) {
         if (job.ncols > 0) {
             const int co = i / job.ncols, n = i - co * job.ncols;
             if (n < job.ncols - 1) job.out[(size_t)co * (job.ncols - 1) + n] = t;

@@ -743,6 +743,10 @@ template <int EP, int WIN>
 __global__ __launch_bounds__(256, 2) void pair_fused_kernel(const bnerv_conv::KArgs ka, const WArgs wa, const SidePack side) {
     pair_fused_body<EP, WIN>(ka, wa, side, (int)blockIdx.x, (int)gridDim.x);
 }
+template <int EP>
+__global__ __launch_bounds__(256, 2) void pair_fold_kernel(const bnerv_conv::KArgs ka, const WArgs wa, const SidePack side) {
+    pair_fold_body<EP>(ka, wa, side, (int)blockIdx.x, (int)gridDim.x);
+}
 
 constexpr size_t WLEAN_MAX_BYTES = 0x7ff00000;
 
@@ -1429,7 +1433,7 @@ int launch_pair(hipStream_t st, bnerv_conv::KArgs& ka, const WArgs& wa, int* n_w
         // HBM traffic of the DSIN pair: see the same file.  BNERV_PAIR_FUSED=<tiles>: every pair from that many tiles on; 0: off.
         const char* fe = getenv("BNERV_PAIR_FUSED");         // (read per call: the parity tests switch forms inside one process)
         const int fused_env = fe ? atoi(fe) : -1;
-        const bool red_ep = EP == BNERV_EP_DGELU_SAVED || EP == BNERV_EP_DSIN;
+        constexpr bool red_ep = EP == BNERV_EP_DGELU_SAVED || EP == BNERV_EP_DSIN;
         const int fused_min = fused_env >= 0 ? fused_env : (red_ep ? 1024 : 0);
         const bnerv_conv_desc& c = ka.d;
         const bnerv_wgrad_desc& w = wa.d;
@@ -1445,6 +1449,26 @@ int launch_pair(hipStream_t st, bnerv_conv::KArgs& ka, const WArgs& wa, int* n_w
             if (n_w_out) *n_w_out = grid;
             SidePack side;
             bnerv_side_take(w.ctx, &side, 2 * grid);
+            if constexpr (red_ep && WIN == BNERV_IN_AFFINE) {
+                // fold form (pairf_body.h pair_fold_body): the input tile staged raw by LDS-DMA, the affine applied by the slab reduction.  One sample
+                // per launch (the fold is per sample), the reducing epilogue's raw-input operand must BE the weight gradient's input, and the
+                // workspace must hold `grid` slabs of Cout x (ncols + 8).  BNERV_PAIR_FOLD=0: the transforming form above.
+                const char* ff = getenv("BNERV_PAIR_FOLD");
+                const float* raw_aux = EP == BNERV_EP_DSIN ? c.aux0 : c.aux1;
+                if (!(ff && ff[0] == '0') && c.B == 1 && raw_aux == w.x && w.scale && w.shift && (reinterpret_cast<uintptr_t>(w.x) & 15) == 0 &&
+                    (size_t)grid * w.Cout * (wa.ncols + 8) * sizeof(float) <= w.ws_bytes) {
+                    const size_t ldsd = pair_fold_lds_bytes();
+                    static bool attrd = false;
+                    if (!attrd) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_fold_kernel<EP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd);
+                        attrd = true;
+                    }
+                    hipLaunchKernelGGL((pair_fold_kernel<EP>), dim3(grid), dim3(256), ldsd, st, ka, wa, side);
+                    BNERV_LAUNCH_CHECK("pair_fold");
+                    if (n_w_out) *n_w_out = -grid;         // negative: the caller queues a FOLD slab reduction
+                    return BNERV_OK;
+                }
+            }
             hipLaunchKernelGGL((pair_fused_kernel<EP, WIN>), dim3(grid), dim3(256), ldsf, st, ka, wa, side);
             BNERV_LAUNCH_CHECK("pair_fused");
             return BNERV_OK;
@@ -1766,6 +1790,9 @@ extern "C" int bnerv_conv_wgrad_pair(void* stream, const bnerv_conv_desc* cdp, c
     // form 2: convs.hip's low-resolution family next to a wide weight gradient
     if (rc == 1) rc = small_pair_try(st, c, wa, &n_slabs);
     if (rc != BNERV_OK) return rc;
-    bnerv_side_push(w.ctx, st, wa.slab, n_slabs, w.Cout * wa.ncols, wa.ncols, w.dw, w.db);     // the slab reduction rides on a later launch
+    if (n_slabs < 0)                                       // the shared-tile pair's fold form: slabs of ncols + 8 columns, the affine applied by the reduction
+        bnerv_side_push(w.ctx, st, wa.slab, -n_slabs, w.Cout * wa.ncols, wa.ncols, w.dw, w.db, w.scale, w.shift);
+    else
+        bnerv_side_push(w.ctx, st, wa.slab, n_slabs, w.Cout * wa.ncols, wa.ncols, w.dw, w.db);     // the slab reduction rides on a later launch
     return BNERV_OK;
 }

@@ -181,16 +181,21 @@ def test_tat_block_backward_on_the_shared_tile_pair(ops, shape, monkeypatch):
     rg = torch.autograd.grad(ref, leaves, cot)
     names = ["x0", "s0", "t0", "s1", "t1", "w0", "b0", "w1", "b1"]
     got = {}
-    for form, env in (("fused", "8"), ("interleaved", "0")):
+    # B == 1: "fused" is the FOLD form (raw input tile by LDS-DMA, the affine applied by the slab reduction, 9 tap-masked gradient sums through
+    # the mask plane -- every tile of these shapes touches the image border) and "transform" the form that applies the prologue on the way into
+    # LDS; B > 1: both are the transforming form (the fold is per sample)
+    for form, env, fold in (("fused", "8", "1"), ("transform", "8", "0"), ("interleaved", "0", "1")):
         monkeypatch.setenv("BNERV_PAIR_FUSED", env)
+        monkeypatch.setenv("BNERV_PAIR_FOLD", fold)
         gl = [gpu(t) for t in leaves]
         out = ops.tat_block(*gl)
         close(out, ref, msg=f"tat fwd ({form})")
         got[form] = torch.autograd.grad(out, gl, cot.to(DEV))
         for n, a, r in zip(names, got[form], rg):
             close(a, r, msg=f"tat d{n} ({form})")
-    for n, a, b in zip(names, got["fused"], got["interleaved"]):
+    for n, a, b, c in zip(names, got["fused"], got["interleaved"], got["transform"]):
         close(a, b, msg=f"tat d{n}: shared-tile pair vs interleaved pair")
+        close(a, c, msg=f"tat d{n}: fold form vs transforming form")
 
 
 @pytest.mark.parametrize("case", [(1, 12, 12, 16, 64, 3, 1), (2, 12, 12, 9, 33, 3, 2), (1, 30, 15, 9, 16, 3, 5), (1, 20, 33, 6, 9, 1, 2), (1, 9, 7, 5, 6, 3, 3),
