@@ -186,3 +186,26 @@ def write_results_csv(args, best, values, psnr_trace, filename='results.csv'):
         wr = csv.writer(f)
         wr.writerow([''] + [k for k, _ in row])          # (pandas' index column of the reference's DataFrame.to_csv)
         wr.writerow([0] + [v for _, v in row])
+
+
+def hard_exit(code=0):
+    """End a finished SCRIPT without the interpreter's teardown: run the registered atexit callbacks, flush, os._exit(code).
+    Why: the teardown of a PyTorch-ROCm process (static destructors of the runtime's worker threads) sporadically ends in
+    `terminate called without an active exception` -> SIGABRT after the script has printed its result -- seen once in ~250 child
+    exits of the GPU suite (round 5, lease r05h3: tools/split_contract.py, exit status -6 behind its complete, correct report).
+    A benchmark line or a checker verdict must not be voided by that.  Only for `if __name__ == "__main__"` endings of scripts;
+    never inside library code."""
+    import atexit
+    import os
+    import sys
+    try:
+        atexit._run_exitfuncs()
+    except Exception:       # noqa: BLE001
+        pass
+    try:
+        sys.stdout.flush()
+        sys.stderr.flush()
+    except Exception:       # noqa: BLE001
+        pass
+    os._exit(int(code))
+

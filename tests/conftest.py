@@ -143,6 +143,12 @@ def run_isolated(nodeid, timeout=900, marker="gpu"):
         if " skipped" in tail and " passed" not in tail:
             pytest.skip(f"isolated child skipped {nodeid}")
         return out
+    if isinstance(rc, int) and rc < 0 and " passed" in out and " failed" not in out and "died in: [bnerv-trail] END" in out:
+        # the child's test PASSED and was reported; the process then died in the interpreter's teardown (torch-ROCm's sporadic
+        # `terminate called without an active exception` at exit, runtime.hard_exit) -- no test was running: the crash tracer's note is an END crumb
+        import warnings
+        warnings.warn(f"isolated child for {nodeid} passed, then died at interpreter exit (signal {-rc})")
+        return out
     how = f"killed by signal {-rc}" if isinstance(rc, int) and rc < 0 else f"exit status {rc}"
     keep = [ln for ln in out.splitlines() if not ln.startswith("  File ") and not ln.startswith("Extension modules:")]
     pytest.fail(f"isolated child for {nodeid}: {how}\n" + "\n".join(keep[-70:])[-6000:], pytrace=False)

@@ -541,3 +541,13 @@ def test_isolated_child_crash_is_an_ordinary_failure():
     assert "passed" in conftest.run_isolated("tests/isolation_probe.py::test_probe_passes", marker="not gpu")
     with pytest.raises(Skipped):
         conftest.run_isolated("tests/isolation_probe.py::test_probe_skips", marker="not gpu")
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` without a launcher re-launches itself one rank per GPU; on a node with fewer devices it must say so and
+    exit instead of hanging in a rendezvous (the driver's 8-GPU line on a smaller box)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BNERV_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "GPU(s) visible on this node" in (r.stderr + r.stdout), (r.stderr + r.stdout)[-500:]

@@ -95,4 +95,5 @@ torch.cuda.synchronize()
 print(f"{N} random cases, {bad} mismatches; worst error relative to the tensor's max per quantity:")
 for k in sorted(worst):
     print(f"  {k:12s} {worst[k]:.2e}")
-sys.exit(1 if bad else 0)
+from boosting_nerv_amd.runtime import hard_exit  # noqa: E402
+hard_exit(1 if bad else 0)
