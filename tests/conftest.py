@@ -119,6 +119,32 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+_session_status = [None]
+
+
+def pytest_sessionfinish(session, exitstatus):
+    _session_status[0] = int(exitstatus)
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_unconfigure(config):
+    """A GPU session ends WITHOUT the interpreter's teardown (boosting_nerv_amd.runtime.hard_exit: atexit callbacks, flush, os._exit with
+    pytest's own exit status).  The summary has been printed by then.  Reason: torch-ROCm's teardown sporadically aborts the process
+    (`terminate called without an active exception`, profiles/r05_pytest_gpu.txt lease r05h3) -- behind a green report that would turn a
+    passed suite into exit status 134.  BNERV_HARD_EXIT=0 switches it off, =force applies it without a GPU (the CPU test of this hook)."""
+    mode = os.environ.get("BNERV_HARD_EXIT", "1")
+    if _session_status[0] is None or mode == "0" or not (torch.cuda.is_available() or mode == "force"):
+        return
+    try:
+        tr = config.pluginmanager.getplugin("terminalreporter")
+        if tr is not None:
+            tr._tw.flush()
+    except Exception:       # noqa: BLE001
+        pass
+    from boosting_nerv_amd.runtime import hard_exit
+    hard_exit(_session_status[0])
+
+
 ISOLATED_CHILD = "BNERV_ISOLATED_CHILD"
 
 

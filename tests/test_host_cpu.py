@@ -551,3 +551,22 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "GPU(s) visible on this node" in (r.stderr + r.stdout), (r.stderr + r.stdout)[-500:]
+
+
+def test_gpu_sessions_end_without_interpreter_teardown_and_keep_their_status():
+    """tests/conftest.py::pytest_unconfigure: a GPU session leaves through runtime.hard_exit (atexit callbacks run, then os._exit with pytest's
+    status) because torch-ROCm's teardown sporadically aborts a finished process.  Forced on here without a GPU: the summary is printed, the
+    exit status is pytest's (0 for a pass, 5 for "no tests ran"), and an atexit callback registered before pytest started still runs."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "sitecustomize.py"), "w") as f:
+            f.write("import atexit, os\natexit.register(lambda: open(os.path.join(%r, 'ran'), 'w').write('x'))\n" % td)
+        env = dict(os.environ, BNERV_HARD_EXIT="force", PYTHONPATH=td + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-m", "pytest", "tests/isolation_probe.py::test_probe_passes", "-q", "-p", "no:cacheprovider"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "1 passed" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+        assert os.path.exists(os.path.join(td, "ran")), "atexit callbacks must run before the hard exit"
+        r = subprocess.run([sys.executable, "-m", "pytest", "tests/isolation_probe.py", "-q", "-p", "no:cacheprovider", "-k", "nothing_matches"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 5, (r.returncode, r.stdout[-300:])
