@@ -1094,3 +1094,22 @@ def test_captured_step_is_bitwise_reproducible_at_full_size():
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "kdeterminism.py")
     r = subprocess.run([sys.executable, tool, "c1", "200"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "identical over 200 steps" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_capture_next_to_an_rccl_watchdog_survives_in_the_forms_the_package_uses():
+    """tools/repro_watchdog_capture.py: an eager RCCL all-reduce followed at once by a stream capture.  The two forms the
+    package uses -- thread-local capture mode with the eager collective on a stream that is never captured, without and with a collective
+    inside the capture -- must survive every round; the round-4 form (torch's default global mode) is run as well and its outcome printed,
+    not asserted: on this stack it aborts in round 0 (`operation not permitted when stream is capturing`, exit status -6)."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "repro_watchdog_capture.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    for i, variant in enumerate(("otherside-thread_local", "othercoll-thread_local")):
+        r = subprocess.run([sys.executable, tool, variant, "4"], capture_output=True, text=True, timeout=300, env=dict(env, MASTER_PORT=str(29731 + i)))
+        assert r.returncode == 0 and r.stdout.count("survived") == 4, (variant, r.returncode, r.stdout[-600:], r.stderr[-1200:])
+    r = subprocess.run([sys.executable, tool, "otherside-global", "4"], capture_output=True, text=True, timeout=300, env=dict(env, MASTER_PORT="29739"))
+    print(f"round-4 form (global capture mode): exit status {r.returncode}, {r.stdout.count('survived')} of 4 rounds survived; "
+          f"{'watchdog: ' + r.stderr.split('terminated with exception:')[1][:90].strip() if 'terminated with exception:' in r.stderr else 'no watchdog exception'}")
