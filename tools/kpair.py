@@ -1,5 +1,7 @@
 """Event-timed back-to-back launches of one 12-channel backward pair at 720x1280 (or HxW given), deferred reductions flushed OUTSIDE the timed region.
-usage: python tools/kpair.py pair_dk2s|pair_dk3s|pair_dk1 [reps=50] [H W]"""
+usage: python tools/kpair.py pair_dk2s|pair_dk3s|pair_dk1 [reps=50] [H W]
+KPAIR_GRAPH=n: the timed loop is a captured graph of n (pair, flush) launches, replayed reps / n times -- no host launch rate in the figure
+(the eager loop issues two ctypes calls per iteration; at ~75 us per iteration it can be the host that is timed)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from boosting_nerv_amd import _lib as L, ops
@@ -27,11 +29,23 @@ def one():
 for _ in range(5):
     one()
 ops._flush_deferred(); torch.cuda.synchronize()
+NG = int(os.environ.get("KPAIR_GRAPH", "0"))
+graph = None
+if NG:
+    graph = torch.cuda.CUDAGraph()
+    with L.graph_capture(graph):
+        for _ in range(NG):
+            one()
+            ops._flush_deferred()
+    reps = max(1, reps // NG)
 for trial in range(3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
+        if graph is not None:
+            graph.replay()
+            continue
         one()
         ops._flush_deferred()      # (a small launch per pair: its cost is in both arms; keeps the queue from growing)
     e1.record(); torch.cuda.synchronize()
-    print(f"{which} {H}x{W} FOLD={os.environ.get('BNERV_PAIR_FOLD','default')} FUSED={os.environ.get('BNERV_PAIR_FUSED','default')}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us per (pair + flush)")
+    print(f"{which} {H}x{W} FOLD={os.environ.get('BNERV_PAIR_FOLD','default')} FUSED={os.environ.get('BNERV_PAIR_FUSED','default')} graph={NG}: {e0.elapsed_time(e1) / (reps * max(NG, 1)) * 1e3:.1f} us per (pair + flush)")
