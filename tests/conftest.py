@@ -141,7 +141,9 @@ def pytest_unconfigure(config):
             tr._tw.flush()
     except Exception:       # noqa: BLE001
         pass
-    from boosting_nerv_amd.runtime import hard_exit
+    from boosting_nerv_amd.runtime import hard_exit, tool_attached
+    if tool_attached():      # (a profiler writes its output from a C-level exit handler: leave the regular way)
+        return
     hard_exit(_session_status[0])
 
 

@@ -570,3 +570,30 @@ def test_gpu_sessions_end_without_interpreter_teardown_and_keep_their_status():
         r = subprocess.run([sys.executable, "-m", "pytest", "tests/isolation_probe.py", "-q", "-p", "no:cacheprovider", "-k", "nothing_matches"],
                            cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 5, (r.returncode, r.stdout[-300:])
+
+
+def test_hard_exit_leaves_the_regular_way_under_a_profiler():
+    """runtime.hard_exit skips the interpreter teardown (os._exit) -- but rocprofv3 writes its traces from a C-level exit handler, which
+    os._exit would skip too (`rocprofv3 --kernel-trace --stats -- python bench.py` left an empty directory).  Under a tool's environment
+    the script must leave through the regular exit: the exit handler of a C library (tests/native/exitmark.c) runs; without the tool it
+    does not (that is the hard exit); the exit status is kept either way."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        so = os.path.join(td, "libexitmark.so")
+        subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", so, os.path.join(ROOT, "tests", "native", "exitmark.c")], check=True, timeout=120)
+        path = os.path.join(td, "prog.py")
+        with open(path, "w") as f:
+            f.write("import ctypes, sys\n"
+                    "sys.path.insert(0, %r)\n"
+                    "ctypes.CDLL(%r)\n"
+                    "from boosting_nerv_amd.runtime import hard_exit\n"
+                    "print('result line', flush=True)\n"
+                    "hard_exit(3)\n" % (ROOT, so))
+        base = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "HSA_TOOLS"))}
+        base.pop("LD_PRELOAD", None)
+        # (ROCPROF_OUTPUT_PATH: one of the variables rocprofv3 always sets for its child, and one the ROCm runtime itself does not act on)
+        plain = subprocess.run([sys.executable, path], env=base, capture_output=True, text=True, timeout=120)
+        assert plain.returncode == 3 and "result line" in plain.stdout and "C-LEVEL-EXIT-HANDLER" not in plain.stdout, (plain.returncode, plain.stdout, plain.stderr[-300:])
+        tool = subprocess.run([sys.executable, path], env=dict(base, ROCPROF_OUTPUT_PATH=td), capture_output=True, text=True, timeout=120)
+        assert tool.returncode == 3 and "result line" in tool.stdout and "C-LEVEL-EXIT-HANDLER" in tool.stdout, (tool.returncode, tool.stdout, tool.stderr[-300:])
