@@ -22,6 +22,7 @@
 #include "common.h"
 #include <vector>
 #include <math.h>
+#include <string.h>
 #include <map>
 #include <mutex>
 
@@ -202,6 +203,7 @@ struct SsimArgs {
     int tiles_x, tiles_y;
     float C1, C2;
     float k_l1, k_l2;          // level 0 only: extra terms k_l1*sign(d) + k_l2*d
+    int acc;                   // level 0 only: dX += (1) instead of dX = (0) -- the spectral gradient is already there (see loss_coarse_kernel)
     Win win;
 };
 
@@ -370,12 +372,19 @@ __global__ __launch_bounds__(320) void ms_coef_kernel(const CoefArgs a) { ms_coe
 // ---- backward from the stored statistic gradients: adjoint of the separable "valid" filter over the 3 maps, then
 //      dX = coef * (A0 + 2 x A1 + y A2) [+ 0.25 * d(coarser level)] [+ L1/L2 terms at level 0].  ~6x less arithmetic than
 //      recomputing the statistics on a 36x52 window per tile.
-struct CoarseChain { const float* own[LV]; int H[LV], W[LV]; int n; };     // level-0 form: the coarser levels' OWN terms (n of them), combined here
+// level-0 form: the coarser levels' OWN terms (n of them), combined here; ph / pw[k]: the zero padding level k was pooled into level k + 1 with
+// (0 on an even pyramid; 1080 -> 540 -> 270 -> 135 -> 68 pads 135), so pixel (y, x) of level k lies in cell ((y + ph) / 2, (x + pw) / 2)
+struct CoarseChain { const float* own[LV]; int H[LV], W[LV], ph[LV], pw[LV]; int n; };
+constexpr int SSIM_BWD_LDS = 3 * (2 * STH + HW_) * (STW + HW_);     // floats: a packed pair and a single map, each (26 + 16) x 42
+// `lds`: SSIM_BWD_LDS floats of the caller's LDS (8-byte aligned) -- a pointer so that a kernel whose blocks run EITHER this body or an FFT
+// body (loss_coarse_kernel) can give both the same allocation: two static arrays would add up and halve the blocks per CU
 template <bool LEVEL0>
-__device__ __forceinline__ void ssim_bwd_body(const SsimArgs& a, const CoarseChain* cc, const int bx, const int by, const int bc, const int nbc) {
+__device__ __forceinline__ void ssim_bwd_body(const SsimArgs& a, const CoarseChain* cc, float* lds, const int bx, const int by, const int bc, const int nbc) {
     constexpr int GH = STH + HW_, GW = STW + HW_;        // 26 x 42 statistic-gradient region
-    __shared__ pk2 sG01[GH][GW], sA01[STH][GW];          // packed pairs of maps, as in the forward pass
-    __shared__ float sG2[GH][GW], sA2[STH][GW];
+    pk2 (*sG01)[GW] = reinterpret_cast<pk2 (*)[GW]>(lds);                                   // packed pairs of maps, as in the forward pass
+    pk2 (*sA01)[GW] = reinterpret_cast<pk2 (*)[GW]>(lds + 2 * GH * GW);
+    float (*sG2)[GW] = reinterpret_cast<float (*)[GW]>(lds + 2 * GH * GW + 2 * STH * GW);
+    float (*sA2)[GW] = reinterpret_cast<float (*)[GW]>(lds + 3 * GH * GW + 2 * STH * GW);
     const int tid = threadIdx.x;
     const int py0 = by * STH, px0 = bx * STW;
     const int wy0 = py0 - HW_, wx0 = px0 - HW_;
@@ -439,8 +448,14 @@ __device__ __forceinline__ void ssim_bwd_body(const SsimArgs& a, const CoarseCha
             // even pyramid: the coarser levels stored only their OWN terms; d_k = own_k + 0.25 d_{k+1} is evaluated here, innermost first,
             // exactly as the level-by-level launches did (0.25 * is exact), so the gradient keeps its bits
             float dc = 0.f;
-            for (int k = cc->n; k >= 1; --k) {
-                const float o = cc->own[k][((size_t)bc * cc->H[k] + (y >> k)) * cc->W[k] + (x >> k)];
+            int yk[LV], xk[LV];
+            yk[0] = y; xk[0] = x;
+#pragma unroll
+            for (int k = 1; k < LV; ++k) { yk[k] = (yk[k - 1] + cc->ph[k - 1]) >> 1; xk[k] = (xk[k - 1] + cc->pw[k - 1]) >> 1; }
+#pragma unroll
+            for (int k = LV - 1; k >= 1; --k) {
+                if (k > cc->n) continue;
+                const float o = cc->own[k][((size_t)bc * cc->H[k] + yk[k]) * cc->W[k] + xk[k]];
                 dc = (k == cc->n) ? o : o + 0.25f * dc;
             }
             d += 0.25f * dc;
@@ -450,22 +465,33 @@ __device__ __forceinline__ void ssim_bwd_body(const SsimArgs& a, const CoarseCha
             const float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
             d += a.k_l1 * sg + a.k_l2 * df;
         }
-        a.dX[((size_t)bc * a.H + y) * a.W + x] = d;
+        float* dst = a.dX + ((size_t)bc * a.H + y) * a.W + x;
+        *dst = (LEVEL0 && a.acc) ? d + *dst : d;
     }
 }
 template <bool LEVEL0>
-__global__ __launch_bounds__(256) void ssim_bwd_from_g_kernel(const SsimArgs a) { const Tile3 t = xcd_tile3(); ssim_bwd_body<LEVEL0>(a, nullptr, t.x, t.y, t.z, gridDim.z); }
-__global__ __launch_bounds__(256) void ssim_bwd_level0_chain_kernel(const SsimArgs a, const CoarseChain cc) { const Tile3 t = xcd_tile3(); ssim_bwd_body<true>(a, &cc, t.x, t.y, t.z, gridDim.z); }
+__global__ __launch_bounds__(256) void ssim_bwd_from_g_kernel(const SsimArgs a) {
+    __shared__ __attribute__((aligned(16))) float sl[SSIM_BWD_LDS];
+    const Tile3 t = xcd_tile3(); ssim_bwd_body<LEVEL0>(a, nullptr, sl, t.x, t.y, t.z, gridDim.z);
+}
+__global__ __launch_bounds__(256) void ssim_bwd_level0_chain_kernel(const SsimArgs a, const CoarseChain cc) {
+    __shared__ __attribute__((aligned(16))) float sl[SSIM_BWD_LDS];
+    const Tile3 t = xcd_tile3(); ssim_bwd_body<true>(a, &cc, sl, t.x, t.y, t.z, gridDim.z);
+}
 // levels 1 .. LV-1 in one launch, each writing only its OWN term (no coarser contribution: the level-0 launch combines them)
-__global__ __launch_bounds__(256) void ssim_bwd_coarse_all_kernel(const SsimAllArgs a) {
-    const int lb = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
-    const int gbx = lb % (int)gridDim.x, gby = lb / (int)gridDim.x;
+__device__ __forceinline__ void ssim_bwd_coarse_body(const SsimAllArgs& a, float* lds, const int lin, const int gx, const int nbc) {
+    const int lb = xcd_remap(lin, gx * nbc);
+    const int gbx = lb % gx, gby = lb / gx;
     int l = 1;
 #pragma unroll
     for (int k = 2; k < LV; ++k) if (gbx >= a.first[k]) l = k;
     const int t = gbx - a.first[l];
     const int tx = cdiv_d(a.lv[l].W, STW);
-    ssim_bwd_body<false>(a.lv[l], nullptr, t % tx, t / tx, gby, gridDim.y);
+    ssim_bwd_body<false>(a.lv[l], nullptr, lds, t % tx, t / tx, gby, nbc);
+}
+__global__ __launch_bounds__(256) void ssim_bwd_coarse_all_kernel(const SsimAllArgs a) {
+    __shared__ __attribute__((aligned(16))) float sl[SSIM_BWD_LDS];
+    ssim_bwd_coarse_body(a, sl, (int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.x, (int)gridDim.y);
 }
 
 // =====================================================================================================================
@@ -851,11 +877,11 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const FftArgs a) {      /
     fft_cols_body(a, lb % (int)gridDim.x, lb / (int)gridDim.x, gridDim.x);
 }
 
-__global__ __launch_bounds__(256) void fft_rows_adj_kernel(const FftArgs a) {
+__device__ __forceinline__ void fft_rows_adj_body(const FftArgs& a, const int bx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float2* buf = reinterpret_cast<float2*>(sm);
     const int W = a.W;
-    const size_t row0 = (size_t)blockIdx.x * ROWS_PER_BLOCK;
+    const size_t row0 = (size_t)bx * ROWS_PER_BLOCK;
     const size_t nrows = (size_t)a.BC * a.H;
     const int nl = (int)min((size_t)ROWS_PER_BLOCK, nrows - row0);
     const int nlines = (nl + 1) >> 1;
@@ -932,6 +958,7 @@ __global__ __launch_bounds__(256) void fft_rows_adj_kernel(const FftArgs a) {
         }
     }
 }
+__global__ __launch_bounds__(256) void fft_rows_adj_kernel(const FftArgs a) { fft_rows_adj_body(a, blockIdx.x); }
 
 // =====================================================================================================================
 // final combine: per-sample loss, batch mean, stats
@@ -1007,8 +1034,21 @@ __global__ __launch_bounds__(256) void loss_mid_kernel(const LossMidArgs a) {
 }
 struct LossTailArgs { SsimArgs s; CoarseChain cc; FinalArgs fin; int gx, gy, n0, BC; };
 __global__ __launch_bounds__(256) void loss_tail_kernel(const LossTailArgs a) {
-    if ((int)blockIdx.x < a.n0) { const int b = xcd_remap((int)blockIdx.x, a.n0); const int bx = b % a.gx, r = b / a.gx; ssim_bwd_body<true>(a.s, &a.cc, bx, r % a.gy, r / a.gy, a.BC); }
+    __shared__ __attribute__((aligned(16))) float sl[SSIM_BWD_LDS];
+    if ((int)blockIdx.x < a.n0) { const int b = xcd_remap((int)blockIdx.x, a.n0); const int bx = b % a.gx, r = b / a.gx; ssim_bwd_body<true>(a.s, &a.cc, sl, bx, r % a.gy, r / a.gy, a.BC); }
     else if (threadIdx.x < 64) loss_final_body(a.fin);
+}
+// coarse:  adjoint row FFTs (the spectral gradient, WRITTEN to grad)  |  the coarser levels' SSIM gradient terms.  Both only need what `mid`
+// left behind and neither fills the chip (1080 one-line blocks of 17 us, 619 short tiles at 720p); the level-0 launch then ADDS its
+// gradient to the spectral one (SsimArgs::acc) instead of a sixth launch accumulating onto it.  One dynamic LDS allocation serves both bodies.
+// (Slot-bound at 720p: 84 VGPRs -> 5 blocks per CU = 1280 slots for 1080 x ~14 us + 1857 x ~5.5 us of block time = 23.8 us against 12.7 + 17.9
+// as two launches; forcing 80 VGPRs for a sixth block spills 22 registers in the butterflies and measured 29 us.)
+struct LossCoarseArgs { FftArgs f; SsimAllArgs s; int n_adj, gx, BC; };
+__global__ __launch_bounds__(256) void loss_coarse_kernel(const LossCoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x;
+    if (b < a.n_adj) { fft_rows_adj_body(a.f, b); return; }              // the long blocks first
+    ssim_bwd_coarse_body(a.s, sm, b - a.n_adj, a.gx, a.BC);
 }
 __global__ void msssim_final_kernel(const float* __restrict__ msval, float* __restrict__ out, int B, int C) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1055,11 +1095,31 @@ static WsLayout make_layout(int B, int C, int H, int W, bool use_ms, bool use_ff
     return L;
 }
 
+static bool loss_fused() {                              // BNERV_LOSS_FUSED=0: the level-by-level MS-SSIM launches (A/B switch, read per call: tests compare the forms)
+    const char* e = getenv("BNERV_LOSS_FUSED");
+    return !(e && e[0] == '0');
+}
 static bool even_pyramid(const WsLayout& L) {         // every pooled level has even sides: no padding anywhere, aligned 2x2 cells
-    const char* e = getenv("BNERV_LOSS_FUSED");                 // A/B switch, read per call (tests compare the two forms bit for bit)
-    if (e && e[0] == '0') return false;
+    if (!loss_fused()) return false;
     for (int l = 0; l < LV - 1; ++l) if ((L.pyr.H[l] & 1) || (L.pyr.W[l] & 1)) return false;
     return true;
+}
+static bool adj_late() {                                // BNERV_LOSS_ADJ=late: round 4's order -- the adjoint row pass as the LAST launch, accumulating
+    const char* e = getenv("BNERV_LOSS_ADJ");           // onto the finished SSIM gradient (A/B switch, read per call; the gradient differs in the last bit:
+    return e && !strcmp(e, "late");                     // fma(k, r, d) there, d + k r here)
+}
+// the 2x2 means of an ODD pyramid, level by level (zero padding where a side is odd, count_include_pad)
+static int launch_pools(hipStream_t st, const float* X, const float* Y, float* ws, const WsLayout& L, int BC) {
+    const float* Xl = X; const float* Yl = Y;
+    for (int l = 0; l < LV - 1; ++l) {
+        const int Hl = L.pyr.H[l], Wl = L.pyr.W[l], Ho = L.pyr.H[l + 1], Wo = L.pyr.W[l + 1];
+        const size_t n = (size_t)BC * Ho * Wo;
+        int gx = (int)((n + 255) / 256); if (gx > 4096) gx = 4096;
+        hipLaunchKernelGGL(avgpool2_kernel, dim3(gx, 1, 2), dim3(256), 0, st, Xl, Yl, ws + L.pyrX[l + 1], ws + L.pyrY[l + 1], BC, Hl, Wl, Ho, Wo, Hl % 2, Wl % 2);
+        BNERV_LAUNCH_CHECK("avgpool2");
+        Xl = ws + L.pyrX[l + 1]; Yl = ws + L.pyrY[l + 1];
+    }
+    return BNERV_OK;
 }
 
 static bool loss_merged() {                             // BNERV_LOSS_MERGED=0: every launch of the even-pyramid form on its own (A/B switch, read per call)
@@ -1095,7 +1155,7 @@ static int fill_even_forward(const float* X, const float* Y, float* ws, const Ws
     return BNERV_OK;
 }
 // ... and of the even-pyramid backward launches (the coarser levels' own terms; level 0 with the 0.25-chain over them)
-static void fill_even_backward(const float* X, const float* Y, float* grad, float* ws, const WsLayout& L, int BC, float k_l1, float k_l2, SsimAllArgs& sa, CoarseChain& cc) {
+static void fill_even_backward(const float* X, const float* Y, float* grad, float* ws, const WsLayout& L, int BC, float k_l1, float k_l2, int acc, SsimAllArgs& sa, CoarseChain& cc) {
     const Win win = make_win();
     int nblk = 0;
     for (int l = 0; l < LV; ++l) {
@@ -1105,8 +1165,9 @@ static void fill_even_backward(const float* X, const float* Y, float* grad, floa
         a.k_l1 = k_l1; a.k_l2 = k_l2; a.G = ws + L.Gl[l];
         sa.first[l] = nblk;
         if (l >= 1) nblk += cdiv(a.W, STW) * cdiv(a.H, STH);
-        cc.own[l] = l ? ws + L.dXl[l] : nullptr; cc.H[l] = a.H; cc.W[l] = a.W;
+        cc.own[l] = l ? ws + L.dXl[l] : nullptr; cc.H[l] = a.H; cc.W[l] = a.W; cc.ph[l] = a.H % 2; cc.pw[l] = a.W % 2;
     }
+    sa.lv[0].acc = acc;
     sa.first[LV] = nblk;
     cc.n = LV - 1;
 }
@@ -1137,15 +1198,8 @@ static int run_ms_forward(hipStream_t st, const float* X, const float* Y, float*
             PyrArgs pa{}; SsimAllArgs sa{}; CoefArgs ca{};
             int rc = fill_even_forward(X, Y, ws, L, BC, chain, want_g, pa, sa, ca);
             if (rc) return rc;
-            const float* Xl = X; const float* Yl = Y;
-            for (int l = 0; l < LV - 1; ++l) {
-                const int Hl = L.pyr.H[l], Wl = L.pyr.W[l], Ho = L.pyr.H[l + 1], Wo = L.pyr.W[l + 1];
-                const size_t n = (size_t)BC * Ho * Wo;
-                int gx = (int)((n + 255) / 256); if (gx > 4096) gx = 4096;
-                hipLaunchKernelGGL(avgpool2_kernel, dim3(gx, 1, 2), dim3(256), 0, st, Xl, Yl, ws + L.pyrX[l + 1], ws + L.pyrY[l + 1], BC, Hl, Wl, Ho, Wo, Hl % 2, Wl % 2);
-                BNERV_LAUNCH_CHECK("avgpool2");
-                Xl = ws + L.pyrX[l + 1]; Yl = ws + L.pyrY[l + 1];
-            }
+            rc = launch_pools(st, X, Y, ws, L, BC);
+            if (rc) return rc;
             hipLaunchKernelGGL(ssim_fwd_all_kernel, dim3(sa.first[LV], BC), dim3(256), 0, st, sa);
             BNERV_LAUNCH_CHECK("ssim_fwd_all");
             hipLaunchKernelGGL(ms_coef_kernel, dim3(BC), dim3(320), 0, st, ca);
@@ -1184,14 +1238,16 @@ static int run_ms_forward(hipStream_t st, const float* X, const float* Y, float*
     return BNERV_OK;
 }
 
-static int run_ms_backward(hipStream_t st, const float* X, const float* Y, float* grad, float* ws, const WsLayout& L, int B, int C, float k_l1, float k_l2) {
+// acc: the level-0 launch adds to `grad` (the spectral gradient is already there) instead of writing it
+static int run_ms_backward(hipStream_t st, const float* X, const float* Y, float* grad, float* ws, const WsLayout& L, int B, int C, float k_l1, float k_l2, int acc) {
     const int BC = B * C;
     const Win win = make_win();
-    if (even_pyramid(L)) {
-        // 2 launches instead of 5: the coarser levels' own terms together, then level 0 with the 0.25-chain over them
+    if (loss_fused()) {
+        // 2 launches instead of 5: the coarser levels' own terms together, then level 0 with the 0.25-chain over them (odd pyramids too:
+        // the chain walks the padded cells, CoarseChain::ph / pw)
         SsimAllArgs sa{};
         CoarseChain cc{};
-        fill_even_backward(X, Y, grad, ws, L, BC, k_l1, k_l2, sa, cc);
+        fill_even_backward(X, Y, grad, ws, L, BC, k_l1, k_l2, acc, sa, cc);
         hipLaunchKernelGGL(ssim_bwd_coarse_all_kernel, dim3(sa.first[LV], BC), dim3(256), 0, st, sa);
         BNERV_LAUNCH_CHECK("ssim_bwd_coarse_all");
         hipLaunchKernelGGL(ssim_bwd_level0_chain_kernel, dim3(cdiv(L.pyr.W[0], STW), cdiv(L.pyr.H[0], STH), BC), dim3(256), 0, st, sa.lv[0], cc);
@@ -1206,7 +1262,7 @@ static int run_ms_backward(hipStream_t st, const float* X, const float* Y, float
         a.dX = l ? ws + L.dXl[l] : grad;
         a.H = Hl; a.W = Wl; a.C1 = 0.01f * 0.01f; a.C2 = 0.03f * 0.03f; a.win = win;
         if (l < LV - 1) { a.dcoarse = ws + L.dXl[l + 1]; a.Hc = L.pyr.H[l + 1]; a.Wc = L.pyr.W[l + 1]; a.ph = Hl % 2; a.pw = Wl % 2; }
-        a.k_l1 = k_l1; a.k_l2 = k_l2;
+        a.k_l1 = k_l1; a.k_l2 = k_l2; a.acc = l == 0 ? acc : 0;
         a.G = ws + L.Gl[l];
         dim3 grid(cdiv(Wl, STW), cdiv(Hl, STH), BC);
         if (l == 0) hipLaunchKernelGGL((ssim_bwd_from_g_kernel<true>), grid, dim3(256), 0, st, a);
@@ -1264,18 +1320,22 @@ extern "C" int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* dp) {
     f.loss_out = d.loss_out; f.stats_out = d.stats_out; f.B = d.B; f.C = d.C; f.n_per_sample = nps; f.ncolblk = L.ncolblk;
     f.c_l1 = d.c_l1; f.c_l2 = d.c_l2; f.c_ms = d.c_ms; f.c_fft = d.c_fft;
 
-    if (use_ms && use_fft && d.grad && even_pyramid(L) && loss_merged()) {
-        // 6 launches: head (row FFTs | pyramid | L1 / L2 sums), SSIM statistics, mid (column FFTs | coefficients), coarse SSIM
-        // gradients, tail (level-0 gradient | loss_final), adjoint row FFTs (adds the spectral gradient)
+    const bool late = adj_late();
+    if (use_ms && use_fft && d.grad && loss_fused() && loss_merged()) {
+        // 5 launches on an even pyramid (9 on an odd one, whose four pooled levels are a launch each): head (row FFTs | pyramid | L1 / L2 sums),
+        // SSIM statistics, mid (column FFTs | coefficients), coarse (adjoint row FFTs -> the spectral gradient | coarse SSIM gradients),
+        // tail (level-0 gradient, added to the spectral one | loss_final).  BNERV_LOSS_ADJ=late: the adjoint rows as a sixth launch behind the tail.
+        const bool even = even_pyramid(L);
         LossHeadArgs ha{}; LossMidArgs ma{}; LossTailArgs ta{};
         SsimAllArgs sf{};
         int rc = fill_even_forward(d.pred, d.target, ws, L, BC, -d.c_ms / (float)BC, true, ha.p, sf, ma.c);
         if (rc) return rc;
         ha.f = a; ha.pred = d.pred; ha.target = d.target; ha.stats_part = ws + L.stats_part; ha.nps = nps;
-        ha.n_fft = nrowblk; ha.pyr_gx = cdiv(L.pyr.W[1], 16); ha.pyr_gy = cdiv(L.pyr.H[1], 16); ha.n_pyr = ha.pyr_gx * ha.pyr_gy * 2 * BC;
+        ha.n_fft = nrowblk; ha.pyr_gx = cdiv(L.pyr.W[1], 16); ha.pyr_gy = cdiv(L.pyr.H[1], 16); ha.n_pyr = even ? ha.pyr_gx * ha.pyr_gy * 2 * BC : 0;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
         hipLaunchKernelGGL(loss_head_kernel, dim3(ha.n_fft + ha.n_pyr + NSB * d.B), dim3(256), lds_row, st, ha);
         BNERV_LAUNCH_CHECK("loss_head");
+        if (!even) { rc = launch_pools(st, d.pred, d.target, ws, L, BC); if (rc) return rc; }
         hipLaunchKernelGGL(ssim_fwd_all_kernel, dim3(sf.first[LV], BC), dim3(256), 0, st, sf);
         BNERV_LAUNCH_CHECK("ssim_fwd_all");
         ma.f = a; ma.ncolblk = L.ncolblk; ma.n_cols = L.ncolblk * BC;
@@ -1283,43 +1343,61 @@ extern "C" int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* dp) {
         hipLaunchKernelGGL(loss_mid_kernel, dim3(ma.n_cols + BC), dim3(256), lds_col, st, ma);
         BNERV_LAUNCH_CHECK("loss_mid");
         SsimAllArgs sb{};
-        fill_even_backward(d.pred, d.target, d.grad, ws, L, BC, k_l1, k_l2, sb, ta.cc);
-        hipLaunchKernelGGL(ssim_bwd_coarse_all_kernel, dim3(sb.first[LV], BC), dim3(256), 0, st, sb);
-        BNERV_LAUNCH_CHECK("ssim_bwd_coarse_all");
+        fill_even_backward(d.pred, d.target, d.grad, ws, L, BC, k_l1, k_l2, late ? 0 : 1, sb, ta.cc);
+        if (late) {
+            hipLaunchKernelGGL(ssim_bwd_coarse_all_kernel, dim3(sb.first[LV], BC), dim3(256), 0, st, sb);
+            BNERV_LAUNCH_CHECK("ssim_bwd_coarse_all");
+        } else {
+            LossCoarseArgs ca{};
+            ca.f = a; ca.f.accumulate = 0; ca.s = sb; ca.n_adj = nrowblk; ca.gx = sb.first[LV]; ca.BC = BC;
+            const size_t lds_c = lds_row > SSIM_BWD_LDS * sizeof(float) ? lds_row : SSIM_BWD_LDS * sizeof(float);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_coarse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+            hipLaunchKernelGGL(loss_coarse_kernel, dim3(ca.n_adj + ca.gx * BC), dim3(256), lds_c, st, ca);
+            BNERV_LAUNCH_CHECK("loss_coarse");
+        }
         ta.s = sb.lv[0]; ta.fin = f; ta.gx = cdiv(L.pyr.W[0], STW); ta.gy = cdiv(L.pyr.H[0], STH); ta.BC = BC; ta.n0 = ta.gx * ta.gy * BC;
         hipLaunchKernelGGL(loss_tail_kernel, dim3(ta.n0 + 1), dim3(256), 0, st, ta);
         BNERV_LAUNCH_CHECK("loss_tail");
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_adj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
-        hipLaunchKernelGGL(fft_rows_adj_kernel, dim3(nrowblk), dim3(256), lds_row, st, a);
-        BNERV_LAUNCH_CHECK("fft_rows_adj");
+        if (late) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_adj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
+            hipLaunchKernelGGL(fft_rows_adj_kernel, dim3(nrowblk), dim3(256), lds_row, st, a);
+            BNERV_LAUNCH_CHECK("fft_rows_adj");
+        }
         return BNERV_OK;
     }
 
+    // one launch per kernel.  With both an MS-SSIM and a spectral term the spectral gradient is written FIRST and the level-0 SSIM launch adds
+    // to it -- the arithmetic of the merged form above, so the two forms agree bit for bit (BNERV_LOSS_ADJ=late: the other order, in both forms)
+    const bool fft_first = use_ms && use_fft && d.grad && !late;
     int rc = launch_stats(st, d.pred, d.target, ws + L.stats_part, d.B, nps);
     if (rc) return rc;
+    auto run_fft = [&](int accumulate) -> int {
+        FftArgs fa = a; fa.accumulate = accumulate;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_adj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_col);
+        hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(nrowblk), dim3(256), lds_row, st, fa);
+        BNERV_LAUNCH_CHECK("fft_rows_fwd");
+        hipLaunchKernelGGL(fft_cols_kernel, dim3(L.ncolblk, BC), dim3(256), lds_col, st, fa);
+        BNERV_LAUNCH_CHECK("fft_cols");
+        if (d.grad) {
+            hipLaunchKernelGGL(fft_rows_adj_kernel, dim3(nrowblk), dim3(256), lds_row, st, fa);
+            BNERV_LAUNCH_CHECK("fft_rows_adj");
+        }
+        return BNERV_OK;
+    };
     if (use_ms) {
         rc = run_ms_forward(st, d.pred, d.target, ws, L, d.B, d.C, -d.c_ms / (float)BC, d.grad != nullptr);
         if (rc) return rc;
-        if (d.grad) { rc = run_ms_backward(st, d.pred, d.target, d.grad, ws, L, d.B, d.C, k_l1, k_l2); if (rc) return rc; }
+        if (fft_first) { rc = run_fft(0); if (rc) return rc; }
+        if (d.grad) { rc = run_ms_backward(st, d.pred, d.target, d.grad, ws, L, d.B, d.C, k_l1, k_l2, fft_first ? 1 : 0); if (rc) return rc; }
     } else if (d.grad) {
         const size_t n = (size_t)d.B * nps;
         int gx = (int)((n + 1023) / 1024); if (gx > 4096) gx = 4096;
         hipLaunchKernelGGL(grad_l1l2_kernel, dim3(gx), dim3(256), 0, st, d.pred, d.target, d.grad, n, k_l1, k_l2);
         BNERV_LAUNCH_CHECK("grad_l1l2");
     }
-    if (use_fft) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rows_adj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_col);
-        hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(nrowblk), dim3(256), lds_row, st, a);
-        BNERV_LAUNCH_CHECK("fft_rows_fwd");
-        hipLaunchKernelGGL(fft_cols_kernel, dim3(L.ncolblk, BC), dim3(256), lds_col, st, a);
-        BNERV_LAUNCH_CHECK("fft_cols");
-        if (d.grad) {
-            hipLaunchKernelGGL(fft_rows_adj_kernel, dim3(nrowblk), dim3(256), lds_row, st, a);
-            BNERV_LAUNCH_CHECK("fft_rows_adj");
-        }
-    }
+    if (use_fft && !fft_first) { rc = run_fft(1); if (rc) return rc; }
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, f);
     BNERV_LAUNCH_CHECK("loss_final");
     return BNERV_OK;

@@ -760,8 +760,9 @@ def test_wide_split_kernels_keep_the_f32_contract():
 
 @pytest.mark.parametrize("shape", [(1, 3, 720, 1280), (2, 3, 176, 208), (1, 1, 192, 352), (1, 3, 1080, 1920), (2, 3, 180, 270)])
 def test_fused_msssim_launches_equal_the_level_by_level_form(ops, shape, monkeypatch):
-    """(The last two shapes have ODD pyramid levels -- 1080 -> ... -> 135 -> 68, and odd from level 0: there only the statistics of the five
-    levels share one launch (round 4), the padded 2x2 means and the gradient chain stay level by level.)
+    """(The last two shapes have ODD pyramid levels -- 1080 -> ... -> 135 -> 68, and odd from level 0: there the padded 2x2 means stay a
+    launch per level; the statistics of the five levels share one launch (round 4) and, since round 5, the gradient takes the same two
+    launches as on an even pyramid -- the 0.25-chain walks the padded cells ((y + pad) / 2 per level).)
     Frames whose pyramid has even sides take the fused MS-SSIM launches (one pyramid kernel, one statistics launch for all five
     levels, the coarser levels' gradients in one launch and their 0.25-chain evaluated inside the level-0 launch: 5 launches instead of
     15).  Same formulas on the same data; the compiler contracts a few multiply-adds differently in the two forms, so the comparison
@@ -780,11 +781,13 @@ def test_fused_msssim_launches_equal_the_level_by_level_form(ops, shape, monkeyp
     assert (ga - gb).abs().max().item() <= 3e-5 * gb.abs().max().item()      # (a0 + 2 x a1 + y a2 cancels: a different contraction shows at 1e-5 of the largest entry)
 
 
-@pytest.mark.parametrize("shape", [(1, 3, 720, 1280), (2, 3, 176, 208)])
+@pytest.mark.parametrize("shape", [(1, 3, 720, 1280), (2, 3, 176, 208), (1, 3, 1080, 1920), (2, 3, 180, 270)])
 def test_merged_loss_launches_change_no_bit(ops, shape, monkeypatch):
-    """Fusion10_freq on an even pyramid: independent launches share one grid as block ranges (row FFTs | pyramid | L1 / L2 sums; column
-    FFTs | MS-SSIM coefficients; level-0 gradient | loss_final -- 6 launches instead of 10).  The bodies are the same code, so the loss,
-    the per-sample statistics and the gradient are BIT-equal to the one-launch-per-kernel form (BNERV_LOSS_MERGED=0)."""
+    """Fusion10_freq: independent launches share one grid as block ranges (row FFTs | pyramid | L1 / L2 sums; column FFTs | MS-SSIM
+    coefficients; adjoint row FFTs | coarse SSIM gradients; level-0 gradient | loss_final -- 5 launches instead of 10 on an even pyramid,
+    9 instead of 16 on an odd one (the last two shapes), whose pooled levels stay a launch each).  The bodies are the same code in the same
+    order (spectral gradient written first, level-0 SSIM gradient added to it), so the loss, the per-sample statistics and the gradient are
+    BIT-equal to the one-launch-per-kernel form (BNERV_LOSS_MERGED=0)."""
     g = torch.Generator().manual_seed(7 + sum(shape))
     tgt = torch.rand(*shape, generator=g).to(DEV)
     pred = (tgt + 0.1 * torch.randn(*shape, generator=g).to(DEV)).clamp(0, 1)
@@ -795,6 +798,27 @@ def test_merged_loss_launches_change_no_bit(ops, shape, monkeypatch):
         out[mode] = (loss.clone(), stats.clone(), grad.clone())
     for a, b in zip(out["1"], out["0"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 720, 1280), (1, 3, 1080, 1920), (2, 3, 180, 270)])
+def test_spectral_gradient_first_or_last_is_the_same_gradient(ops, shape, monkeypatch):
+    """The adjoint row FFTs either write the spectral gradient before the level-0 SSIM launch adds to it (default: they share the coarse
+    SSIM launch) or accumulate onto the finished gradient as a last launch (BNERV_LOSS_ADJ=late, round 4's order).  Same terms, one rounding
+    apart (d + k r against fma(k, r, d)): loss and statistics bit-equal, the gradient within 2e-7 of its largest entry -- in the merged and
+    in the one-launch-per-kernel form."""
+    g = torch.Generator().manual_seed(11 + sum(shape))
+    tgt = torch.rand(*shape, generator=g).to(DEV)
+    pred = (tgt + 0.1 * torch.randn(*shape, generator=g).to(DEV)).clamp(0, 1)
+    for merged in ("1", "0"):
+        monkeypatch.setenv("BNERV_LOSS_MERGED", merged)
+        out = {}
+        for mode in ("early", "late"):
+            monkeypatch.setenv("BNERV_LOSS_ADJ", mode)
+            loss, stats, grad = ops.loss_value_grad_stats(pred, tgt, "Fusion10_freq")
+            out[mode] = (loss.clone(), stats.clone(), grad.clone())
+        assert torch.equal(out["early"][0], out["late"][0]) and torch.equal(out["early"][1], out["late"][1])
+        ga, gb = out["early"][2], out["late"][2]
+        assert (ga - gb).abs().max().item() <= 2e-7 * gb.abs().max().item(), (merged, (ga - gb).abs().max().item(), gb.abs().max().item())
 
 
 def test_msssim_kernel_against_independent_form(ops):
