@@ -3,7 +3,7 @@ every 30 epochs, 8-bit quantised twin, Huffman bits per pixel -- through THIS re
 (132 x 3x720x1280; no dataset ships), run TWICE with the clip resident in HBM, plus a shorter run on PNG files of the same clip through the
 reference's DataLoader path (VideoDataSet, shuffle=True, num_workers=4, pin_memory, one host -> device copy per step).
 
-    python tools/recipe_record.py [epochs=300] [tag=r04]        (through gpurun, repo root)
+    python tools/recipe_record.py [epochs=300] [tag=r05]        (through gpurun, repo root)
         -> gpurun_out/<tag>_cli_c1_e<epochs>.txt   both invocations' wall time, the script's own "Training wo evaluation" line, every Eval line
         -> gpurun_out/<tag>_cli_c1_e<epochs>.json  the numbers bench.py puts on its line as `recipe`
 
@@ -19,7 +19,7 @@ import time
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
 FLAGS = ("--data_path synthetic:bunny --vid bunny --model NeRV_Boost --sft_block res_sft --ch_t 32 --optim_type Adan --conv_type convnext pshuffel_3x3 "
          "--act sin --norm none --crop_list 720_1280 --resize_list -1 --loss Fusion10_freq --embed pe_1.25_80 --fc_hw 9_16 --dec_strds 5 2 2 2 2 --ks 0_3_3 "
          f"--reduce 2 --dec_blks 1 1 2 2 2 --modelsize 0.8 -e {E} --eval_freq 30 --lower_width 12 -b 1 --lr 0.003 --overwrite").split()

@@ -1,10 +1,13 @@
 #!/usr/bin/env bash
 # Round-5 evidence -> gpurun_out/r05_*: PMC traffic of the step's dominant kernels (stamped with their sources), bench lines of C1 / C3 / C4 / C5,
 # rocprofv3 kernel-trace summaries (step kernels only) and per-launch timelines of the replayed steps.  The GPU suite runs are separate
-# (tools/suite_repeat.sh, one lease each).   usage (through gpurun, repo root): tools/round5_evidence.sh [fast]
+# (tools/suite_repeat.sh, one lease each).   usage (through gpurun, repo root): tools/round5_evidence.sh [fast] [nopmc]
 set -u
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
-for k in pair_dk2s pair_dk3s pair_dk1 k2s c4 pair_c4 wide wide_pair; do python tools/pmc_traffic.py $k r05 > /dev/null 2>&1; done
+# (nopmc: keep the committed traffic profiles -- they are stamped with the kernel sources they were measured on and bench.py refuses a stale one)
+if [ "${1:-}" != nopmc ] && [ "${2:-}" != nopmc ]; then
+  for k in pair_dk2s pair_dk3s pair_dk1 k2s c4 pair_c4 wide wide_pair; do python tools/pmc_traffic.py $k r05 > /dev/null 2>&1; done
+fi
 cp $O/r05_traffic_*.json $R/profiles/ 2>/dev/null          # the bench lines below read (and verify) them
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/r05_bench_c1.json 2> $O/r05_bench_c1.err
