@@ -88,7 +88,8 @@ class TrainStep:
         # gradient seeds backward directly and the per-sample PSNR comes from the same L2 sums (stats[:, 4])
         loss, stats, grad = ops.loss_value_grad_stats(img_out, self.static_img, self.loss_type)
         if self._lazy_flush_valid():
-            with ops.lazy_flush():              # the blocks' slab reductions are flushed by their first reader, not once per block
+            # (dx_ok: the model's first block hands its queued input gradient to a flushing operator of this package -- ops._flush_deferred)
+            with ops.lazy_flush(dx_ok=getattr(self.model, "lazy_dx_ok", False)):      # slab reductions are flushed by their first reader, not per block
                 img_out.backward(grad)
         else:
             img_out.backward(grad)

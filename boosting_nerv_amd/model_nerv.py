@@ -149,6 +149,7 @@ def decoder_layers_forward(layers, output, t_embed, out_list, mods=None):
 
 class NeRV_Boost(_CEMHooks, nn.Module):
     lazy_flush_ok = True     # every reader of a deferred slab reduction in this model's backward is an operator of this package (engine.TrainStep)
+    lazy_dx_ok = True        # the first block's input gradient (the stem pair's queued reduction) is read by the stem MLP's grouped dense backward, which flushes
     dp_hook = None           # engine.TrainStep with two gradient buckets: called with d(loss)/d(stem output), i.e. after the decoder's backward
 
     def dp_late_parameters(self):

@@ -67,7 +67,11 @@ def _wgrad_conv_pair(wg, cv):
     """One weight gradient and one data gradient that read the same incoming gradient and do not depend on each other, as ONE launch
     when the library takes the pair (include/bnerv.h bnerv_conv_wgrad_pair: 12-channel 3x3 layers), as the two usual launches
     otherwise.  wg: keyword arguments of _wgrad (x, g, dw, db first), always deferred; cv: keyword arguments of _conv (x, w, bias, out
-    first) for an EP_DGELU_SAVED / EP_DSIN / EP_PLAIN epilogue.  Returns what _conv returns (the [B, 2, C] channel sums, or None)."""
+    first) for an EP_DGELU_SAVED / EP_DSIN / EP_PLAIN epilogue.  Returns what _conv returns (the [B, 2, C] channel sums, or None).
+    Side effect: `_pair_dx_deferred` says whether the DATA gradient itself (cv's `out`) is still a queued slab reduction when the call
+    returns (the stem pair, csrc/stem.hip: its K-slice slabs are summed by a deferred job) -- every other form writes `out` directly."""
+    global _pair_dx_deferred
+    _pair_dx_deferred = False
     lib = L.load()
     x, g, dw, db = wg.pop("x"), wg.pop("g"), wg.pop("dw"), wg.pop("db")
     nbytes = lib.bnerv_conv_wgrad_ws_bytes(wg["B"], wg["Cin"], wg["Cout"], wg["H"], wg["W"], wg["k"])
@@ -98,6 +102,7 @@ def _wgrad_conv_pair(wg, cv):
         L.check(rc, "bnerv_conv_wgrad_pair")
         if skw is not None:
             L.ctx().keep.append(skw)                       # (the stem pair sums its slabs in a deferred reduction: alive until the flush)
+            _pair_dx_deferred = True                       # cv's `out` is complete only after the next flush
     L.ctx().keep.append(ws)
     if red:
         st = torch.empty(cv["B"], 2, cv["Cout"], dtype=torch.float32, device=cx.device)
@@ -120,13 +125,19 @@ def _reduce_slabs(slabs, n_slabs, count, out, defer=False):
 
 
 _lazy_depth = 0       # > 0: inside lazy_flush() -- the per-block flushes are postponed to the first consumer of a deferred result
+_lazy_dx_ok = False   # inside lazy_flush(dx_ok=True): a block may also RETURN a data gradient whose slab reduction is still queued
+_pair_dx_deferred = False   # set by _wgrad_conv_pair: the data gradient of the last pair is a queued slab reduction (the stem pair)
 
 
-def _flush_deferred(force=True, block_end=False):
+def _flush_deferred(force=True, block_end=False, dx_deferred=False):
     """Launch whatever slab reductions are still queued on this stream's context.  `block_end`: the call that closes a block's
     backward -- inside lazy_flush() it is skipped, because the queued results (weight / bias gradients, the per-channel TAT sums) have
-    no reader until the grouped dense backward or the optimizer, and both flush first: ~5 small dependent launches per step less."""
-    if block_end and _lazy_depth > 0:
+    no reader until the grouped dense backward or the optimizer, and both flush first: ~5 small dependent launches per step less.
+    `dx_deferred`: the block returns a DATA gradient that is itself queued (the stem pair): autograd hands it to whatever produced the
+    block's input -- skipped only where the model vouches that this reader is a flushing operator of this package (lazy_flush(dx_ok=True):
+    NeRV_Boost, whose first block is fed by the stem MLP; E-NeRV's first up-conv is fed by a stock torch.sin, which would read the
+    unreduced buffer)."""
+    if block_end and _lazy_depth > 0 and (not dx_deferred or _lazy_dx_ok):
         return
     c = L.ctx()
     L.check(L.load().bnerv_flush_deferred(c.handle, L.stream()), "bnerv_flush_deferred")
@@ -135,16 +146,23 @@ def _flush_deferred(force=True, block_end=False):
 
 class lazy_flush:
     """with lazy_flush(): backward()  -- postpone the end-of-block flushes of the deferred slab reductions; every consumer inside this
-    package (grouped dense / dense GEMM / stand-alone affine backward) flushes on entry, and leaving the context flushes the rest."""
+    package (grouped dense / dense GEMM / stand-alone affine backward) flushes on entry, and leaving the context flushes the rest.
+    dx_ok: the model's promise that a block's INPUT gradient may stay queued too (see _flush_deferred)."""
+
+    def __init__(self, dx_ok=False):
+        self.dx_ok = bool(dx_ok)
 
     def __enter__(self):
-        global _lazy_depth
+        global _lazy_depth, _lazy_dx_ok
         _lazy_depth += 1
+        self._prev = _lazy_dx_ok
+        _lazy_dx_ok = self.dx_ok
         return self
 
     def __exit__(self, *exc):
-        global _lazy_depth
+        global _lazy_depth, _lazy_dx_ok
         _lazy_depth -= 1
+        _lazy_dx_ok = self._prev
         if _lazy_depth == 0:
             _flush_deferred()
         return False
@@ -398,6 +416,10 @@ class _TimeBranch(torch.autograd.Function):
         dxa, dwa, dba = _dense_grouped_bwd([none] * n + [sin], list(hs) + [sy0], w2s + [sw1], list(outs) + [sy1], [None] * n + [saux1],
                                            list(d_outs) + [d_sy1], [True] * (n + 1), [True] * (n + 1), False, B, defer_reduce=True)
         dx4, d_sy0 = dxa[:n], dxa[n]
+        if any(w.shape[0] > L.DENSE_DX_CHUNK for w in w2s):
+            # a modulation MLP wider than one dx chunk (C_i in 65..128): its hidden-layer gradient dx4[i] is itself a queued slab
+            # reduction, and level 2 reads it -- reduce now (one more launch, only for such widths; C1 / C4 widths are <= 59)
+            _flush_deferred()
         # level 2: layer 0 of every MLP (all read z_t: one shared gradient, summed over the MLPs below)
         dx3, dw3, db3 = _dense_grouped_bwd([relu] * n, [ty1] * n, w1s, hs, [None] * n, dx4, [True] * n, [True] * n, True, B, defer_reduce=True)
         _flush_deferred()                   # both reductions (and whatever else was still queued) in ONE launch
@@ -426,7 +448,8 @@ def time_branch(pos, bases, stem, stem_t, mlps):
         return None
     fl = lambda t: t.reshape(t.shape[0], -1).shape
     SH, TH, TO = stem[0].shape[0], stem_t[0].shape[0], stem_t[2].shape[0]
-    if B > 4 or 2 * Lv > 256 or (2 * Lv) % 4 or TH > 64 or TH % 4 or TO > 32 or TO % 4 or len(mlps) > L.MAX_DENSE_GROUPS:
+    # (the backward groups every MLP's layer 1 WITH the stem's layer 1 in one grouped launch: n + 1 groups)
+    if B > 4 or 2 * Lv > 256 or (2 * Lv) % 4 or TH > 64 or TH % 4 or TO > 32 or TO % 4 or len(mlps) + 1 > L.MAX_DENSE_GROUPS:
         return None
     # every layer must have the width the kernel indexes with (an SFTLayer built with factor != 1 has a narrower hidden layer)
     if fl(stem[0])[1] != 2 * Lv or fl(stem_t[0])[1] != 2 * Lv or fl(stem[2])[1] != SH or fl(stem_t[2])[1] != TH:
@@ -477,16 +500,18 @@ class _Conv2dPS(torch.autograd.Function):
         dw = torch.empty_like(w)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_b else None
         dx = None
+        dxq = False
         if ctx.needs_input_grad[0] and k == 3:                 # (dW | dx): one launch where the library pairs them
             dx = torch.empty_like(x)
             _wgrad_conv_pair(dict(x=x, g=g, dw=dw, db=db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s),
                              dict(x=g, w=w, bias=None, out=dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1))
+            dxq = _pair_dx_deferred
         else:
             _wgrad(x, g, dw, db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s, defer=True)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 _conv(g, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1)
-        _flush_deferred(block_end=True)
+        _flush_deferred(block_end=True, dx_deferred=dxq)
         return dx, dw, db, None
 
 
@@ -590,16 +615,18 @@ class _SNeRVBlock(torch.autograd.Function):
         dwu = torch.empty_like(wu)
         dbu = torch.empty(Ct, dtype=torch.float32, device=x.device) if ctx.has_bu else None
         dx = None
+        dxq = False
         if ctx.needs_input_grad[0] and k == 3:      # (dW_block | d block conv): one launch where the library pairs them
             dx = torch.empty_like(x)
             _wgrad_conv_pair(dict(x=x, g=du, dw=dwu, db=dbu, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s),
                              dict(x=du, w=wu, bias=None, out=dx, B=B, Cin=Ct, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1))
+            dxq = _pair_dx_deferred
         else:
             _wgrad(x, du, dwu, dbu, B=B, Cin=Cin, Cout=Ct, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE, g_s=s, defer=True)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 _conv(du, wu, None, dx, B=B, Cin=Ct, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_UNSHUFFLE, ep_mode=L.EP_PLAIN, in_s=s, transposed=1)
-        _flush_deferred(block_end=True)
+        _flush_deferred(block_end=True, dx_deferred=dxq)
         m = ctx.mshape
         return dx, dwu, dbu, ds0.reshape(m), dt0.reshape(m), ds1.reshape(m), dt1.reshape(m), dw0, db0, dw1, db1, None
 

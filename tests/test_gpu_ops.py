@@ -90,6 +90,101 @@ def test_dense_shared_input_gradient(ops):
     close(gz, rz, msg="shared dz")
 
 
+def _poison_pool(shapes, n=24):
+    """Fill the caching allocator's free blocks of these sizes with NaN: a following torch.empty of the same shape then hands out NaN,
+    so a kernel result that was never written (a slab reduction still queued) cannot pass as last call's value."""
+    junk = [torch.full(sh, float("nan"), device=DEV) for sh in shapes for _ in range(n)]
+    torch.cuda.synchronize()
+    del junk
+
+
+@pytest.mark.parametrize("widths", [(96, 128, 12), (65, 30, 30, 100)])
+def test_time_branch_with_modulations_wider_than_one_dx_chunk(ops, widths):
+    """NeRV_Boost's one-launch time branch (ops.time_branch; model_nerv.py:47-51, model_blocks.py:92-105) with TAT modulation MLPs
+    of more than DENSE_DX_CHUNK = 64 output channels (a NeRV-boost with fc_dim in 65..128): the layer-1 input gradient of such an MLP
+    is a two-chunk slab reduction, which the grouped backward must have SUMMED before layer 0 reads it (round-5 advisor finding: it
+    was only queued).  Outputs and every parameter gradient against float64 autograd."""
+    from boosting_nerv_amd import _lib as L
+    g = torch.Generator().manual_seed(11 + len(widths))
+    Lv, SH, SO, TH, TO, B = 80, 256, 30 * 9 * 16, 64, 32, 1
+    rn = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc)
+    bases = (1.25 ** torch.arange(8, dtype=torch.float32).repeat_interleave(10)) * math.pi      # (moderate arguments: the PE itself is pinned elsewhere)
+    pos = torch.tensor([0.37], dtype=torch.float64)
+    stem = [rn(SH, 2 * Lv, 1, 1, sc=0.08), rn(SH, sc=0.1), rn(SO, SH, 1, 1, sc=0.06), rn(SO, sc=0.1)]
+    stem_t = [rn(TH, 2 * Lv, 1, 1, sc=0.08), rn(TH, sc=0.1), rn(TO, TH, 1, 1, sc=0.12), rn(TO, sc=0.1)]
+    mlps = [[rn(TO, TO, 1, 1, sc=0.2), rn(TO, sc=0.1), rn(C_, TO, 1, 1, sc=0.2), rn(C_, sc=0.1)] for C_ in widths]
+    flat = stem + stem_t + [t for m in mlps for t in m]
+    cots = [rn(B, SO), rn(B, TO)] + [rn(B, C_) for C_ in widths]
+
+    def ref():
+        ps = [t.double().requires_grad_(True) for t in flat]
+        arg = pos.float()[:, None] * bases[None, :]                      # the reference's single fp32 product (model_blocks.py:122)
+        pe = torch.cat([torch.sin(arg), torch.cos(arg)], 1).double()
+        lin = lambda x, w, b: x @ w.flatten(1).T + b
+        so = torch.sin(lin(torch.sin(lin(pe, ps[0], ps[1])), ps[2], ps[3]))
+        zt = torch.sin(lin(torch.sin(lin(pe, ps[4], ps[5])), ps[6], ps[7]))
+        outs = [lin(torch.relu(lin(zt, ps[8 + 4 * i], ps[9 + 4 * i])), ps[10 + 4 * i], ps[11 + 4 * i]) for i in range(len(widths))]
+        gr = torch.autograd.grad([so, zt] + outs, ps, [c.double() for c in cots])
+        return [so, zt] + outs, gr
+    r_out, r_g = ref()
+    pg = [t.to(DEV).requires_grad_(True) for t in flat]
+    assert max(widths) > L.DENSE_DX_CHUNK
+    _poison_pool([(2, B, TO), (B, TO)])
+    res = ops.time_branch(pos.to(DEV), bases.to(DEV), tuple(pg[:4]), tuple(pg[4:8]), [tuple(pg[8 + 4 * i:12 + 4 * i]) for i in range(len(widths))])
+    assert res is not None, "these shapes are the kernel's"
+    got = [res[0], res[1]] + list(res[2])
+    for a, b in zip(got, r_out):
+        close(a, b.float(), rtol=1e-4, atol=3e-5, msg="time branch fwd")
+    gg = torch.autograd.grad(got, pg, [c.to(DEV) for c in cots])
+    for i, (a, b) in enumerate(zip(gg, r_g)):
+        assert torch.isfinite(a).all(), f"time branch grad {i}: non-finite (an unreduced buffer was read)"
+        close(a, b.float(), msg=f"time branch grad {i}")
+
+
+def test_time_branch_refuses_more_groups_than_its_backward_can_hold(ops):
+    """40 modulation MLPs fit the forward's table but not the backward's grouped launch (n + 1 groups): the gate must say no, so the
+    caller takes the layer-by-layer path instead of failing in backward (round-5 advisor finding)."""
+    from boosting_nerv_amd import _lib as L
+    z = lambda *sh: torch.zeros(*sh, device=DEV)
+    stem = (z(256, 160, 1, 1), z(256), z(64, 256, 1, 1), z(64))
+    stem_t = (z(64, 160, 1, 1), z(64), z(32, 64, 1, 1), z(32))
+    mk = lambda n: [(z(32, 32, 1, 1), z(32), z(12, 32, 1, 1), z(12)) for _ in range(n)]
+    bases = torch.ones(80, device=DEV)
+    pos = torch.tensor([0.5], dtype=torch.float64, device=DEV)
+    assert ops.time_branch(pos, bases, stem, stem_t, mk(L.MAX_DENSE_GROUPS)) is None
+    assert ops.time_branch(pos, bases, stem, stem_t, mk(L.MAX_DENSE_GROUPS - 1)) is not None
+
+
+@pytest.mark.parametrize("dx_ok", [False, True])
+def test_stem_pair_input_gradient_is_complete_for_a_stock_consumer(ops, dx_ok):
+    """E-NeRV's first up-conv (Conv_Up_Block.conv1, model_enerv.py:73-102: 3x3 59 -> 350, PixelShuffle(5) at 9x16) takes the stem pair,
+    whose data gradient is a QUEUED slab reduction; its input comes from a stock torch.sin, whose backward does not flush.  Inside
+    ops.lazy_flush() the operator must therefore reduce before it returns -- unless the model vouches for a flushing reader (dx_ok,
+    NeRV_Boost), in which case the reader's flush (here: an explicit one) completes it."""
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Ct, H, W, s = 1, 59, 350, 9, 16, 5
+    z = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Ct, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Ct, generator=g) * 0.1
+    cot = torch.randn(B, Ct // (s * s), H * s, W * s, generator=g)
+    zr, wr, br = (t.double().requires_grad_(True) for t in (z, w, b))
+    ref = F.pixel_shuffle(F.conv2d(torch.sin(zr), wr, br, padding=1), s)
+    rz, rw, rb = torch.autograd.grad(ref, [zr, wr, br], cot.double())
+    zg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (z, w, b))
+    xin = torch.sin(zg)
+    out = ops.conv2d_ps(xin, wg, bg, s)
+    close(out, ref.float(), msg="stem-shape up-conv fwd")
+    _poison_pool([(B, Cin, H, W)])
+    if dx_ok:
+        hook = xin.register_hook(lambda gr: ops._flush_deferred())      # the flushing reader the model vouches for
+    with ops.lazy_flush(dx_ok=dx_ok):
+        gz, gw, gb = torch.autograd.grad(out, [zg, wg, bg], cot.to(DEV))
+    assert torch.isfinite(gz).all(), "the data gradient reached torch.sin's backward unreduced"
+    close(gz, rz.float(), msg="stem pair dz through a stock sin")
+    close(gw, rw.float(), msg="stem pair dw")
+    close(gb, rb.float(), msg="stem pair db")
+
+
 # ---------------------------------------------------------------------------------------------------------------- conv
 CONV_CASES = [  # B, Cin, Cout_total, H, W, k, s
     (1, 12, 12, 16, 64, 3, 1), (2, 12, 48, 9, 33, 3, 2), (1, 15, 48, 11, 40, 3, 2), (2, 30, 750, 9, 16, 3, 5),
