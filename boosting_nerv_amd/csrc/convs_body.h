@@ -5,6 +5,10 @@
 #include "sidejob.h"
 #include "conv_common.h"
 
+#ifndef BNERV_ABLS
+#define BNERV_ABLS 0   // debug ablations (never shipped; tools/ksmall.py): bit 0 no weight loads, 1 no input loads, 2 no K loop, 3 no epilogue math
+#endif
+
 namespace bnerv_convs {
 using namespace bnerv_conv;
 
@@ -90,7 +94,7 @@ __device__ __forceinline__ void conv_small_body(const SArgs& sa, const int tile,
             const int c = sidx / (SROWS * SSEGS), rem = sidx - c * (SROWS * SSEGS), r = rem / SSEGS, sg = rem - r * SSEGS;
             const int gy = ty0 + r - 1, gx = tx0 + 4 * sg - SXOFF;
             const bool ok = sidx < NSLOT && c < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            ra[k] = bload(rx, ok ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB, sb);
+            ra[k] = bload(rx, (ok && !((BNERV_ABLS & 2) && d.B > 0)) ? (unsigned)(((c * H + r) * W + 4 * sg) * 4) : OOB, sb);
             sc[k] = 1.f; sh[k] = 0.f;
             if constexpr (AFF) { if (ok) { sc[k] = 1.0f + d.scale[b * Cin + c]; sh[k] = d.shift[b * Cin + c]; } else sc[k] = 0.f; }
         }
@@ -107,14 +111,14 @@ __device__ __forceinline__ void conv_small_body(const SArgs& sa, const int tile,
             const float* src = d.w + (size_t)co_base * Cin * 9;
             const int nvalid = min(16, Cout - co_base) * Cin * 9;
 #pragma unroll
-            for (int u = 0; u < NWL; ++u) { const int i = tid + u * 256; wv[u] = i < nvalid ? src[i] : 0.f; }
+            for (int u = 0; u < NWL; ++u) { const int i = tid + u * 256; wv[u] = (i < nvalid && !((BNERV_ABLS & 1) && d.B > 0)) ? src[i] : 0.f; }
         } else {
             // W(co, ci, t) = w[ci][co][8 - t] (w is [wCo = Cin][wCi = Cout][9]): per ci a segment of 16 x 9 floats; kept as [ci][16][9]
 #pragma unroll
             for (int u = 0; u < NWL; ++u) {
                 const int i = tid + u * 256;
                 const int ci = i / 144, rem = i - ci * 144, col = rem / 9;
-                wv[u] = (i < ncopy && co_base + col < Cout) ? d.w[((size_t)ci * d.wCi + co_base) * 9 + rem] : 0.f;
+                wv[u] = (i < ncopy && co_base + col < Cout && !((BNERV_ABLS & 1) && d.B > 0)) ? d.w[((size_t)ci * d.wCi + co_base) * 9 + rem] : 0.f;
             }
         }
 #pragma unroll
@@ -157,7 +161,7 @@ __device__ __forceinline__ void conv_small_body(const SArgs& sa, const int tile,
     const bool ci_tail = (Cin & 3) != 0;                       // the last quad reads beyond Cin: those weights must count as zero
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        if (4 * q < Cin) {                                     // block-uniform
+        if (4 * q < Cin && !((BNERV_ABLS & 4) && d.B > 0)) {   // block-uniform
             const bool bvalid = !ci_tail || (4 * q + kq < Cin);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {

@@ -998,6 +998,36 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert out["config"]["dp_buckets"] == (2 if pm["2"] < pm["1"] else 1)
 
 
+@pytest.mark.isolated
+def test_bench_eight_ranks_share_one_gpu(tmp_path):
+    """`python bench.py --gpus 8` as the driver's scaling run launches it (torch.distributed.run, 8 ranks) with BNERV_BENCH_SHARE_GPU=1:
+    all eight ranks on this box's single GPU over gloo.  The first real 8-GPU run must not die on a port, a time-out, the two-bucket
+    probe or a shard of 17 padded frames: ONE JSON line, n_gpus 8, global batch 8, replicas in sync (the numbers mean nothing here)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BNERV_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 5 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp8"
+    assert out["scaling"] == "weak" and out["value"] > 0 and out["cpu_baseline"] is None
+    assert out["config"]["replicas_in_sync"] is True and "error" not in out
+    assert out["allreduce_us"] > 0 and out["dp"]["allreduce_bytes"] == 4 * 1489577
+
+
 def test_bench_two_ranks_over_rccl(tmp_path):
     """bench.py --gpus 2 exactly as the driver launches it, over RCCL (backend nccl), one rank per GPU -- runs only where two devices
     are visible (the build box has one: skipped there).  The flat-bucket all-reduce is captured INSIDE the step graph

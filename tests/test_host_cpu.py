@@ -216,6 +216,57 @@ def test_dp_gradient_mean_two_ranks_gloo():
     assert allidx == list(range(10))
 
 
+def _gloo_world8_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from boosting_nerv_amd.dp import GradBucket, shard_indices
+        gen = torch.Generator().manual_seed(100)
+        shapes = [(256, 160), (256,), (48, 12, 3, 3), (3, 12, 1, 1), (3,), (1000, 33)]
+        params = [torch.nn.Parameter(torch.randn(*sh, generator=gen)) for sh in shapes]
+        own = [torch.randn(*sh, generator=torch.Generator().manual_seed(7 * rank + i)) for i, sh in enumerate(shapes)]
+        for p, g in zip(params, own):
+            p.grad = g.clone()
+        GradBucket(params).allreduce_mean()
+        ok = True
+        for p, g in zip(params, own):
+            parts = [torch.empty_like(g) for _ in range(world)]
+            dist.all_gather(parts, g)
+            ok &= torch.allclose(p.grad, sum(parts) / world, rtol=1e-6, atol=1e-7)
+        # the reference's frame shards at -b 8 -d on 8 GPUs: 132 frames -> 17 per rank, 4 padding duplicates (train_nerv_all.py:168, :189-191)
+        sh = shard_indices(132, rank, world, seed=0)
+        from torch.utils.data.distributed import DistributedSampler
+        ds = DistributedSampler(list(range(132)), num_replicas=world, rank=rank, shuffle=True, seed=0)
+        q.put((rank, ok, sh, list(iter(ds))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_world8_bucket_mean_and_padded_shards_gloo():
+    """world_size 8 on CPU (gloo), the shape of the driver's 8-GPU run: the flat-bucket all-reduce averages 8 different gradients like
+    DDP; `shard_indices(132, r, 8)` equals torch's DistributedSampler on every rank -- 17 frames per rank (132 -> 136 with four padding
+    duplicates taken from the head of the permutation), the shards cover every frame, and exactly four frames appear twice."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_world8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _, _ in res)
+    for _, _, mine, ref in res:
+        assert mine == ref and len(mine) == 17
+    allidx = sum((s for _, _, s, _ in res), [])
+    assert len(allidx) == 136 and sorted(set(allidx)) == list(range(132))
+    from collections import Counter
+    assert sorted(Counter(allidx).values())[-5:] == [1, 2, 2, 2, 2]
+
+
 def _gloo_two_bucket_worker(rank, world, port, q):
     import torch.distributed as dist
     import torch.nn as nn
