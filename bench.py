@@ -796,11 +796,11 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():      # (also the 1-rank group of BNERV_BENCH_FORCE_BUCKET: a live watchdog thread must not meet the teardown)
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
     main()
     from boosting_nerv_amd.runtime import hard_exit
-    hard_exit(0)        # (the line is printed, the process group destroyed: skip the interpreter teardown, see runtime.hard_exit)
+    hard_exit(0)        # (the line is printed, the process group destroyed: quiesce torch's autograd worker, then the regular teardown -- runtime.hard_exit)

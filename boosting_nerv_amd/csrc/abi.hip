@@ -94,9 +94,11 @@ int bnerv_side_flush(bnerv_ctx* ctx, hipStream_t st) {
         sp.n_slices = 0;
         while (n < (int)q.size() && n < SIDE_FLUSH_JOBS) {
             sp.j[n] = q[n];
+            sp.start[n] = sp.n_slices;
             sp.n_slices += q[n].slices;
             ++n;
         }
+        for (int k = n; k < SIDE_FLUSH_JOBS; ++k) sp.start[k] = 0x7fffffff;
         sp.n_jobs = n;
         q.erase(q.begin(), q.begin() + n);
         hipLaunchKernelGGL(side_flush_many_kernel, dim3(sp.n_slices), dim3(256), 0, st, sp);

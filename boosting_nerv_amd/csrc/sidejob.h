@@ -37,6 +37,7 @@ constexpr int SIDE_FLUSH_JOBS = 32;    // the stand-alone flush takes many more 
 struct SideFlushPack {
     SideJob j[SIDE_FLUSH_JOBS];
     int n_jobs, n_slices;
+    int start[SIDE_FLUSH_JOBS];          // first slice of job k (prefix sums of j[].slices): a block finds its job in ONE round trip
 };
 
 // the caller-owned context of one stream (include/bnerv.h): the deferred-reduction queue and a scratch buffer in device memory
@@ -64,10 +65,28 @@ int bnerv_side_pending(const bnerv_ctx* ctx);
 // one slice (256 threads, `red` = 256 floats of LDS the caller no longer needs; caller guarantees a barrier before)
 // FOLD: the instantiation of the stand-alone flush kernels (abi.hip), which alone execute fold jobs (bnerv_side_take never hands one to a hosting
 // launch: the hosted copy of this routine inside the hot kernels keeps its register footprint)
+// which job slice s belongs to; *s becomes the slice index inside that job
+template <class Pack>
+__device__ __forceinline__ int side_find_job(const Pack& sp, int* s) {
+    int j = 0;
+    while (j < sp.n_jobs - 1 && *s >= sp.j[j].slices) { *s -= sp.j[j].slices; ++j; }
+    return j;
+}
+// the stand-alone flush carries up to 32 jobs: the walk above is a chain of up to 31 dependent scalar loads per BLOCK (measured: the 44 000
+// blocks of C3's final flush spent most of their 142 us in it).  Here lane k compares against start[k]: one load, one ballot.
+template <>
+__device__ __forceinline__ int side_find_job<SideFlushPack>(const SideFlushPack& sp, int* s) {
+    const int k = (int)(threadIdx.x & 63);
+    const int st = k < sp.n_jobs ? sp.start[k < SIDE_FLUSH_JOBS ? k : 0] : 0x7fffffff;
+    const unsigned long long m = __ballot(st <= *s);
+    const int j = __popcll(m) - 1;                         // start[0] == 0: at least one bit
+    *s -= __shfl(st, j, 64);
+    return __builtin_amdgcn_readfirstlane(j);
+}
+
 template <class Pack, bool FOLD = false>
 __device__ __forceinline__ void side_slice(const Pack& sp, int s, float* red) {
-    int j = 0;
-    while (j < sp.n_jobs - 1 && s >= sp.j[j].slices) { s -= sp.j[j].slices; ++j; }
+    const int j = side_find_job(sp, &s);
     const SideJob& job = sp.j[j];
     const int epb = job.epb, lanes = 256 / epb;
     const int e = threadIdx.x % epb, lane = threadIdx.x / epb;

@@ -31,6 +31,8 @@ int bnerv_convbf_pair_try(hipStream_t st, const bnerv_conv_desc& d, int vec, con
 bool bnerv_convs_shape_ok(const bnerv_conv_desc& d, int vec);     // convs.hip
 int bnerv_stem_wgrad_try(hipStream_t st, const bnerv_wgrad_desc& d);   // stem.hip (images of <= 256 pixels): 1 = not that layer
 int bnerv_stem_pair_try(hipStream_t st, const bnerv_conv_desc& c, const bnerv_wgrad_desc& d, int* n_slabs);   // stem.hip: the stem stage's (dW | d input) as one launch
+int bnerv_wgrad1x1_slabs(const bnerv_wgrad_desc& d);                                   // wgrad1.hip: pointwise (k = 1) layers as a plain GEMM over the pixels
+int bnerv_wgrad1x1_try(hipStream_t st, const bnerv_wgrad_desc& d, int* n_slabs);
 #include <stdlib.h>
 #include <type_traits>
 #include <string.h>
@@ -1351,6 +1353,12 @@ extern "C" size_t bnerv_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int
     bnerv_wgrad_desc t{};
     t.B = B; t.H = H; t.W = W; t.k = k;
     int nb = wlean_blocks(t) > p.nsplit ? wlean_blocks(t) : p.nsplit;           // covers whichever kernel the launcher picks
+    if (k == 1) {
+        bnerv_wgrad_desc t1{};
+        t1.B = B; t1.Cin = Cin; t1.Cout = Cout; t1.H = H; t1.W = W; t1.k = 1; t1.g_s = 1;
+        const int n1 = bnerv_wgrad1x1_slabs(t1);
+        if (n1 > nb) nb = n1;
+    }
     if (k == 3) {
         t.Cin = Cin; t.Cout = Cout;
         const WidePlan wp = wide_plan(t);
@@ -1389,7 +1397,13 @@ extern "C" int bnerv_conv_wgrad(void* stream, const bnerv_wgrad_desc* dp) {
         if (rs != 1) return rs;
     }
     int rc = -1, n_slabs = p.nsplit;
-    if (wlean_ok(wa)) {
+    if (d.k == 1) {                                       // pointwise layers with 16 or more channels on both sides: the plain GEMM over pixels (wgrad1.hip)
+        int n1 = 0;
+        const int r1 = bnerv_wgrad1x1_try(st, d, &n1);
+        if (r1 < 0) return r1;
+        if (r1 == BNERV_OK) { rc = BNERV_OK; n_slabs = n1; }
+    }
+    if (rc == -1 && wlean_ok(wa)) {
         rc = d.k == 1 ? launch_wlean_modes<1>(st, wa) : launch_wlean_modes<3>(st, wa);
         if (rc == BNERV_OK) n_slabs = wlean_blocks(d);
     }

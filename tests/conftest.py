@@ -128,12 +128,16 @@ def pytest_sessionfinish(session, exitstatus):
 
 @pytest.hookimpl(trylast=True)
 def pytest_unconfigure(config):
-    """A GPU session ends WITHOUT the interpreter's teardown (boosting_nerv_amd.runtime.hard_exit: atexit callbacks, flush, os._exit with
-    pytest's own exit status).  The summary has been printed by then.  Reason: torch-ROCm's teardown sporadically aborts the process
-    (`terminate called without an active exception`, profiles/r05_pytest_gpu.txt lease r05h3) -- behind a green report that would turn a
-    passed suite into exit status 134.  BNERV_HARD_EXIT=0 switches it off, =force applies it without a GPU (the CPU test of this hook)."""
-    mode = os.environ.get("BNERV_HARD_EXIT", "1")
-    if _session_status[0] is None or mode == "0" or not (torch.cuda.is_available() or mode == "force"):
+    """A GPU session quiesces torch's autograd worker before the interpreter goes down (boosting_nerv_amd.runtime.quiesce_autograd: the
+    root cause of round 5's exit-time abort, profiles/r06_exit_abort.md) and then leaves the REGULAR way.  BNERV_HARD_EXIT=1 restores
+    round 5's behaviour -- no interpreter teardown at all (atexit callbacks, flush, os._exit with pytest's own status); =force applies that
+    without a GPU (the CPU test of the hook)."""
+    mode = os.environ.get("BNERV_HARD_EXIT", "0")
+    if _session_status[0] is None or not (torch.cuda.is_available() or mode == "force"):
+        return
+    from boosting_nerv_amd.runtime import hard_exit, quiesce_autograd, tool_attached
+    quiesce_autograd()
+    if mode not in ("1", "force"):
         return
     try:
         tr = config.pluginmanager.getplugin("terminalreporter")
@@ -141,9 +145,9 @@ def pytest_unconfigure(config):
             tr._tw.flush()
     except Exception:       # noqa: BLE001
         pass
-    from boosting_nerv_amd.runtime import hard_exit, tool_attached
     if tool_attached():      # (a profiler writes its output from a C-level exit handler: leave the regular way)
         return
+    os.environ["BNERV_HARD_EXIT"] = "1"
     hard_exit(_session_status[0])
 
 
@@ -170,12 +174,6 @@ def run_isolated(nodeid, timeout=900, marker="gpu"):
         tail = out[-600:]
         if " skipped" in tail and " passed" not in tail:
             pytest.skip(f"isolated child skipped {nodeid}")
-        return out
-    if isinstance(rc, int) and rc < 0 and " passed" in out and " failed" not in out and "died in: [bnerv-trail] END" in out:
-        # the child's test PASSED and was reported; the process then died in the interpreter's teardown (torch-ROCm's sporadic
-        # `terminate called without an active exception` at exit, runtime.hard_exit) -- no test was running: the crash tracer's note is an END crumb
-        import warnings
-        warnings.warn(f"isolated child for {nodeid} passed, then died at interpreter exit (signal {-rc})")
         return out
     how = f"killed by signal {-rc}" if isinstance(rc, int) and rc < 0 else f"exit status {rc}"
     keep = [ln for ln in out.splitlines() if not ln.startswith("  File ") and not ln.startswith("Extension modules:")]

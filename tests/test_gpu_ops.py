@@ -511,7 +511,33 @@ def test_deferred_reductions_match_immediate(ops):
     torch.testing.assert_close(out_c, out_d, rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 23, 70, 7), (1, 64, 36, 64, 7), (1, 3, 9, 16, 3), (2, 4, 17, 33, 5)])
+def test_flush_of_many_deferred_reductions_finds_every_job(ops):
+    """The stand-alone flush carries up to 32 queued reductions per launch and every block looks its job up from the prefix sums of their
+    slice counts (sidejob.h side_find_job: one load + one ballot instead of a walk over the jobs): 70 jobs of very different shapes
+    (three launches), each against the immediate kernel's result bit for bit and against float64."""
+    from boosting_nerv_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(21)
+    ctx = L.StreamContext()
+    jobs = []
+    for i in range(70):
+        n_slabs = [1, 3, 17, 64, 200, 700][i % 6]
+        count = [5, 24, 333, 1308, 40, 4097, 9][i % 7]
+        slabs = torch.randn(n_slabs, count, generator=g).to(DEV)
+        out = torch.full((count,), float("nan"), device=DEV)
+        L.check(lib.bnerv_reduce_slabs_deferred(ctx.handle, L.stream(), L.ptr(slabs), n_slabs, count, L.ptr(out)), "defer")
+        jobs.append((slabs, out, n_slabs, count))
+    assert lib.bnerv_deferred_pending(ctx.handle) == 70
+    L.check(lib.bnerv_flush_deferred(ctx.handle, L.stream()), "flush")
+    assert lib.bnerv_deferred_pending(ctx.handle) == 0
+    for slabs, out, n_slabs, count in jobs:
+        now = torch.empty(count, device=DEV)
+        L.check(lib.bnerv_reduce_slabs_deferred(None, L.stream(), L.ptr(slabs), n_slabs, count, L.ptr(now)), "immediate")
+        assert torch.equal(out, now), (n_slabs, count)
+        torch.testing.assert_close(out.double(), slabs.double().sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 23, 70, 7), (1, 64, 36, 64, 7), (1, 3, 9, 16, 3), (2, 4, 17, 33, 5), (1, 8, 100, 200, 7), (1, 64, 216, 384, 7)])
 def test_dwconv_fwd_bwd(ops, shape):
     """Depthwise KxK conv of the ConvNeXt encoder block against F.conv2d(groups=C): output, dx, dw, db."""
     B, C, H, W, K = shape
@@ -527,6 +553,37 @@ def test_dwconv_fwd_bwd(ops, shape):
     close(out, ref, msg="dwconv fwd")
     for n, a, r in zip("xwb", torch.autograd.grad(out, [xg, wg, bg], cot.to(DEV)), rg):
         close(a, r, msg=f"dwconv d{n}")
+
+
+@pytest.mark.parametrize("case", [(2, 64, 256, 64, 64), (1, 256, 64, 72, 128), (1, 48, 20, 64, 68), (3, 16, 16, 40, 104), (1, 80, 130, 216, 384)])
+def test_pointwise_weight_gradient_as_a_gemm_over_pixels(ops, case):
+    """k = 1 weight / bias gradient of layers with 16 or more channels on both sides from 4096 pixels on (csrc/wgrad1.hip: the ConvNeXt
+    block's pwconv1 / pwconv2 of the reference's encoder, model_blocks.py:245-258, through lib/quant_ops.py:39-41's backward) against the
+    float64 contraction: channel counts that are not multiples of 16 / 64, several samples, a pixel count that does not divide into the
+    slabs evenly, and the bias column."""
+    from boosting_nerv_amd import _lib as L
+    B, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    gy = torch.randn(B, Cout, H, W, generator=g).to(DEV)
+    dw, db = torch.full((Cout, Cin, 1, 1), float("nan"), device=DEV), torch.full((Cout,), float("nan"), device=DEV)
+    ops._wgrad(x, gy, dw, db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=1, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE)
+    ref = torch.einsum("bohw,bihw->oi", gy.double(), x.double())
+    bound = torch.einsum("bohw,bihw->oi", gy.double().abs(), x.double().abs())
+    err = ((dw.flatten(1).double() - ref).abs() / bound).max().item()
+    assert err < 3.5e-7, f"pointwise dW: max |err| / sum|g||x| = {err:.2e}"
+    rb = gy.double().sum((0, 2, 3))
+    eb = ((db.double() - rb).abs() / gy.double().abs().sum((0, 2, 3))).max().item()
+    assert eb < 3.5e-7, f"pointwise db: {eb:.2e}"
+    # and through the operator the encoder uses (conv2d_ps with k = 1): same gradient as F.conv2d
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)).to(DEV).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).to(DEV).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    out = ops.conv2d_ps(xr, w, b, 1)
+    gw, gb_, gx = torch.autograd.grad(out, [w, b, xr], gy)
+    close(gw.flatten(1), ref.float(), msg="conv2d_ps k=1 dw")
+    close(gb_, rb.float(), msg="conv2d_ps k=1 db")
+    close(gx, torch.einsum("bohw,oi->bihw", gy.double(), w.detach().flatten(1).double()).float(), msg="conv2d_ps k=1 dx")
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 23, 70), (1, 64, 36, 64), (3, 16, 9, 16), (1, 1, 4, 300)])
