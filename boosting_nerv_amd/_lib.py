@@ -161,6 +161,8 @@ SYMBOLS = {
     "bnerv_fft_prepare": (_I, [_I, _I]),
     "bnerv_loss_fwd_bwd": (_I, [_V, C.POINTER(LossDesc)]),
     "bnerv_msssim": (_I, [_V, _V, _V, _V, _V, _Z, _I, _I, _I, _I]),
+    "bnerv_tanh_grad_blocks": (_I, [_I]),
+    "bnerv_tanh_grad": (_I, [_V, _V, _V, _V, _V, _I, _I, _I]),
     "bnerv_psnr_ws_bytes": (_Z, [_I, _I, _I, _I]),
     "bnerv_psnr": (_I, [_V, _V, _V, _V, _V, _Z, _I, _I, _I, _I]),
     "bnerv_adan_multi_tensor": (_I, [_V, C.POINTER(AdanChunk), C.POINTER(AdanHyper)]),
@@ -172,7 +174,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class BnervError(RuntimeError):

@@ -696,7 +696,28 @@ class _HeadTanh(torch.autograd.Function):
         dw = torch.empty_like(w)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_b else None
         dx = None
-        if ctx.needs_input_grad[0]:
+        if k == 3 and Cout <= 4 and Cin >= 16 and os.environ.get("BNERV_HEAD_SWAP", "1") != "0":
+            # HNeRV_Boost's 3x3 head (38 -> 3, model_hnerv.py:214).  As dW[co] = sum_p gt[co][p] x[.][p + tap] the MFMA tile has 3 of its 16
+            # rows in use (272 us at 1080p).  The same sums with the ROLES SWAPPED -- x as the "gradient" (M = 38 input channels), gt as the
+            # "input" (N = 3 couts x 9 taps) -- are S[ci][co][t'] = sum_q x[ci][q] gt[co][q + t' - 1] = dW[co][ci][2 - t'] (zero padding
+            # excludes the same terms on both sides): one weight-gradient launch on the well-filled shape, then a transpose + tap flip of
+            # 1026 numbers.  gt = the tanh-gradient as a tensor (bnerv_tanh_grad), whose channel sums are the bias gradient.
+            lib = L.load()
+            HW = H * W
+            gt = torch.empty_like(g)
+            nblk = lib.bnerv_tanh_grad_blocks(HW)
+            part = torch.empty(B * nblk, Cout, dtype=torch.float32, device=x.device)
+            L.check(lib.bnerv_tanh_grad(L.stream(), L.ptr(g), L.ptr(img), L.ptr(gt), L.ptr(part), B, Cout, HW), "bnerv_tanh_grad")
+            if db is not None:
+                _reduce_slabs(part, B * nblk, Cout, db, defer=True)
+            sw = torch.empty(Cin, Cout, k, k, dtype=torch.float32, device=x.device)
+            sb = torch.empty(Cin, dtype=torch.float32, device=x.device)           # (the swapped call's "bias gradient": channel sums of x, unused)
+            _wgrad(gt, x, sw, sb, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE)
+            dw = sw.permute(1, 0, 2, 3).flip(2, 3).contiguous()
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _conv(g, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_TANHGRAD, ep_mode=L.EP_PLAIN, transposed=1, aux0=img)
+        elif ctx.needs_input_grad[0]:
             # (dW | dx) of the head: one streaming pass where the library pairs them (1x1, tanh-grad prologue), the two launches otherwise
             dx = torch.empty_like(x)
             _wgrad_conv_pair(dict(x=x, g=g, dw=dw, db=db, B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_TANHGRAD, gaux=img),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BNERV_ABI_VERSION 8
+#define BNERV_ABI_VERSION 9
 
 #define BNERV_OK 0
 #define BNERV_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -371,6 +371,14 @@ int bnerv_fft_prepare(int H, int W);
 int bnerv_loss_fwd_bwd(void* stream, const bnerv_loss_desc* d);
 /* per-sample MS-SSIM only (evaluate(): msssim_fn_single, hnerv_utils.py:410-412); out [B] */
 int bnerv_msssim(void* stream, const float* x, const float* y, float* out, void* ws, size_t ws_bytes, int B, int C, int H, int W);
+/* (ABI 9) The output head's tanh-gradient as a tensor: gt = g * 0.5 (1 - (2 img - 1)^2), the derivative of OutImg's tanh(v) * 0.5 + 0.5
+ * (reference model_blocks.py:57-63) applied to the incoming gradient -- what the IN_TANHGRAD prologue computes on the fly -- with the
+ * per-block channel sums of gt in part [B * bnerv_tanh_grad_blocks(HW)][C] (sum over the first index = the head's bias gradient:
+ * bnerv_reduce_slabs(part, B * blocks, C, db)).  Used by the 3x3 head of HNeRV_Boost (model_hnerv.py:214), whose weight gradient runs
+ * with input and gradient swapped (38 input channels on the MFMA M side). */
+int bnerv_tanh_grad_blocks(int HW);
+int bnerv_tanh_grad(void* stream, const float* g, const float* img, float* gt, float* part, int B, int C, int HW);
+
 /* psnr[b] = -10 log10(mean_{CHW}(out-gt)^2 + 1e-9)  (hnerv_utils.py:400-403); ws: bnerv_psnr_ws_bytes() */
 size_t bnerv_psnr_ws_bytes(int B, int C, int H, int W);
 int bnerv_psnr(void* stream, const float* out, const float* gt, float* psnr, void* ws, size_t ws_bytes, int B, int C, int H, int W);

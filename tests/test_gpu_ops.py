@@ -330,6 +330,33 @@ def test_head_tanh(ops, k, hw):
         close(a, r, msg=f"head d{n}")
 
 
+@pytest.mark.parametrize("case", [(1, 38, 3, 40, 64), (2, 20, 3, 17, 36), (1, 16, 4, 33, 20), (1, 38, 3, 24, 30)])
+def test_wide_head_weight_gradient_with_swapped_roles(ops, case, monkeypatch):
+    """HNeRV_Boost's 3x3 output head (38 -> 3 + OutImg tanh, model_hnerv.py:214, model_blocks.py:57-63): the weight gradient computed
+    with input and gradient swapped (ops._HeadTanh.backward: bnerv_tanh_grad + one weight-gradient launch with the 38 channels on the M
+    side, then a transpose + tap flip) against the CPU oracle and against the direct form (BNERV_HEAD_SWAP=0) -- dx, dw, db; image
+    sizes with ragged rows (W % 4 != 0: the streaming kernel's scalar path) and borders in every tile."""
+    B, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).requires_grad_(True)
+    ref = cpu_ref.out_img(F.conv2d(x, w, b, padding=1))
+    cot = torch.randn(ref.shape, generator=g)
+    rg = torch.autograd.grad(ref, [x, w, b], cot)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BNERV_HEAD_SWAP", flag)
+        gl = [gpu(t) for t in (x, w, b)]
+        out = ops.head_tanh(*gl)
+        close(out, ref, msg="wide head fwd")
+        res[flag] = torch.autograd.grad(out, gl, cot.to(DEV))
+        for n, a, r in zip("xwb", res[flag], rg):
+            close(a, r, msg=f"wide head d{n} (swap {flag})")
+    for a, c in zip(res["1"], res["0"]):
+        close(a, c.cpu(), msg="swapped against direct")
+
+
 def test_blocks_against_reference_goldens():
     """The module-level API (same classes / state_dict keys as the reference) on the reference's own golden vectors."""
     from oracle import configs

@@ -24,7 +24,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, name), f"{name} declared in include/bnerv.h but not exported by libbnerv_hip.so"
         assert name in _lib.SYMBOLS, f"{name} has no ctypes binding in boosting_nerv_amd/_lib.py"
     assert set(_lib.SYMBOLS) <= declared
-    assert lib.bnerv_abi_version() == _lib.ABI_VERSION == 8 and lib.bnerv_build_arch() == b"gfx950"
+    assert lib.bnerv_abi_version() == _lib.ABI_VERSION == 9 and lib.bnerv_build_arch() == b"gfx950"
 
 
 def test_abi_argument_validation_without_gpu():
