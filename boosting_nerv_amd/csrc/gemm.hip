@@ -145,7 +145,9 @@ int dw_splits(int B) { return B < GEMM_SPLITK_MIN_ROWS ? 1 : (cdiv(B, 256) > 512
 // x, inp, out, dout, dx: [B, C, HW];  w1 [4C, C], b1 [4C], w2 [C, 4C], b2 [C], gamma [C] (may be NULL: no layer scale).
 // C in {16, 32, 48, 64}.  Block = 256 threads; every wave owns NT consecutive 16-pixel tiles of one sample; the weights sit in
 // LDS as MFMA A fragments ([tile][k step][lane]) for the whole block.
-constexpr int CNX_NT = 2;                                  // pixel tiles per wave (A-fragment reuse)
+// pixel tiles per wave: 2 (A-fragment reuse) on images that fill the chip; 1 on small ones -- a wave's item is one serial chain of
+// ~512 MFMAs + 64 erf per tile (~28 us: the round-5 C3 timeline shows 57 us for the launches at 72 x 128, 36 x 64 and 18 x 32 alike),
+// so a small image wants twice the waves on half the chain
 
 struct MlpArgs {
     const float* x; const float* inp; const float* w1; const float* b1; const float* w2; const float* b2; const float* gamma;
@@ -158,18 +160,32 @@ struct MlpArgs {
 // A fragments of W2 for output tile o, k index (t, r): lane (m = li, kq) <- w2[16 o + li][16 t + 4 kq + r]
 template <int C>
 __device__ __forceinline__ void stage_weights(const MlpArgs& a, float* s_w1, float* s_w2, int tid) {
-    constexpr int HID = 4 * C;
-    for (int e = tid; e < HID * C; e += 256) {             // s_w1[(t * (C/4) + s) * 64 + lane]
-        const int lane = e & 63, rest = e >> 6, s = rest % (C / 4), t = rest / (C / 4);
-        s_w1[e] = a.w1[(16 * t + (lane & 15)) * C + 4 * s + (lane >> 4)];
+    constexpr int HID = 4 * C, KS1 = C / 4, HT = HID / 16;
+    // Coalesced float4 loads, all of a matrix's in flight at once (16 per thread at C = 64), then the LDS stores.  A float4 of W1's row
+    // 16 t + li at columns 4 s .. 4 s + 3 is the fragment element of lanes (li, kq = 0..3) of (t, s); a float4 of W2's row 16 o + li at
+    // columns 16 t + 4 kq .. + 3 is elements r = 0..3 of lane (li, kq) of (o, t).  (The "load a dword, store it" loop this replaces was one
+    // L2 round trip per element: 128 per block at C = 64.)
+    constexpr int N4 = HID * C / 1024;                    // float4 per thread and matrix: 1 / 4 / 9 / 16 at C = 16 / 32 / 48 / 64
+    f32x4 v[N4];
+#pragma unroll
+    for (int u = 0; u < N4; ++u) v[u] = *reinterpret_cast<const f32x4*>(a.w1 + (size_t)(tid + u * 256) * 4);
+#pragma unroll
+    for (int u = 0; u < N4; ++u) {
+        const int e4 = tid + u * 256, row = e4 / KS1, sq = e4 - row * KS1, t = row >> 4, li = row & 15;
+        float* d = s_w1 + (t * KS1 + sq) * 64 + li;
+        d[0] = v[u][0]; d[16] = v[u][1]; d[32] = v[u][2]; d[48] = v[u][3];
     }
-    for (int e = tid; e < C * HID; e += 256) {             // s_w2[((o * (HID/16) + t) * 4 + r) * 64 + lane]
-        const int lane = e & 63, rest = e >> 6, r = rest & 3, t = (rest >> 2) % (HID / 16), o = (rest >> 2) / (HID / 16);
-        s_w2[e] = a.w2[(16 * o + (lane & 15)) * HID + 16 * t + 4 * (lane >> 4) + r];
+#pragma unroll
+    for (int u = 0; u < N4; ++u) v[u] = *reinterpret_cast<const f32x4*>(a.w2 + (size_t)(tid + u * 256) * 4);
+#pragma unroll
+    for (int u = 0; u < N4; ++u) {
+        const int e4 = tid + u * 256, row = e4 / (HID / 4), q4 = e4 - row * (HID / 4), t = q4 >> 2, kq = q4 & 3, o = row >> 4, li = row & 15;
+        float* d = s_w2 + ((o * HT + t) * 4) * 64 + kq * 16 + li;
+        d[0] = v[u][0]; d[64] = v[u][1]; d[128] = v[u][2]; d[192] = v[u][3];
     }
 }
 
-template <int C>
+template <int C, int CNX_NT>
 __global__ __launch_bounds__(256) void cnx_mlp_fwd_kernel(const MlpArgs a) {
     constexpr int HID = 4 * C, KS1 = C / 4, HT = HID / 16, OT = C / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -210,16 +226,18 @@ __global__ __launch_bounds__(256) void cnx_mlp_fwd_kernel(const MlpArgs a) {
                 for (int n = 0; n < CNX_NT; ++n) h[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, xf[n][s], h[n], 0, 0, 0);
             }
             // lane holds hidden units 16 t + 4 kq + r of pixel li: bias, GELU, then straight into GEMM 2 as B fragments
+            // (GELU through common.h's packed pair form -- one exp2 + one rcp per element, |error| <= 1.5e-7 on erf, the TAT conv0 epilogue's
+            //  arithmetic -- instead of erff: 64 erff per 16-pixel tile were ~5 us of a wave's ~30 us chain)
+            const f32x4 bb4 = *reinterpret_cast<const f32x4*>(a.b1 + 16 * t + 4 * kq);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int hid = 16 * t + 4 * kq + r;
-                const float bb = a.b1[hid];
+            for (int n = 0; n < CNX_NT; ++n) {
+                const f32x4 pre = h[n] + bb4;
+                if (a.hsave && px[n] < a.HW) {
 #pragma unroll
-                for (int n = 0; n < CNX_NT; ++n) {
-                    const float pre = h[n][r] + bb;
-                    if (a.hsave && px[n] < a.HW) a.hsave[((size_t)b * HID + hid) * a.HW + px[n]] = pre;
-                    h[n][r] = gelu_f(pre);
+                    for (int r = 0; r < 4; ++r) a.hsave[((size_t)b * HID + 16 * t + 4 * kq + r) * a.HW + px[n]] = pre[r];
                 }
+                f32x4 gd;
+                gelu_pair4_f(pre, &h[n], &gd);
             }
 #pragma unroll
             for (int o = 0; o < OT; ++o)
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(256) void cnx_mlp_fwd_kernel(const MlpArgs a) {
 // GEMMs, which go through bnerv_conv_wgrad with k = 1) and dX.  The transposed weights are staged as A fragments:
 //   W2^T for hidden tile t, k step s (output channels 4s..4s+3): lane (m = li, kq) <- w2[4 s + kq][16 t + li]
 //   W1^T for input tile i, k index (t, r):                         lane (m = li, kq) <- w1[16 t + 4 kq + r][16 i + li]
-template <int C>
+template <int C, int CNX_NT>
 __global__ __launch_bounds__(256) void cnx_mlp_bwd_kernel(const MlpArgs a) {
     constexpr int HID = 4 * C, KS1 = C / 4, HT = HID / 16, OT = C / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -260,12 +278,27 @@ __global__ __launch_bounds__(256) void cnx_mlp_bwd_kernel(const MlpArgs a) {
     float* s_w1t = smem + HID * C;                         // [((i * HT + t) * 4 + r) * 64 + lane]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    for (int e = tid; e < HID * C; e += 256) {
-        const int ln = e & 63, rest = e >> 6;
-        { const int s = rest % KS1, t = rest / KS1;
-          s_w2t[e] = a.w2[(4 * s + (ln >> 4)) * HID + 16 * t + (ln & 15)]; }
-        { const int r = rest & 3, t = (rest >> 2) % HT, i = (rest >> 2) / HT;
-          s_w1t[e] = a.w1[(16 * t + 4 * (ln >> 4) + r) * C + 16 * i + (ln & 15)]; }
+    {   // coalesced float4 loads, a matrix at a time, then float4 LDS stores (see stage_weights): a float4 of W2's row 4 s + kq at columns
+        // 16 t + li0 .. + 3 is lanes (li0 .. li0 + 3, kq) of (t, s); a float4 of W1's row 16 t + 4 kq + r at columns 16 i + li0 .. + 3 is
+        // lanes (li0 .. + 3, kq) of (i, t, r)
+        constexpr int N4 = HID * C / 1024;
+        f32x4 v[N4];
+#pragma unroll
+        for (int u = 0; u < N4; ++u) v[u] = *reinterpret_cast<const f32x4*>(a.w2 + (size_t)(tid + u * 256) * 4);
+#pragma unroll
+        for (int u = 0; u < N4; ++u) {
+            const int e4 = tid + u * 256, row = e4 / (HID / 4), q4 = e4 - row * (HID / 4), col0 = 4 * q4;
+            const int t = col0 >> 4, li0 = col0 & 15, sq = row >> 2, kq = row & 3;
+            *reinterpret_cast<f32x4*>(s_w2t + (t * KS1 + sq) * 64 + kq * 16 + li0) = v[u];
+        }
+#pragma unroll
+        for (int u = 0; u < N4; ++u) v[u] = *reinterpret_cast<const f32x4*>(a.w1 + (size_t)(tid + u * 256) * 4);
+#pragma unroll
+        for (int u = 0; u < N4; ++u) {
+            const int e4 = tid + u * 256, row = e4 / (C / 4), c4 = e4 - row * (C / 4), col0 = 4 * c4;
+            const int i = col0 >> 4, li0 = col0 & 15, t = row >> 4, kq = (row & 15) >> 2, r = row & 3;
+            *reinterpret_cast<f32x4*>(s_w1t + ((i * HT + t) * 4 + r) * 64 + kq * 16 + li0) = v[u];
+        }
     }
     __syncthreads();
     const int tiles_per_b = (a.HW + 16 * CNX_NT - 1) / (16 * CNX_NT);
@@ -306,17 +339,19 @@ __global__ __launch_bounds__(256) void cnx_mlp_bwd_kernel(const MlpArgs a) {
 #pragma unroll
                 for (int n = 0; n < CNX_NT; ++n) dg[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt, yf[n][s], dg[n], 0, 0, 0);
             }
+            // gelu and gelu' together (common.h gelu_pair4_f: one shared exp2 + one rcp per element instead of two erff and an expf --
+            // 64 such triples per 16-pixel tile were ~13 us of a wave's ~34 us chain)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int hid = 16 * t + 4 * kq + r;
+            for (int n = 0; n < CNX_NT; ++n) {
+                f32x4 gv, gd;
+                gelu_pair4_f(f32x4{pre[n][0], pre[n][1], pre[n][2], pre[n][3]}, &gv, &gd);
 #pragma unroll
-                for (int n = 0; n < CNX_NT; ++n) {
-                    const float gv = gelu_f(pre[n][r]);
-                    const float dh = dg[n][r] * gelu_grad_f(pre[n][r]);
+                for (int r = 0; r < 4; ++r) {
+                    const float dh = dg[n][r] * gd[r];
                     dg[n][r] = dh;
                     if (px[n] < a.HW) {
-                        const size_t idx = ((size_t)b * HID + hid) * a.HW + px[n];
-                        a.gbuf[idx] = gv;
+                        const size_t idx = ((size_t)b * HID + 16 * t + 4 * kq + r) * a.HW + px[n];
+                        a.gbuf[idx] = gv[r];
                         a.dhbuf[idx] = dh;
                     }
                 }
@@ -342,22 +377,30 @@ __global__ __launch_bounds__(256) void cnx_mlp_bwd_kernel(const MlpArgs a) {
     }
 }
 
-template <int C>
-int launch_mlp(hipStream_t st, const MlpArgs& a, bool bwd) {
+template <int C, int NT>
+int launch_mlp_nt(hipStream_t st, const MlpArgs& a, bool bwd) {
     const size_t lds = (size_t)2 * 4 * C * C * sizeof(float);
-    const int total = a.B * cdiv(a.HW, 16 * CNX_NT);
+    const int total = a.B * cdiv(a.HW, 16 * NT);
     int grid = cdiv(total, 4);
     const int cap = 256 * (lds > 80 * 1024 ? 1 : 2);
     if (grid > cap) grid = cap;
     if (bwd) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnx_mlp_bwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(cnx_mlp_bwd_kernel<C>, dim3(grid), dim3(256), lds, st, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnx_mlp_bwd_kernel<C, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((cnx_mlp_bwd_kernel<C, NT>), dim3(grid), dim3(256), lds, st, a);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnx_mlp_fwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(cnx_mlp_fwd_kernel<C>, dim3(grid), dim3(256), lds, st, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cnx_mlp_fwd_kernel<C, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((cnx_mlp_fwd_kernel<C, NT>), dim3(grid), dim3(256), lds, st, a);
     }
     BNERV_LAUNCH_CHECK(bwd ? "cnx_mlp_bwd" : "cnx_mlp_fwd");
     return BNERV_OK;
+}
+
+template <int C>
+int launch_mlp(hipStream_t st, const MlpArgs& a, bool bwd) {
+    // one 16-pixel tile per wave while that still leaves every wave at most one item (1024 wave slots at one block per CU)
+    static const int nt1_max = [] { const char* e = getenv("BNERV_CNX_NT1_MAX"); return e ? atoi(e) : 16384; }();     // (A/B switch: pixels)
+    if ((long)a.B * a.HW <= nt1_max) return launch_mlp_nt<C, 1>(st, a, bwd);
+    return launch_mlp_nt<C, 2>(st, a, bwd);
 }
 
 int launch_mlp_c(hipStream_t st, const MlpArgs& a, bool bwd) {
@@ -457,6 +500,7 @@ extern "C" int bnerv_dense_gemm_bwd(void* stream, const float* x, const float* w
 extern "C" int bnerv_cnx_mlp_fwd(void* stream, const float* x, const float* inp, const float* w1, const float* b1, const float* w2, const float* b2,
                                  const float* gamma, float* out, float* hsave, int B, int C, int HW) {
     BNERV_REQUIRE(x && inp && w1 && b1 && w2 && b2 && out && B > 0 && HW > 0, "cnx_mlp_fwd: bad args");
+    BNERV_REQUIRE(((reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2)) & 15) == 0, "cnx_mlp_fwd: weights must be 16-byte aligned");
     MlpArgs a{};
     a.x = x; a.inp = inp; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.gamma = gamma; a.out = out; a.hsave = hsave;
     a.B = B; a.C = C; a.HW = HW;
@@ -468,6 +512,7 @@ extern "C" int bnerv_cnx_mlp_fwd(void* stream, const float* x, const float* inp,
 extern "C" int bnerv_cnx_mlp_bwd(void* stream, const float* h1, const float* dout, const float* w1, const float* w2, const float* gamma,
                                  float* dx, float* gbuf, float* dhbuf, int B, int C, int HW) {
     BNERV_REQUIRE(h1 && dout && w1 && w2 && dx && gbuf && dhbuf && B > 0 && HW > 0, "cnx_mlp_bwd: bad args");
+    BNERV_REQUIRE(((reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2)) & 15) == 0, "cnx_mlp_bwd: weights must be 16-byte aligned");
     MlpArgs a{};
     a.hin = h1; a.dout = dout; a.w1 = w1; a.w2 = w2; a.gamma = gamma; a.dx = dx; a.gbuf = gbuf; a.dhbuf = dhbuf;
     a.B = B; a.C = C; a.HW = HW;
