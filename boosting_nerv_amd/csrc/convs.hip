@@ -27,6 +27,37 @@ __global__ __launch_bounds__(256, 4) void conv_small_kernel(const SArgs sa) {
     conv_small_body<IN, EP, NQ>(sa, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
+// the same body with 96 staged channels (NQ = 24: 112 KB of LDS, ~150 registers -- one block per CU, which is all a <= 32 x 32 image fills anyway)
+template <int IN, int EP>
+__global__ __launch_bounds__(256, 1) void conv_small96_kernel(const SArgs sa) {
+    conv_small_body<IN, EP, 24>(sa, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+template <int IN, int EP>
+int launch_small96(hipStream_t st, const SArgs& sa) {
+    const bnerv_conv_desc& d = sa.d;
+    const size_t lds = convs_lds_bytes<24>();
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small96_kernel<IN, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv_small96_kernel<IN, EP>), dim3(sa.tiles_x * sa.tiles_y, cdiv(d.Cout, 16), d.B), dim3(256), lds, st, sa);
+    BNERV_LAUNCH_CHECK("conv_small96");
+    return BNERV_OK;
+}
+// (instantiated for the TAT convs and their data gradients only: HNeRV-boost's decoder[0], 95 -> 95 at 9 x 16, model_hnerv.py:200-202)
+template <int IN, int EP>
+constexpr bool small96_combo() {
+    return (IN == BNERV_IN_AFFINE && (EP == BNERV_EP_BIAS_GELU || EP == BNERV_EP_BIAS_RES)) ||
+           (IN == BNERV_IN_PLAIN && (EP == BNERV_EP_DGELU_SAVED || EP == BNERV_EP_DSIN));
+}
+static bool small96_shape(const bnerv_conv_desc& d) {
+    static const bool off = [] { const char* e = getenv("BNERV_SMALL96"); return e && e[0] == '0'; }();     // A/B switch
+    if (off || d.in_mode == BNERV_IN_UNSHUFFLE || d.Cin <= 32 || d.Cin > 96 || d.out_s != 1 || d.in_s != 1 || (size_t)d.H * d.W > 1024) return false;
+    const int i = d.in_mode, e = d.ep_mode;
+    return (i == BNERV_IN_AFFINE && (e == BNERV_EP_BIAS_GELU || e == BNERV_EP_BIAS_RES)) || (i == BNERV_IN_PLAIN && (e == BNERV_EP_DGELU_SAVED || e == BNERV_EP_DSIN));
+}
+
 template <int IN, int EP, int NQ>
 int launch_small(hipStream_t st, const SArgs& sa) {
     const bnerv_conv_desc& d = sa.d;
@@ -44,7 +75,10 @@ int launch_small(hipStream_t st, const SArgs& sa) {
 template <int IN, int EP>
 int launch_small_nq(hipStream_t st, const SArgs& sa) {
     if constexpr (IN == BNERV_IN_UNSHUFFLE) return sa.d.Cin <= 32 ? launch_small<IN, EP, 8>(st, sa) : launch_small<IN, EP, 16>(st, sa);
-    else return sa.d.Cin <= 16 ? launch_small<IN, EP, 4>(st, sa) : launch_small<IN, EP, 8>(st, sa);
+    else {
+        if constexpr (small96_combo<IN, EP>()) { if (sa.d.Cin > 32) return launch_small96<IN, EP>(st, sa); }
+        return sa.d.Cin <= 16 ? launch_small<IN, EP, 4>(st, sa) : launch_small<IN, EP, 8>(st, sa);
+    }
 }
 
 }  // namespace
@@ -57,7 +91,10 @@ bool bnerv_convs_shape_ok(const bnerv_conv_desc& d, int vec) {
     static const size_t px_up = [] { const char* e = getenv("BNERV_SMALL_MAXPX_UP"); return e ? (size_t)atol(e) : (size_t)65536; }();     // (A/B switches)
     static const size_t px_uns = [] { const char* e = getenv("BNERV_SMALL_MAXPX_UNS"); return e ? (size_t)atol(e) : (size_t)65536; }();
     const size_t max_px = uns ? px_uns : (d.out_s == 2 && d.Cout >= 32) ? px_up : 16384;
-    if (!(vec && d.k == 3 && d.Cin <= (uns ? 64 : 32) && (size_t)d.H * d.W <= max_px && d.B <= 65535 && cdiv(d.Cout, 16) <= 65535)) return false;
+    // (33..96 input channels on an image of <= 1024 pixels: the 96-channel staging of conv_small96_kernel -- round 5 ran HNeRV-boost's
+    //  95 -> 95 TAT convs at 9 x 16 on the generic kernel's 12 blocks: 47-53 us per launch for 0.2 GFLOP)
+    const int cin_max = uns ? 64 : (small96_shape(d) ? 96 : 32);
+    if (!(vec && d.k == 3 && d.Cin <= cin_max && (size_t)d.H * d.W <= max_px && d.B <= 65535 && cdiv(d.Cout, 16) <= 65535)) return false;
     if (uns) return d.in_s == 2 && (d.Cin & 3) == 0 && d.ep_mode == BNERV_EP_PLAIN && d.out_s == 1 && (size_t)d.B * d.Cin * d.H * d.W * 4 < LEAN_MAX_BYTES;
     if (d.in_s != 1) return false;
     if (d.Cin <= 12 && d.Cout <= 12) return false;                 // the 12-channel layers have their own family (conv4.hip)

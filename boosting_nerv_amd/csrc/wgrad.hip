@@ -1587,6 +1587,7 @@ static int small_pair_try(hipStream_t st, const bnerv_conv_desc& c, WArgs& wa, i
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const int cvec = ((c.W % 4 == 0) && al(c.x) && al(c.out) && al(c.out2) && al(c.aux0) && al(c.aux1) && al(c.aux2)) ? 1 : 0;
     if (!bnerv_convs_shape_ok(c, cvec)) return 1;
+    if (c.in_mode != BNERV_IN_UNSHUFFLE && c.Cin > 32) return 1;                           // (convs.hip's 96-channel form has no paired instantiation)
     if (c.ep_mode == BNERV_EP_PLAIN && bnerv_conv_splitk_ws_bytes(&c) != 0) return 1;     // (a split-K layer: its own launches)
     if (!(w.k == 3 && w.B == c.B && w.H == c.H && w.W == c.W && w.defer_finish && w.ctx && w.ctx == c.ctx)) return 1;
     bnerv_convs::SArgs sa;

@@ -246,7 +246,9 @@ def _tat_ref(x0, mods, w0, b0, w1, b1):
     return x0 + F.conv2d(f * (s1 + 1) + t1, w1, b1, padding=1)
 
 
-@pytest.mark.parametrize("shape", [(1, 12, 16, 64), (2, 15, 11, 13), (1, 30, 45, 80), (2, 38, 9, 40), (2, 55, 17, 36), (1, 95, 10, 44), (3, 17, 8, 32)])
+# (95 x 9 x 16, 64 x 20 x 48 and 33 x 7 x 12: the 96-channel staging of convs.hip's low-resolution family -- HNeRV-boost's decoder[0])
+@pytest.mark.parametrize("shape", [(1, 12, 16, 64), (2, 15, 11, 13), (1, 30, 45, 80), (2, 38, 9, 40), (2, 55, 17, 36), (1, 95, 10, 44), (3, 17, 8, 32),
+                                   (1, 95, 9, 16), (2, 64, 20, 48), (1, 33, 7, 12)])
 def test_tat_block(ops, shape):
     x0, mods, w0, b0, w1, b1, g = _tat_inputs(*shape, seed=7)
     ref = _tat_ref(x0, mods, w0, b0, w1, b1)
