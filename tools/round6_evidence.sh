@@ -16,7 +16,7 @@ if [ "${1:-}" != fast ]; then
 fi
 for c in c1 c3 c4; do
   rm -rf /tmp/ks_$c
-  rocprofv3 --kernel-trace --stats -d /tmp/ks_$c -- python $R/bench.py --config $c --steps 20 --warmup 5 --steps_only > /tmp/ks_$c.log 2>&1
+  BNERV_BENCH_SETTLE_MS=0 rocprofv3 --kernel-trace --stats -d /tmp/ks_$c -- python $R/bench.py --config $c --steps 20 --warmup 5 --steps_only > /tmp/ks_$c.log 2>&1
   { echo "# Round 6 -- $c: rocprofv3 --kernel-trace --stats -- python bench.py --config $c --steps 20 --warmup 5 --steps_only (MI355X)";
     echo "# The table covers the step kernels of the whole process: 3 eager + 1 recording + 21 replayed steps (no micro-benchmark, no eval)."; echo;
     python $R/tools/prof_summary.py /tmp/ks_$c 25 40; } > $O/r06_${c}_step_kerneltrace.md 2>&1
