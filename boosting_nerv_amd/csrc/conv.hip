@@ -26,6 +26,7 @@ int bnerv_convbf_try(hipStream_t st, const bnerv_conv_desc& d, int vec, int kspl
 namespace bnerv_conv { struct KArgs; }
 int bnerv_conv4_try(hipStream_t st, bnerv_conv::KArgs& ka);   // conv4.hip: 1 = not that family's layer
 int bnerv_convs_try(hipStream_t st, const bnerv_conv_desc& d, int vec, int ksplit);   // convs.hip (low-resolution stages): 1 = not that family's layer
+int bnerv_head3_try(hipStream_t st, const bnerv_conv_desc& d);            // head3.hip (3x3 head with 3 outputs: forward + tanh, data gradient): 1 = not that layer
 bool bnerv_convs_shape_ok(const bnerv_conv_desc& d, int vec);
 int bnerv_stem_dgrad_try(hipStream_t st, const bnerv_conv_desc& d);       // stem.hip (images of <= 256 pixels, long K): 1 = not that layer
 size_t bnerv_stem_dgrad_ws_bytes(const bnerv_conv_desc& d);
@@ -1752,6 +1753,10 @@ extern "C" int bnerv_conv_igemm(void* stream, const bnerv_conv_desc* dp) {
         hipLaunchKernelGGL(head1x1_dgrad_kernel, dim3(cdiv(hw4, 256), d.B), dim3(256), 0, st, d, hw4);
         BNERV_LAUNCH_CHECK("head1x1_dgrad");
         return BNERV_OK;
+    }
+    if (d.k == 3 && (d.Cout == 3 || d.Cin == 3) && ka.ksplit == 1) {      // HNeRV-boost's 3x3 head and its data gradient: streaming VALU kernels
+        const int rh = bnerv_head3_try(st, d);
+        if (rh != 1) return rh;
     }
     if (d.ep_mode == BNERV_EP_PLAIN && d.partial != nullptr) {            // tiny image, long K (the stem up-conv's data gradient)
         const int rs = bnerv_stem_dgrad_try(st, d);

@@ -714,9 +714,9 @@ class _HeadTanh(torch.autograd.Function):
             sb = torch.empty(Cin, dtype=torch.float32, device=x.device)           # (the swapped call's "bias gradient": channel sums of x, unused)
             _wgrad(gt, x, sw, sb, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_PLAIN, g_mode=L.IN_UNSHUFFLE)
             dw = sw.permute(1, 0, 2, 3).flip(2, 3).contiguous()
-            if ctx.needs_input_grad[0]:
+            if ctx.needs_input_grad[0]:           # (gt is a tensor now: the data gradient reads 3 planes instead of 6 -- csrc/head3.hip, 78 against 91 us at 1080p)
                 dx = torch.empty_like(x)
-                _conv(g, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_TANHGRAD, ep_mode=L.EP_PLAIN, transposed=1, aux0=img)
+                _conv(gt, w, None, dx, B=B, Cin=Cout, Cout=Cin, H=H, W=W, k=k, in_mode=L.IN_PLAIN, ep_mode=L.EP_PLAIN, transposed=1)
         elif ctx.needs_input_grad[0]:
             # (dW | dx) of the head: one streaming pass where the library pairs them (1x1, tanh-grad prologue), the two launches otherwise
             dx = torch.empty_like(x)
