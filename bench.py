@@ -302,6 +302,7 @@ def cpu_baseline(args, model_cpu_sd, frames, norm_idxs, budget_s=30.0, max_steps
     best = max(sweep, key=sweep.get)
     torch.set_num_threads(best)
     n, t0 = 0, time.time()
+    step_ts = []
     if slow:
         # the best setting's sweep step counts; more steps only while the whole baseline stays inside 4 x the budget
         n, dt = sweep_t[best]
@@ -310,11 +311,15 @@ def cpu_baseline(args, model_cpu_sd, frames, norm_idxs, budget_s=30.0, max_steps
             n += 1
     else:
         while n < max_steps and (n == 0 or (time.time() - t_all) < budget_s + 15.0) and (n == 0 or time.time() - t0 < budget_s):
-            one()
+            step_ts.append(one())
             n += 1
         dt = time.time() - t0
+    spread = None
+    if step_ts:
+        st = sorted(step_ts)
+        spread = {"min": round(st[0], 3), "median": round(st[len(st) // 2], 3), "max": round(st[-1], 3)}     # (the mean above is the reported rate; host steps vary with thread placement)
     return {"value": round(n / dt, 4), "unit": "frames/s", "cores": best, "host_cores": hw, "kind": "port", "cpu": cpu_model_string(),
-            "sweep_frames_per_s_by_threads": sweep or None,
+            "sweep_frames_per_s_by_threads": sweep or None, "step_seconds": spread,
             "sample": f"{n} timed full train steps (fwd + {args.loss} + bwd + Adan) of the same model / frame size at the best of the swept thread counts "
                       f"({best} threads; sweep: {'1 timed step per setting, a step takes more than a tenth of the budget' if slow else '1 untimed + 2 timed steps per setting'}), "
                       f"oracle/cpu_ref.py on torch CPU fp32, timed budget {budget_s:.0f} s"}
