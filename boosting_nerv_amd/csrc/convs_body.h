@@ -2,6 +2,7 @@
 // next to the weight gradient that reads the same incoming gradient.  See convs.hip for the design.
 #pragma once
 #include "common.h"
+#include <type_traits>
 #include "sidejob.h"
 #include "conv_common.h"
 
@@ -123,6 +124,13 @@ __device__ __forceinline__ void conv_small_body(const SArgs& sa, const int tile,
         }
 #pragma unroll
         for (int u = 0; u < NWL; ++u) { const int i = tid + u * 256; if (i < ncopy) s_w[i] = wv[u]; }
+        // the last channel quad may reach up to 3 channels past Cin: zero what it reads beyond the slice (forward: the 36 floats after the
+        // last row; transposed: the [ci][16][9] segments of the missing channels), so that 0 (the A side) meets a finite number
+        if (Cin & 3) {
+            const int tail = d.transposed ? (4 - (Cin & 3)) * 144 : 36;
+            if (tid < tail && ncopy + tid < 16 * NCH * 9) s_w[ncopy + tid] = 0.f;
+            if (tid + 256 < tail && ncopy + tid + 256 < 16 * NCH * 9) s_w[ncopy + tid + 256] = 0.f;
+        }
     }
     if constexpr (UNS) {
 #pragma unroll
@@ -153,25 +161,44 @@ __device__ __forceinline__ void conv_small_body(const SArgs& sa, const int tile,
     }
     __syncthreads();
 
-    // ---- K loop: A = pixel li of the wave's row, channel 4q + kq ; B = W(co_base + li, 4q + kq, tap) from the raw slice
+    // ---- K loop: A = pixel li of the wave's row, channel 4q + kq ; B = W(co_base + li, 4q + kq, tap) from the raw slice.
+    // One channel quad per iteration of a REAL loop over the quads that exist (pointer bumps; every LDS address inside the body is base +
+    // immediate), two quads per trip so that quad q + 1's eighteen operands are in flight under quad q's nine MFMAs in two fixed register
+    // sets -- round 5's form was a chain of per-quad uniform branches with a select per operand, ~80 cycles per MFMA at one wave per SIMD
+    // (tools/ksmall.py ablation: 2.6 of a 60-block launch's 7.3 us).  Channels beyond Cin in the last quad: their A planes are zero and
+    // their weights are finite (the next row of the slice, or the zero-filled tail above), so the products vanish without a select.
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* a_base = s_in + kq * SPLANE + wave * SRS + li + SCOL0;
-    const float* b_base = d.transposed ? s_w + (kq * 16 + li) * 9 : s_w + li * Cin * 9 + kq * 9;
+    const float* ap = s_in + kq * SPLANE + wave * SRS + li + SCOL0;
+    const float* bp = d.transposed ? s_w + (kq * 16 + li) * 9 : s_w + li * Cin * 9 + kq * 9;
     const int b_qstep = d.transposed ? 4 * 144 : 36;           // + 4 input channels
-    const bool ci_tail = (Cin & 3) != 0;                       // the last quad reads beyond Cin: those weights must count as zero
+    const int nq = (BNERV_ABLS & 4) && d.B > 0 ? 0 : min(NQ, (Cin + 3) >> 2);
+    auto ld = [&](const float* a, const float* b, float (&av)[9], float (&bv)[9], auto tr) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (4 * q < Cin && !((BNERV_ABLS & 4) && d.B > 0)) {   // block-uniform
-            const bool bvalid = !ci_tail || (4 * q + kq < Cin);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float av = a_base[q * 4 * SPLANE + (t / 3) * SRS + (t % 3)];
-                float bv = b_base[q * b_qstep + (d.transposed ? 8 - t : t)];
-                bv = bvalid ? bv : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-            }
+        for (int t = 0; t < 9; ++t) {
+            av[t] = a[(t / 3) * SRS + (t % 3)];
+            bv[t] = b[decltype(tr)::value ? 8 - t : t];
         }
-    }
+    };
+    auto kloop = [&](auto tr) __attribute__((always_inline)) {
+        float a0[9], b0[9], a1[9], b1[9];
+        if (nq > 0) ld(ap, bp, a0, b0, tr);
+        int q = 0;
+#pragma unroll 1
+        for (; q + 1 < nq; q += 2) {
+            ld(ap + 4 * SPLANE, bp + b_qstep, a1, b1, tr);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b0[t], acc, 0, 0, 0);
+            ap += 8 * SPLANE; bp += 2 * b_qstep;
+            if (q + 2 < nq) ld(ap, bp, a0, b0, tr);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], b1[t], acc, 0, 0, 0);
+        }
+        if (q < nq) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b0[t], acc, 0, 0, 0);
+        }
+    };
+    if (d.transposed) kloop(std::true_type{}); else kloop(std::false_type{});
 
     // ---- epilogue from the accumulator: lane (li, kq) = output channel co_base + li, pixels (row wave, columns 4 kq .. 4 kq + 3)
     const int co = co_base + li, gy = ty0 + wave, gx = tx0 + 4 * kq;
